@@ -1,0 +1,214 @@
+/*
+ * cdc_oracle.c -- TEST INFRASTRUCTURE ONLY. CPU restatement (plain C + OpenMP) of the
+ * tensor primitives on the CDC decode hot path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product (cdc_compression_amd/)
+ * must never import, link or call it.
+ *
+ * The reference (/root/reference, pure-Python PyTorch) delegates this arithmetic to ATen:
+ *   nn.Conv2d            xparam/modules/network_components.py:50,87,105,125-126 ; unet.py:104
+ *   nn.ConvTranspose2d   xparam/modules/network_components.py:39
+ *   LayerNorm (channel)  xparam/modules/network_components.py:56-66
+ *   LinearAttention core xparam/modules/network_components.py:128-139
+ * ATen itself is not under /root/reference (pinned pytorch=2.0.0, environment.yml:130), so the
+ * published semantics of those ops are restated here (NCHW fp32, zero padding,
+ * cross-correlation, biased variance) and pinned against outputs of the real reference
+ * generated in the build container (tests/golden/make_golden.py -> tests/golden/*.npz).
+ *
+ * Accumulation type: ORC_ACC (float by default = the CPU baseline; -DORC_ACC=double builds the
+ * tight checker used to measure fp32 round-off of both the reference and the HIP path).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef ORC_ACC
+#define ORC_ACC float
+#endif
+typedef ORC_ACC acc_t;
+
+#define CO_BLK 4
+
+/* y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[b,ci,oy*s+ky-p,ox*s+kx-p]
+ * (torch.nn.functional.conv2d semantics; reference call sites listed above). */
+void orc_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cin,
+                int H, int W, int Cout, int KH, int KW, int stride, int pad)
+{
+    const int Ho = (H + 2 * pad - KH) / stride + 1;
+    const int Wo = (W + 2 * pad - KW) / stride + 1;
+#pragma omp parallel
+    {
+        acc_t *acc = (acc_t *)malloc(sizeof(acc_t) * CO_BLK * Wo);
+#pragma omp for collapse(3) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int cb = 0; cb < (Cout + CO_BLK - 1) / CO_BLK; ++cb)
+                for (int oy = 0; oy < Ho; ++oy) {
+                    const int co0 = cb * CO_BLK;
+                    const int nco = (Cout - co0) < CO_BLK ? (Cout - co0) : CO_BLK;
+                    for (int j = 0; j < nco; ++j) {
+                        const acc_t bv = bias ? (acc_t)bias[co0 + j] : (acc_t)0;
+                        for (int ox = 0; ox < Wo; ++ox) acc[j * Wo + ox] = bv;
+                    }
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int ky = 0; ky < KH; ++ky) {
+                            const int iy = oy * stride + ky - pad;
+                            if (iy < 0 || iy >= H) continue;
+                            const float *xr = x + (((size_t)b * Cin + ci) * H + iy) * W;
+                            for (int kx = 0; kx < KW; ++kx) {
+                                /* valid ox range: 0 <= ox*stride + kx - pad < W */
+                                int lo = pad - kx;
+                                lo = lo > 0 ? (lo + stride - 1) / stride : 0;
+                                int hi = (W - 1 + pad - kx) / stride; /* inclusive */
+                                if (W - 1 + pad - kx < 0) continue;
+                                if (hi > Wo - 1) hi = Wo - 1;
+                                const float *xs = xr + kx - pad;
+                                for (int j = 0; j < nco; ++j) {
+                                    const acc_t wv =
+                                        (acc_t)w[(((size_t)(co0 + j) * Cin + ci) * KH + ky) * KW + kx];
+                                    acc_t *a = acc + j * Wo;
+                                    if (stride == 1) {
+                                        for (int ox = lo; ox <= hi; ++ox) a[ox] += wv * (acc_t)xs[ox];
+                                    } else {
+                                        for (int ox = lo; ox <= hi; ++ox)
+                                            a[ox] += wv * (acc_t)xs[ox * stride];
+                                    }
+                                }
+                            }
+                        }
+                    for (int j = 0; j < nco; ++j) {
+                        float *yr = y + (((size_t)b * Cout + co0 + j) * Ho + oy) * Wo;
+                        for (int ox = 0; ox < Wo; ++ox) yr[ox] = (float)acc[j * Wo + ox];
+                    }
+                }
+        free(acc);
+    }
+}
+
+/* torch.nn.functional.conv_transpose2d semantics, weight layout [Cin][Cout][KH][KW]
+ * (reference: Upsample, network_components.py:34-42 ; hyper_dec, compress_modules.py:166-177):
+ * y[b,co,iy*s-p+ky, ix*s-p+kx] += x[b,ci,iy,ix] * w[ci,co,ky,kx] ; Ho=(H-1)*s-2p+KH+outpad. */
+void orc_conv_transpose2d(const float *x, const float *w, const float *bias, float *y, int B,
+                          int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                          int outpad)
+{
+    const int Ho = (H - 1) * stride - 2 * pad + KH + outpad;
+    const int Wo = (W - 1) * stride - 2 * pad + KW + outpad;
+#pragma omp parallel
+    {
+        acc_t *acc = (acc_t *)malloc(sizeof(acc_t) * (size_t)Ho * Wo);
+#pragma omp for collapse(2) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int co = 0; co < Cout; ++co) {
+                const acc_t bv = bias ? (acc_t)bias[co] : (acc_t)0;
+                for (int i = 0; i < Ho * Wo; ++i) acc[i] = bv;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float *xp = x + ((size_t)b * Cin + ci) * H * W;
+                    const float *wp = w + ((size_t)ci * Cout + co) * KH * KW;
+                    for (int ky = 0; ky < KH; ++ky)
+                        for (int kx = 0; kx < KW; ++kx) {
+                            const acc_t wv = (acc_t)wp[ky * KW + kx];
+                            for (int iy = 0; iy < H; ++iy) {
+                                const int oy = iy * stride - pad + ky;
+                                if (oy < 0 || oy >= Ho) continue;
+                                for (int ix = 0; ix < W; ++ix) {
+                                    const int ox = ix * stride - pad + kx;
+                                    if (ox < 0 || ox >= Wo) continue;
+                                    acc[oy * Wo + ox] += wv * (acc_t)xp[iy * W + ix];
+                                }
+                            }
+                        }
+                }
+                float *yp = y + ((size_t)b * Cout + co) * Ho * Wo;
+                for (int i = 0; i < Ho * Wo; ++i) yp[i] = (float)acc[i];
+            }
+        free(acc);
+    }
+}
+
+/* Channel LayerNorm, reference network_components.py:56-66:
+ *   var = torch.var(x, dim=1, unbiased=False); mean = torch.mean(x, dim=1)
+ *   (x - mean) / (var + eps).sqrt() * g + b                                  */
+void orc_chan_layernorm(const float *x, const float *g, const float *bb, float *y, int B, int C,
+                        int HW, float eps)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < HW; ++p) {
+            const float *xp = x + (size_t)b * C * HW + p;
+            float *yp = y + (size_t)b * C * HW + p;
+            acc_t s = 0;
+            for (int c = 0; c < C; ++c) s += (acc_t)xp[(size_t)c * HW];
+            const acc_t mean = s / (acc_t)C;
+            acc_t v = 0;
+            for (int c = 0; c < C; ++c) {
+                const acc_t d = (acc_t)xp[(size_t)c * HW] - mean;
+                v += d * d;
+            }
+            const acc_t var = v / (acc_t)C;
+            const acc_t den = (acc_t)sqrt((double)(var + (acc_t)eps));
+            for (int c = 0; c < C; ++c) {
+                const acc_t xn = ((acc_t)xp[(size_t)c * HW] - mean) / den;
+                yp[(size_t)c * HW] = (float)(xn * (acc_t)g[c] + (acc_t)bb[c]);
+            }
+        }
+}
+
+/* LinearAttention core (heads=1), reference network_components.py:128-137:
+ *   q,k,v = qkv.chunk(3, dim=1) as [B][C][N];  q = q*scale;  k = k.softmax(dim=-1)
+ *   context[d,e] = sum_n k[d,n] v[e,n];  out[e,n] = sum_d context[d,e] q[d,n]       */
+void orc_linear_attention_core(const float *qkv, float *out, int B, int C, int N, float scale)
+{
+#pragma omp parallel
+    {
+        float *ks = (float *)malloc(sizeof(float) * (size_t)C * N);
+        acc_t *ctx = (acc_t *)malloc(sizeof(acc_t) * (size_t)C * C);
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            const float *q = qkv + (size_t)b * 3 * C * N;
+            const float *k = q + (size_t)C * N;
+            const float *v = k + (size_t)C * N;
+            for (int d = 0; d < C; ++d) {
+                const float *kr = k + (size_t)d * N;
+                float m = kr[0];
+                for (int n = 1; n < N; ++n) m = kr[n] > m ? kr[n] : m;
+                acc_t z = 0;
+                for (int n = 0; n < N; ++n) {
+                    const float e = expf(kr[n] - m);
+                    ks[(size_t)d * N + n] = e;
+                    z += (acc_t)e;
+                }
+                for (int n = 0; n < N; ++n)
+                    ks[(size_t)d * N + n] = (float)((acc_t)ks[(size_t)d * N + n] / z);
+            }
+            for (int d = 0; d < C; ++d)
+                for (int e = 0; e < C; ++e) {
+                    acc_t s = 0;
+                    const float *kr = ks + (size_t)d * N, *vr = v + (size_t)e * N;
+                    for (int n = 0; n < N; ++n) s += (acc_t)kr[n] * (acc_t)vr[n];
+                    ctx[(size_t)d * C + e] = s;
+                }
+            float *o = out + (size_t)b * C * N;
+            for (int e = 0; e < C; ++e) {
+                float *orow = o + (size_t)e * N;
+                for (int n = 0; n < N; ++n) orow[n] = 0.f;
+            }
+            /* out[e,n] = sum_d ctx[d,e] * (q[d,n]*scale) ; accumulate d-outer for contiguity */
+            for (int e = 0; e < C; ++e) {
+                acc_t *tmp = (acc_t *)malloc(sizeof(acc_t) * N);
+                for (int n = 0; n < N; ++n) tmp[n] = 0;
+                for (int d = 0; d < C; ++d) {
+                    const acc_t cv = ctx[(size_t)d * C + e];
+                    const float *qr = q + (size_t)d * N;
+                    for (int n = 0; n < N; ++n) tmp[n] += cv * (acc_t)(qr[n] * scale);
+                }
+                float *orow = o + (size_t)e * N;
+                for (int n = 0; n < N; ++n) orow[n] = (float)tmp[n];
+                free(tmp);
+            }
+        }
+        free(ks);
+        free(ctx);
+    }
+}
+
+int orc_acc_bytes(void) { return (int)sizeof(acc_t); }

@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (buggyyang/CDC_compression at /root/reference).
+
+Runs only in the build container (the reference cannot travel to the GPU box).  It imports the
+reference's own modules (with a stub `lpips`, which the decode path never calls), injects the
+deterministic synthetic parameters of cdc_compression_amd.synth, runs the reference's PyTorch CPU
+path, and stores inputs + expected outputs as small .npz / .json fixtures in this directory.
+
+    python tests/golden/make_golden.py            # regenerate everything (~2-3 min, 8 cores)
+
+Fixtures are data only: no reference source text is stored.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from cdc_compression_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference(tree):
+    """Import `modules.*` of one reference tree (xparam | epsilonparam) under a private name."""
+    sys.modules["lpips"] = types.SimpleNamespace(LPIPS=lambda **k: None)
+    for k in [k for k in sys.modules if k == "modules" or k.startswith("modules.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, tree))
+    try:
+        import modules.unet as unet
+        import modules.denoising_diffusion as dd
+        import modules.compress_modules as cm
+        import modules.network_components as nc
+    finally:
+        sys.path.pop(0)
+    return types.SimpleNamespace(unet=unet, dd=dd, cm=cm, nc=nc)
+
+
+def manifest_of(module):
+    return [(k, list(v.shape)) for k, v in module.state_dict().items()]
+
+
+def load_synth(module, seed, final_gain=1.0):
+    man = manifest_of(module)
+    sd = synth.unet_state_dict(man, seed=seed, final_gain=final_gain)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    module.eval()
+    return man, sd
+
+
+def digest(a, nsample=64, seed=11):
+    a = np.asarray(a, np.float32)
+    flat = a.reshape(-1)
+    idx = (synth._splitmix64(np.arange(nsample, dtype=np.uint64) + np.uint64(seed * 1000))
+           % np.uint64(flat.size)).astype(np.int64)
+    return {"shape": list(a.shape), "sum": float(flat.astype(np.float64).sum()),
+            "sumsq": float((flat.astype(np.float64) ** 2).sum()),
+            "idx": idx, "val": flat[idx].copy()}
+
+
+CONFIGS = {
+    # name: (tree, unet kwargs, ctx channel list, H, W, B)
+    "small_x": ("xparam", dict(dim=16, channels=3, context_channels=8, dim_mults=(1, 2, 3),
+                               context_dim_mults=(1, 2), embd_type="01"), [8, 16], 32, 32, 2),
+    "small_eps": ("epsilonparam", dict(dim=16, channels=3, context_channels=3,
+                                       dim_mults=(1, 2, 3), context_dim_mults=(1, 2)),
+                  [3, 16], 32, 32, 2),
+    "odd_x": ("xparam", dict(dim=24, channels=3, context_channels=5, dim_mults=(1, 3),
+                             context_dim_mults=(1,), embd_type="01"), [5], 24, 40, 1),
+    "full_x": ("xparam", dict(dim=64, channels=3, context_channels=64,
+                              dim_mults=(1, 2, 3, 4, 5, 6), context_dim_mults=(1, 2, 3, 4),
+                              embd_type="01"), [64, 64, 128, 192], 64, 64, 1),
+    "full_eps": ("epsilonparam", dict(dim=64, channels=3, context_channels=3,
+                                      dim_mults=(1, 2, 3, 4, 5, 6),
+                                      context_dim_mults=(1, 2, 3, 4)), [3, 64, 128, 192], 64, 64, 1),
+}
+
+DIFF = {
+    "xparam": dict(num_timesteps=8193, loss_type="l2", lagrangian=0.0032, pred_mode="x",
+                   aux_loss_weight=0, aux_loss_type="lpips", var_schedule="cosine",
+                   use_loss_weight=True, loss_weight_min=5),
+    "epsilonparam": dict(num_timesteps=20000, loss_type="l1", clip_noise="none", vbr=False,
+                         lagrangian=0.9, pred_mode="noise", var_schedule="linear",
+                         aux_loss_weight=0, aux_loss_type="lpips"),
+}
+
+
+class FixedContext(torch.nn.Module):
+    """Stand-in context_fn returning a fixed pyramid (the decode path only reads ["output"])."""
+
+    def __init__(self, ctx):
+        super().__init__()
+        self.ctx = ctx
+
+    def forward(self, images, *a):
+        return {"output": self.ctx, "bpp": torch.zeros(images.shape[0])}
+
+
+def gen_unet(name, taps=True):
+    tree, kw, ctxc, H, W, B = CONFIGS[name]
+    ref = import_reference(tree)
+    torch.manual_seed(0)
+    net = ref.unet.Unet(**kw)
+    man, sd = load_synth(net, seed=0, final_gain=0.2 if tree == "epsilonparam" else 1.0)
+    x = synth.normal("x", (B, 3, H, W), seed=1, std=0.8)
+    ctx = synth.context_pyramid(ctxc, B, H, W, seed=3)
+    time = np.linspace(0.1, 0.7, B, dtype=np.float32).reshape(B, 1)
+    acts = {}
+    hooks = []
+    if taps:
+        def mk(key):
+            def fn(m, i, o):
+                acts[key] = o.detach().numpy().copy()
+            return fn
+        for key, mod in [("downs.0.0", net.downs[0][0]), ("downs.0.2", net.downs[0][2]),
+                         ("downs.1.3", net.downs[1][3] if len(net.downs) > 2 else net.downs[0][3]),
+                         ("mid_block1", net.mid_block1), ("ups.0", net.ups[0][3])]:
+            hooks.append(mod.register_forward_hook(mk(key)))
+    with torch.no_grad():
+        y = net(torch.from_numpy(x), torch.from_numpy(time),
+                [torch.from_numpy(c) for c in ctx]).numpy()
+    for h in hooks:
+        h.remove()
+    out = {"x": x, "time": time, "y": y, "B": B, "H": H, "W": W}
+    for i, c in enumerate(ctx):
+        out[f"ctx{i}"] = c
+    if name.startswith("full"):
+        # full-width model: keep the file small (inputs are regenerated from synth; store digests)
+        out = {"time": time, "y": y, "B": B, "H": H, "W": W}
+        for k, v in acts.items():
+            d = digest(v)
+            out[f"tap_{k}_idx"], out[f"tap_{k}_val"] = d["idx"], d["val"]
+            out[f"tap_{k}_sum"] = d["sum"]
+    else:
+        for k, v in acts.items():
+            out[f"tap_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **out)
+    with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
+        json.dump({"unet_kwargs": {k: (list(v) if isinstance(v, tuple) else v)
+                                   for k, v in kw.items()},
+                   "context_channels_per_level": ctxc, "manifest": man}, f)
+    print(name, "unet ok", y.shape, float(np.abs(y).max()))
+    return ref, net, kw, ctxc
+
+
+def gen_decode(name, steps_list, eta_case=False):
+    tree, kw, ctxc, H, W, B = CONFIGS[name]
+    ref, net, _, _ = gen_unet(name, taps=not name.startswith("full") or True)
+    ctx = synth.context_pyramid(ctxc, B, H, W, seed=3)
+    tctx = [torch.from_numpy(c) for c in ctx]
+    diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=FixedContext(tctx),
+                                    **({"ae_fn": None} if tree == "xparam" else {}), **DIFF[tree])
+    diff.eval()
+    init = synth.normal("init", (B, 3, H, W), seed=1, std=0.8)
+    images = np.zeros((B, 3, H, W), np.float32)
+    out = {}
+    for steps in steps_list:
+        with torch.no_grad():
+            if tree == "xparam":
+                rec, _ = diff.compress(torch.from_numpy(images), sample_steps=steps,
+                                       bpp_return_mean=True, init=torch.from_numpy(init.copy()))
+            else:
+                rec, _ = diff.compress(torch.from_numpy(images), sample_steps=steps,
+                                       sample_mode="ddim", bpp_return_mean=False,
+                                       init=torch.from_numpy(init.copy()))
+        out[f"decode_{steps}"] = rec.numpy()
+        print(name, "decode", steps, float(rec.abs().max()))
+    if eta_case:
+        # eta != 0: the reference draws torch.randn_like every step from the global CPU RNG;
+        # record the draws so the same noise can be fed to the build (xparam :172 / eps :150).
+        steps = steps_list[0]
+        torch.manual_seed(1234)
+        noises = np.stack([torch.randn((B, 3, H, W)).numpy() for _ in range(steps)])
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            if tree == "xparam":
+                rec, _ = diff.compress(torch.from_numpy(images), sample_steps=steps,
+                                       init=torch.from_numpy(init.copy()), eta=0.5)
+            else:
+                rec, _ = diff.compress(torch.from_numpy(images), sample_steps=steps,
+                                       sample_mode="ddim", init=torch.from_numpy(init.copy()),
+                                       eta=0.5)
+        out["eta_steps"] = steps
+        out["eta_noises"] = noises
+        out["eta_decode"] = rec.numpy()
+    np.savez_compressed(os.path.join(HERE, f"decode_{name}.npz"), **out)
+
+
+def gen_schedules():
+    out = {}
+    for tree in ("xparam", "epsilonparam"):
+        ref = import_reference(tree)
+        net = ref.unet.Unet(dim=8, dim_mults=(1,), context_dim_mults=(1,))
+        diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=None,
+                                        **({"ae_fn": None} if tree == "xparam" else {}),
+                                        **DIFF[tree])
+        tag = "x" if tree == "xparam" else "eps"
+        out[f"{tag}_train_alphas_cumprod_digest"] = np.array(
+            [float(diff.train_alphas_cumprod.double().sum()),
+             float(diff.train_alphas_cumprod[-1]), float(diff.train_alphas_cumprod[0])])
+        for steps in (1, 2, 4, 7, 65, 200, 500, 1000):
+            diff.set_sample_schedule(steps, torch.device("cpu"))
+            for nm in ("alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod_prev",
+                       "one_minus_alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                       "sqrt_recipm1_alphas_cumprod", "sigma"):
+                out[f"{tag}_{steps}_{nm}"] = getattr(diff, nm).numpy().copy()
+            if tree == "xparam":
+                out[f"{tag}_{steps}_index"] = diff.index.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "schedules.npz"), **out)
+    print("schedules ok")
+
+
+def gen_full_res():
+    """BASELINE-size (256x256) x-param U-Net forward + 4-step decode of the real reference, B=1,
+    stored as digests (sums + 64 sampled pixels)."""
+    tree, kw, ctxc, _, _, _ = CONFIGS["full_x"]
+    ref = import_reference(tree)
+    net = ref.unet.Unet(**kw)
+    load_synth(net, seed=0)
+    B, H, W = 1, 256, 256
+    x = synth.normal("x", (B, 3, H, W), seed=1, std=0.8)
+    ctx = synth.context_pyramid(ctxc, B, H, W, seed=3)
+    tctx = [torch.from_numpy(c) for c in ctx]
+    time = np.full((B, 1), 0.37, np.float32)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x), torch.from_numpy(time), tctx).numpy()
+    d = digest(y)
+    out = {"time": time, "y_idx": d["idx"], "y_val": d["val"], "y_sum": d["sum"],
+           "y_sumsq": d["sumsq"]}
+    diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=FixedContext(tctx), ae_fn=None,
+                                    **DIFF[tree])
+    diff.eval()
+    init = synth.normal("init", (B, 3, H, W), seed=1, std=0.8)
+    with torch.no_grad():
+        rec, _ = diff.compress(torch.zeros(B, 3, H, W), sample_steps=4,
+                               init=torch.from_numpy(init.copy()))
+    d = digest(rec.numpy())
+    out.update({"dec4_idx": d["idx"], "dec4_val": d["val"], "dec4_sum": d["sum"],
+                "dec4_sumsq": d["sumsq"]})
+    np.savez_compressed(os.path.join(HERE, "full_res_x_256.npz"), **out)
+    print("full res ok", d["sum"])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_schedules()
+    gen_decode("small_x", [4, 1], eta_case=True)
+    gen_decode("small_eps", [4], eta_case=True)
+    gen_unet("odd_x")
+    gen_decode("full_x", [3])
+    gen_decode("full_eps", [3])
+    gen_full_res()
