@@ -1,0 +1,99 @@
+"""ctypes binding of libcdc_hip.so (include/cdc_hip.h).  There is NO CPU fallback: if the HIP
+library is missing or cannot be loaded, importing the product path fails loudly."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcdc_hip.so")
+
+CDC_MEM_HOST, CDC_MEM_DEVICE = 0, 1
+CDC_PRED_X, CDC_PRED_NOISE = 0, 1
+CDC_MAX_LEVELS = 8
+
+_f = ctypes.POINTER(ctypes.c_float)
+_i = ctypes.c_int
+_vp = ctypes.c_void_p
+
+
+class UnetConfig(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int32), ("channels", ctypes.c_int32),
+                ("context_channels", ctypes.c_int32), ("out_dim", ctypes.c_int32),
+                ("n_dim_mults", ctypes.c_int32), ("dim_mults", ctypes.c_int32 * CDC_MAX_LEVELS),
+                ("n_context_dim_mults", ctypes.c_int32),
+                ("context_dim_mults", ctypes.c_int32 * CDC_MAX_LEVELS)]
+
+
+class CdcError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libcdc_hip.so for gfx950 with hipcc (csrc/Makefile)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CdcError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (share torch's libamdhip64.so.7 so device pointers are compatible)
+    except Exception:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    H = _vp
+    pp = ctypes.POINTER(_vp)
+    L.cdc_create.argtypes = [ctypes.POINTER(UnetConfig), _i, ctypes.POINTER(H)]
+    L.cdc_destroy.argtypes = [H]
+    L.cdc_destroy.restype = None
+    L.cdc_last_error.argtypes = [H]
+    L.cdc_last_error.restype = ctypes.c_char_p
+    L.cdc_version.restype = ctypes.c_char_p
+    L.cdc_num_tensors.argtypes = [H]
+    L.cdc_tensor_info.argtypes = [H, _i, ctypes.POINTER(ctypes.c_char_p),
+                                  ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_i)]
+    L.cdc_load_tensor.argtypes = [H, ctypes.c_char_p, _vp, ctypes.POINTER(ctypes.c_int64), _i]
+    L.cdc_finalize_weights.argtypes = [H]
+    L.cdc_unet_forward.argtypes = [H, _vp, _vp, pp, _i, _vp, _i, _i, _i, _i, _vp]
+    L.cdc_set_schedule.argtypes = [H, _i, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.cdc_ddim_step.argtypes = [H, _vp, _i, pp, _i, _vp, ctypes.c_float, _vp, _i, _i, _i, _i, _i,
+                                _i, _vp]
+    L.cdc_decode.argtypes = [H, _vp, pp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    L.cdc_prof_enable.argtypes = [H, _i]
+    L.cdc_prof_name.argtypes = [_i]
+    L.cdc_prof_name.restype = ctypes.c_char_p
+    L.cdc_prof_get.argtypes = [H, _i, ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_double)]
+    L.cdc_prof_reset.argtypes = [H]
+    L.cdc_op_conv2d.argtypes = [H, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp, _i, _vp, _vp]
+    L.cdc_op_conv_transpose2d.argtypes = [H, _vp, _vp, _vp, _vp] + [_i] * 5
+    L.cdc_op_chan_layernorm.argtypes = [H, _vp, _vp, _vp, _vp, _i, _i, _i]
+    L.cdc_op_linear_attention.argtypes = [H] + [_vp] * 7 + [_i] * 4
+    _lib = L
+    return L
+
+
+EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_num_tensors",
+           "cdc_tensor_info", "cdc_load_tensor", "cdc_finalize_weights", "cdc_unet_forward",
+           "cdc_set_schedule", "cdc_ddim_step", "cdc_decode", "cdc_prof_enable",
+           "cdc_prof_num_classes", "cdc_prof_name", "cdc_prof_get", "cdc_prof_reset",
+           "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
+           "cdc_op_linear_attention"]
+
+
+def check(handle, rc):
+    if rc != 0:
+        msg = lib().cdc_last_error(handle)
+        raise CdcError(f"libcdc_hip error {rc}: {msg.decode() if msg else ''}")

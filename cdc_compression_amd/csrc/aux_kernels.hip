@@ -1,0 +1,348 @@
+// aux_kernels.hip -- the non-GEMM kernels of the decode path: standalone channel LayerNorm,
+// time-embedding MLPs, k-softmax statistics, linear-attention context (k.v^T on MFMA), DDIM update.
+#include <math.h>
+
+#include <algorithm>
+
+#include "cdc_internal.h"
+
+namespace cdc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channel LayerNorm (reference network_components.py:56-66), NCHW: one thread per pixel, channel
+// loop strided by HW (coalesced across the wave).  Used where the convolution epilogue cannot own
+// all channels (few-pixel levels, Cout % 32 != 0) and for statistics-only passes.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ln_kernel(const LnArgs a) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.HW) return;
+    const size_t base = (size_t)b * a.C * a.HW + p;
+    const float *x = a.in + base;
+    float s = 0.f;
+    for (int c = 0; c < a.C; ++c) s += x[(size_t)c * a.HW];
+    const float mean = s / (float)a.C;
+    float q = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+        const float d = x[(size_t)c * a.HW] - mean;
+        q += d * d;
+    }
+    const float var = q / (float)a.C;
+    if (!a.out) {
+        a.stat_mean[(size_t)b * a.HW + p] = mean;
+        a.stat_rstd[(size_t)b * a.HW + p] = 1.0f / sqrtf(var + a.eps);
+        return;
+    }
+    const float den = sqrtf(var + a.eps);
+    float *y = a.out + base;
+    const float *r = a.resid ? a.resid + base : nullptr;
+    const float *sh = a.shift ? a.shift + (size_t)b * a.shift_bs : nullptr;
+    float s2 = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+        float v = (x[(size_t)c * a.HW] - mean) / den * a.g[c] + a.b[c];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (sh) v += sh[c];
+        if (r) v += r[(size_t)c * a.HW];
+        y[(size_t)c * a.HW] = v;
+        s2 += v;
+    }
+    if (a.stat_mean) {
+        const float m2 = s2 / (float)a.C;
+        float q2 = 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const float d = y[(size_t)c * a.HW] - m2;
+            q2 += d * d;
+        }
+        a.stat_mean[(size_t)b * a.HW + p] = m2;
+        a.stat_rstd[(size_t)b * a.HW + p] = 1.0f / sqrtf(q2 / (float)a.C + a.eps);
+    }
+}
+
+hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
+    const int block = a.HW >= 256 ? 256 : 64;
+    dim3 grid((unsigned)ceil_div(a.HW, block), (unsigned)B);
+    hipLaunchKernelGGL(ln_kernel, grid, dim3(block), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time embedding: Unet.time_mlp (unet.py:41) then every ResnetBlock.mlp
+// (network_components.py:96-100, LeakyReLU(0.2) -> Linear(dim, cout)).  One workgroup per image.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) temb_kernel(const TembArgs a) {
+    extern __shared__ float sm[];
+    float *h = sm;                 // [4*dim]
+    float *t = sm + 4 * a.dim;     // [dim]  LeakyReLU(temb)
+    const int b = blockIdx.x;
+    const float tv = a.time[b];
+    for (int j = threadIdx.x; j < 4 * a.dim; j += blockDim.x) {
+        const float u = a.w0[j] * tv + a.b0[j];
+        h[j] = 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));     // nn.GELU() (erf form)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.dim; i += blockDim.x) {
+        const float *w = a.w2 + (size_t)i * 4 * a.dim;
+        float s = 0.f;
+        for (int j = 0; j < 4 * a.dim; ++j) s += w[j] * h[j];
+        s += a.b2[i];
+        t[i] = s >= 0.f ? s : 0.2f * s;
+    }
+    __syncthreads();
+    for (int l = 0; l < a.n_layers; ++l) {
+        const TembLayer L = a.layers[l];
+        for (int co = threadIdx.x; co < L.cout; co += blockDim.x) {
+            const float *w = L.w + (size_t)co * a.dim;
+            float s = 0.f;
+            for (int i = 0; i < a.dim; ++i) s += w[i] * t[i];
+            a.shift[(size_t)b * a.shift_bs + L.out_off + co] = s + L.bias[co];
+        }
+    }
+}
+
+hipError_t temb_launch(const TembArgs &a, int B, hipStream_t st) {
+    hipLaunchKernelGGL(temb_kernel, dim3(B), dim3(256), sizeof(float) * 5 * a.dim, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k.softmax(dim=-1) statistics (network_components.py:134): row max and sum of exp over N pixels.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kstats_kernel(const float *k, long long k_bs, int C, int N,
+                                                     float *kmax, float *ksum) {
+    __shared__ float red[4];
+    const int d = blockIdx.x, b = blockIdx.y;
+    const float *row = k + (size_t)b * k_bs + (size_t)d * N;
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float m = -INFINITY;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) m = fmaxf(m, row[n]);
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) s += expf(row[n] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += red[i];
+        kmax[(size_t)b * C + d] = m;
+        ksum[(size_t)b * C + d] = t;
+    }
+}
+
+hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, float *ksum,
+                         int B, hipStream_t st) {
+    const int block = N >= 1024 ? 256 : 64;
+    hipLaunchKernelGGL(kstats_kernel, dim3(C, B), dim3(block), 0, st, k, k_bs, C, N, kmax, ksum);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// context = softmax(k) . v^T  (network_components.py:135), unnormalised partial sums:
+//   S[b][split][d][e] = sum_{n in split} exp(k[d,n] - kmax[d]) * v[e,n]
+// 64(d) x 64(e) output tile per workgroup, MFMA 32x32x2 f32 with A[i=d][k=n], B[k=n][j=e]; the
+// four waves split each 64-pixel chunk (16 pixels = 8 k-steps each) and are summed through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCtxPch = 64;             // pixels per staged chunk
+constexpr int kCtxLd = kCtxPch + 1;     // padded row stride (conflict-free column reads)
+
+__global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const float *v,
+                                                          long long kv_bs, int C, int N,
+                                                          const float *kmax, float *S, int nsplit,
+                                                          int tiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *kl = sm;                          // [64][kCtxLd]
+    float *vl = sm + 64 * kCtxLd;            // [64][kCtxLd]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dt = blockIdx.x / tiles, et = blockIdx.x % tiles;
+    const int split = blockIdx.y, b = blockIdx.z;
+    const int d0 = dt * 64, e0 = et * 64;
+    const int nps = round_up(ceil_div(N, nsplit), kCtxPch);
+    const int n_begin = split * nps;
+    const int n_end = min(N, n_begin + nps);
+    const float *kb = k + (size_t)b * kv_bs;
+    const float *vb = v + (size_t)b * kv_bs;
+    const float *mb = kmax + (size_t)b * C;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, jj = lane & 31;
+    for (int n0 = n_begin; n0 < n_end; n0 += kCtxPch) {
+        __syncthreads();
+        // stage: 64 rows x 64 pixels for k (exponentiated) and v; thread -> (row, 16-pixel strip)
+        for (int e = tid; e < 64 * kCtxPch; e += 256) {
+            const int row = e >> 6, col = e & 63;
+            const int n = n0 + col;
+            float kv = 0.f, vv = 0.f;
+            if (n < n_end) {
+                if (d0 + row < C) kv = expf(kb[(size_t)(d0 + row) * N + n] - mb[d0 + row]);
+                if (e0 + row < C) vv = vb[(size_t)(e0 + row) * N + n];
+            }
+            kl[row * kCtxLd + col] = kv;
+            vl[row * kCtxLd + col] = vv;
+        }
+        __syncthreads();
+        const int nb = wave * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = kl[(i * 32 + jj) * kCtxLd + nb + ks + half];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = vl[(j * 32 + jj) * kCtxLd + nb + ks + half];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // cross-wave reduction through LDS: red[wave][d 64][e 64]
+    __syncthreads();
+    float *red = sm;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int e = j * 32 + jj;
+                red[(wave * 64 + d) * 64 + e] = acc[i][j][r];
+            }
+    __syncthreads();
+    float *out = S + (((size_t)b * nsplit + split) * C) * C;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int d = idx >> 6, e = idx & 63;
+        if (d0 + d < C && e0 + e < C) {
+            const float s = red[idx] + red[4096 + idx] + red[8192 + idx] + red[12288 + idx];
+            out[(size_t)(d0 + d) * C + e0 + e] = s;
+        }
+    }
+}
+
+hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
+                              const float *kmax, float *S, int nsplit, int B, hipStream_t st) {
+    const int tiles = ceil_div(C, 64);
+    const size_t lds = sizeof(float) * 4 * 64 * 64;      // reduction buffer (>= staging tiles)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)ctx_partial_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ctx_partial_kernel, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
+                       kv_bs, C, N, kmax, S, nsplit, tiles);
+    return hipGetLastError();
+}
+
+// ctxw[b][d][e] = scale * (sum_split S[b][split][d][e]) / ksum[b][d]   (q*scale folded in, :132)
+__global__ void __launch_bounds__(256) ctx_reduce_kernel(const float *S, const float *ksum, int C,
+                                                         int nsplit, float scale, float *ctxw,
+                                                         int Cin_pad, int COP) {
+    const int d = blockIdx.x, b = blockIdx.y;
+    float *row = ctxw + ((size_t)b * Cin_pad + d) * COP;
+    if (d >= C) {
+        for (int e = threadIdx.x; e < COP; e += blockDim.x) row[e] = 0.f;
+        return;
+    }
+    const float z = ksum[(size_t)b * C + d];
+    for (int e = threadIdx.x; e < COP; e += blockDim.x) {
+        float s = 0.f;
+        if (e < C) {
+            for (int sp = 0; sp < nsplit; ++sp)
+                s += S[(((size_t)b * nsplit + sp) * C + d) * C + e];
+            s = s / z * scale;
+        }
+        row[e] = s;
+    }
+}
+
+hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
+                             float *ctxw, int Cin_pad, int COP, int B, hipStream_t st) {
+    hipLaunchKernelGGL(ctx_reduce_kernel, dim3(Cin_pad, B), dim3(COP >= 256 ? 256 : 64), 0, st, S,
+                       ksum, C, nsplit, scale, ctxw, Cin_pad, COP);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDIM update.  x-param: xparam/modules/denoising_diffusion.py:152-174 ; eps-param:
+// epsilonparam/modules/denoising_diffusion.py:137-152.  Same operation order as the reference.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
+    const float c_recip = a.tab[0 * a.steps + a.i];
+    const float c_recipm1 = a.tab[1 * a.steps + a.i];
+    const float c_acp = a.tab[2 * a.steps + a.i];
+    const float c_1macp = a.tab[3 * a.steps + a.i];
+    const float sig = a.eta * a.tab[4 * a.steps + a.i];
+    float var = c_1macp - sig * sig;
+    if (a.pred_mode == 0) var = fmaxf(var, 0.f);          // x-param .clamp(min=0) (:169)
+    const float c_eps = sqrtf(var);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const float fx = a.fx[idx], x = a.x[idx];
+        float x0, eps;
+        if (a.pred_mode == 0) {
+            x0 = fx;
+            if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            eps = (c_recip * x - x0) / c_recipm1;
+        } else {
+            eps = fx;
+            x0 = c_recip * x - c_recipm1 * eps;
+            if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        }
+        float xn = c_acp * x0 + c_eps * eps;
+        if (a.noise) xn += sig * a.noise[idx];
+        a.x_next[idx] = xn;
+    }
+}
+
+hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
+    const int grid = (int)std::min<long long>((a.n + 255) / 256, 4096);
+    hipLaunchKernelGGL(ddim_kernel, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) copy_kernel(const float *src, long long src_bs, float *dst,
+                                                   long long dst_bs, long long n) {
+    const int b = blockIdx.y;
+    const float *s = src + (size_t)b * src_bs;
+    float *d = dst + (size_t)b * dst_bs;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
+                                long long n, int B, hipStream_t st) {
+    const int gx = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(copy_kernel, dim3(gx, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, n);
+    return hipGetLastError();
+}
+
+}  // namespace cdc

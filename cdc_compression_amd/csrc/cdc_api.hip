@@ -1,0 +1,1155 @@
+// cdc_api.hip -- C-ABI of libcdc_hip.so (include/cdc_hip.h): parameter repacking, the per-shape
+// launch program of Unet.forward (xparam/modules/unet.py:106-135), and the DDIM sampler loop
+// (xparam/modules/denoising_diffusion.py:152-205, epsilonparam/...:137-192).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/cdc_hip.h"
+#include "cdc_internal.h"
+
+using namespace cdc;
+
+namespace {
+
+enum ProfClass { PC_CONV3 = 0, PC_CONV7, PC_CONV1, PC_DOWN, PC_UP, PC_ATTN_CTX, PC_LN, PC_SMALL,
+                 PC_COUNT };
+const char *kProfNames[PC_COUNT] = {"conv3x3", "conv7x7", "conv1x1", "downsample", "upsample",
+                                    "attn_ctx", "layernorm", "small"};
+
+struct Param {                    // one state_dict entry
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> host;
+    bool loaded = false;
+    size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+
+struct ConvW {                    // packed convolution weights (device)
+    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    bool transposed = false;      // ConvTranspose2d 4x4 s2 p1 as four 2x2 phase convolutions
+    int Cin_pad = 0, COP = 0, nz = 1;
+    float *wp = nullptr, *bias = nullptr;
+    long long w_zs = 0, w_bs = 0;
+};
+
+struct Act { float *p = nullptr; int C = 0, H = 0, W = 0;
+             long long bs() const { return (long long)C * H * W; } };
+
+struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift_off;
+                   ConvW c1, c2, cres; float *g1, *b1, *g2, *b2, *mlp_w, *mlp_b; };
+struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb; };
+
+struct Op {
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, DDIM, COPY } kind;
+    int prof = PC_SMALL;
+    double flops = 0, bytes = 0;
+    ConvArgs conv; ConvPlan plan; int nz = 1;
+    LnArgs ln;
+    TembArgs temb;
+    struct { const float *k, *v; long long bs; int C, N; float *kmax, *ksum, *S, *ctxw;
+             int nsplit, Cin_pad, COP; float scale; } at;
+    DdimArgs ddim;
+    struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
+};
+
+}  // namespace
+
+struct cdc_handle {
+    cdc_unet_config cfg;
+    int device = 0;
+    std::string err;
+    hipStream_t own_stream = nullptr;
+    // architecture (unet.py:33-35)
+    std::vector<int> dims, context_dims;
+    int n_res = 0, out_dim = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+    bool finalized = false;
+    std::vector<void *> weight_allocs;
+    // weights
+    float *tm_w0 = nullptr, *tm_b0 = nullptr, *tm_w2 = nullptr, *tm_b2 = nullptr;
+    std::vector<ResBlockW> rbs;          // in forward order
+    std::vector<AttnW> attns;
+    std::vector<ConvW> downs, ups;
+    float *fin_g = nullptr, *fin_b = nullptr;
+    ConvW fin_conv;
+    TembLayer *d_temb_layers = nullptr;
+    int shift_bs = 0;
+    // program
+    int pB = 0, pH = 0, pW = 0;
+    std::vector<Op> ops;
+    std::vector<void *> act_allocs;
+    size_t act_bytes = 0;
+    float *in_x = nullptr, *in_time = nullptr, *out_fx = nullptr, *shift = nullptr;
+    std::vector<Act> in_ctx;
+    float *xa = nullptr, *xb = nullptr, *noise_buf = nullptr;     // decode ping-pong
+    // schedule
+    int steps = 0;
+    float *d_tab = nullptr;              // [5][steps]
+    std::vector<float> h_time_in;
+    float *d_time_steps = nullptr;       // [steps][B] time value replicated per image
+    int time_steps_B = 0;
+    // profiling
+    bool prof = false;
+    double prof_ms[PC_COUNT] = {0}, prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0};
+    int64_t prof_launches[PC_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+std::string g_create_err;
+
+int fail(cdc_handle *h, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(h, CDC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// manifest (reference state_dict order: time_mlp, downs, ups, mid_*, final_conv)
+// ------------------------------------------------------------------------------------------------
+void add_param(cdc_handle *h, const std::string &name, std::vector<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.shape = std::move(shape);
+    h->pindex[name] = (int)h->params.size();
+    h->params.push_back(std::move(p));
+}
+
+void add_resblock_params(cdc_handle *h, const std::string &p, int cin, int cout, int k) {
+    const int d = h->cfg.dim;
+    add_param(h, p + ".mlp.1.weight", {cout, d});
+    add_param(h, p + ".mlp.1.bias", {cout});
+    add_param(h, p + ".block1.block.0.weight", {cout, cin, k, k});
+    add_param(h, p + ".block1.block.0.bias", {cout});
+    add_param(h, p + ".block1.block.1.g", {1, cout, 1, 1});
+    add_param(h, p + ".block1.block.1.b", {1, cout, 1, 1});
+    add_param(h, p + ".block2.block.0.weight", {cout, cout, 3, 3});
+    add_param(h, p + ".block2.block.0.bias", {cout});
+    add_param(h, p + ".block2.block.1.g", {1, cout, 1, 1});
+    add_param(h, p + ".block2.block.1.b", {1, cout, 1, 1});
+    if (cin != cout) {
+        add_param(h, p + ".res_conv.weight", {cout, cin, 1, 1});
+        add_param(h, p + ".res_conv.bias", {cout});
+    }
+}
+
+void add_attn_params(cdc_handle *h, const std::string &p, int c) {
+    add_param(h, p + ".fn.fn.to_qkv.weight", {3 * c, c, 1, 1});
+    add_param(h, p + ".fn.fn.to_out.weight", {c, c, 1, 1});
+    add_param(h, p + ".fn.fn.to_out.bias", {c});
+    add_param(h, p + ".fn.norm.g", {1, c, 1, 1});
+    add_param(h, p + ".fn.norm.b", {1, c, 1, 1});
+}
+
+int down_in_channels(const cdc_handle *h, int ind) {     // unet.py:65-68
+    const int dim_in = h->dims[ind];
+    const bool is_last = ind >= h->n_res - 1;
+    if (!is_last && ind < (int)h->context_dims.size() - 1) return dim_in + h->context_dims[ind];
+    return dim_in;
+}
+
+void build_manifest(cdc_handle *h) {
+    const int d = h->cfg.dim;
+    add_param(h, "time_mlp.0.weight", {4 * d, 1});
+    add_param(h, "time_mlp.0.bias", {4 * d});
+    add_param(h, "time_mlp.2.weight", {d, 4 * d});
+    add_param(h, "time_mlp.2.bias", {d});
+    const int n = h->n_res;
+    for (int i = 0; i < n; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        const int dout = h->dims[i + 1];
+        add_resblock_params(h, p + ".0", down_in_channels(h, i), dout, i == 0 ? 7 : 3);
+        add_resblock_params(h, p + ".1", dout, dout, 3);
+        add_attn_params(h, p + ".2", dout);
+        if (i < n - 1) {
+            add_param(h, p + ".3.conv.weight", {dout, dout, 3, 3});
+            add_param(h, p + ".3.conv.bias", {dout});
+        }
+    }
+    for (int i = 0; i < n - 1; ++i) {          // reversed(in_out[1:]), unet.py:88
+        const int lvl = n - 1 - i;             // in_out[lvl] = (dims[lvl], dims[lvl+1])
+        const int din = h->dims[lvl], dout = h->dims[lvl + 1];
+        const std::string p = "ups." + std::to_string(i);
+        add_resblock_params(h, p + ".0", dout * 2, din, 3);
+        add_resblock_params(h, p + ".1", din, din, 3);
+        add_attn_params(h, p + ".2", din);
+        add_param(h, p + ".3.conv.weight", {din, din, 4, 4});
+        add_param(h, p + ".3.conv.bias", {din});
+    }
+    const int mid = h->dims[n];
+    add_resblock_params(h, "mid_block1", mid, mid, 3);
+    add_attn_params(h, "mid_attn", mid);
+    add_resblock_params(h, "mid_block2", mid, mid, 3);
+    add_param(h, "final_conv.0.g", {1, d, 1, 1});
+    add_param(h, "final_conv.0.b", {1, d, 1, 1});
+    add_param(h, "final_conv.1.weight", {h->out_dim, d, 7, 7});
+    add_param(h, "final_conv.1.bias", {h->out_dim});
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight upload / repacking
+// ------------------------------------------------------------------------------------------------
+int upload(cdc_handle *h, const float *src, size_t n, float **dst, std::vector<void *> *pool) {
+    void *p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+    pool->push_back(p);
+    if (src && n) HIP_TRY(h, hipMemcpy(p, src, n * sizeof(float), hipMemcpyHostToDevice));
+    *dst = (float *)p;
+    return CDC_OK;
+}
+
+const std::vector<float> &hostp(cdc_handle *h, const std::string &name) {
+    return h->params[h->pindex.at(name)].host;
+}
+
+int upload_param(cdc_handle *h, const std::string &name, float **dst) {
+    const auto &v = hostp(h, name);
+    return upload(h, v.data(), v.size(), dst, &h->weight_allocs);
+}
+
+// Conv2d OIHW -> [tap][Cin_pad][COP]; ConvTranspose2d IOHW(4x4,s2,p1) -> [phase][2x2 tap][Cin_pad][COP]
+int pack_conv(cdc_handle *h, const float *w, const float *bias, int Cout, int Cin, int KH, int KW,
+              int stride, int pad, bool transposed, ConvW *cw, std::vector<void *> *pool) {
+    cw->Cin = Cin; cw->Cout = Cout; cw->stride = stride; cw->pad = pad;
+    cw->transposed = transposed;
+    cw->Cin_pad = round_up(Cin, 16);
+    cw->COP = round_up(Cout, 32);
+    std::vector<float> packed;
+    if (!transposed) {
+        cw->KH = KH; cw->KW = KW; cw->nz = 1;
+        const int taps = KH * KW;
+        packed.assign((size_t)taps * cw->Cin_pad * cw->COP, 0.f);
+        for (int co = 0; co < Cout; ++co)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    packed[((size_t)t * cw->Cin_pad + ci) * cw->COP + co] =
+                        w[((size_t)co * Cin + ci) * taps + t];
+        cw->w_zs = 0;
+    } else {
+        // out[2m+py][2n+px] = sum_{a,b in {0,1}} x[m+a-(1-py)][n+b-(1-px)] * w[ci][co][3-py-2a][3-px-2b]
+        cw->KH = 2; cw->KW = 2; cw->nz = 4; cw->stride = 1;
+        cw->w_zs = (long long)4 * cw->Cin_pad * cw->COP;
+        packed.assign((size_t)4 * cw->w_zs, 0.f);
+        for (int z = 0; z < 4; ++z) {
+            const int py = z >> 1, px = z & 1;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int ky = 3 - py - 2 * a, kx = 3 - px - 2 * b;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int co = 0; co < Cout; ++co)
+                            packed[(size_t)z * cw->w_zs +
+                                   ((size_t)(a * 2 + b) * cw->Cin_pad + ci) * cw->COP + co] =
+                                w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+                }
+        }
+    }
+    int rc = upload(h, packed.data(), packed.size(), &cw->wp, pool);
+    if (rc) return rc;
+    cw->bias = nullptr;
+    if (bias) rc = upload(h, bias, Cout, &cw->bias, pool);
+    return rc;
+}
+
+int pack_named_conv(cdc_handle *h, const std::string &wname, const std::string &bname, int stride,
+                    int pad, bool transposed, ConvW *cw) {
+    const Param &p = h->params[h->pindex.at(wname)];
+    const float *bias = bname.empty() ? nullptr : hostp(h, bname).data();
+    const int d0 = (int)p.shape[0], d1 = (int)p.shape[1];
+    const int KH = (int)p.shape[2], KW = (int)p.shape[3];
+    if (!transposed)
+        return pack_conv(h, p.host.data(), bias, d0, d1, KH, KW, stride, pad, false, cw,
+                         &h->weight_allocs);
+    return pack_conv(h, p.host.data(), bias, d1, d0, KH, KW, stride, pad, true, cw,
+                     &h->weight_allocs);
+}
+
+int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k, int *shift_off) {
+    ResBlockW rb;
+    rb.prefix = p; rb.cin = cin; rb.cout = cout; rb.k = k; rb.has_res = cin != cout;
+    rb.shift_off = *shift_off;
+    *shift_off += round_up(cout, 32);
+    int rc;
+    if ((rc = pack_named_conv(h, p + ".block1.block.0.weight", p + ".block1.block.0.bias", 1, k / 2,
+                              false, &rb.c1))) return rc;
+    if ((rc = pack_named_conv(h, p + ".block2.block.0.weight", p + ".block2.block.0.bias", 1, 1,
+                              false, &rb.c2))) return rc;
+    if (rb.has_res &&
+        (rc = pack_named_conv(h, p + ".res_conv.weight", p + ".res_conv.bias", 1, 0, false, &rb.cres)))
+        return rc;
+    if ((rc = upload_param(h, p + ".block1.block.1.g", &rb.g1))) return rc;
+    if ((rc = upload_param(h, p + ".block1.block.1.b", &rb.b1))) return rc;
+    if ((rc = upload_param(h, p + ".block2.block.1.g", &rb.g2))) return rc;
+    if ((rc = upload_param(h, p + ".block2.block.1.b", &rb.b2))) return rc;
+    if ((rc = upload_param(h, p + ".mlp.1.weight", &rb.mlp_w))) return rc;
+    if ((rc = upload_param(h, p + ".mlp.1.bias", &rb.mlp_b))) return rc;
+    h->rbs.push_back(rb);
+    return CDC_OK;
+}
+
+int pack_attn(cdc_handle *h, const std::string &p, int c) {
+    AttnW a;
+    a.prefix = p; a.C = c;
+    int rc;
+    if ((rc = pack_named_conv(h, p + ".fn.fn.to_qkv.weight", "", 1, 0, false, &a.qkv))) return rc;
+    if ((rc = pack_named_conv(h, p + ".fn.fn.to_out.weight", p + ".fn.fn.to_out.bias", 1, 0, false,
+                              &a.out))) return rc;
+    if ((rc = upload_param(h, p + ".fn.norm.g", &a.ng))) return rc;
+    if ((rc = upload_param(h, p + ".fn.norm.b", &a.nb))) return rc;
+    h->attns.push_back(a);
+    return CDC_OK;
+}
+
+void free_pool(std::vector<void *> *pool) {
+    for (void *p : *pool) (void)hipFree(p);
+    pool->clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// program construction
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    cdc_handle *h;
+    int B;
+    std::vector<void *> *pool;      // where device allocations are recorded
+    int rc = CDC_OK;
+
+    float *dalloc(size_t nfloats) {
+        if (rc) return nullptr;
+        void *p = nullptr;
+        const size_t bytes = std::max<size_t>(nfloats, 1) * sizeof(float);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            rc = fail(h, CDC_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return nullptr;
+        }
+        pool->push_back(p);
+        h->act_bytes += bytes;
+        return (float *)p;
+    }
+    Act new_act(int C, int H, int W) {
+        Act a; a.C = C; a.H = H; a.W = W;
+        a.p = dalloc((size_t)B * C * H * W);
+        return a;
+    }
+
+    struct ConvOpts {
+        const float *ln_g = nullptr, *ln_b = nullptr;  // fused LN after bias
+        int relu = 0;
+        const float *shift = nullptr;                  // + shift[b][co]
+        const float *resid = nullptr; long long resid_bs = 0, resid_cs = 0;
+        float *stat_mean = nullptr, *stat_rstd = nullptr;
+        const float *pre_mean = nullptr, *pre_rstd = nullptr, *pre_g = nullptr, *pre_b = nullptr;
+        long long w_bs = 0;
+        bool no_bias = false;
+    };
+
+    // Emits one convolution.  a1 (optional) is the second concat source.  Returns false when
+    // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
+    bool conv(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1,
+              long long bs1, int H, int W, float *out, long long out_bs, const ConvOpts &o,
+              bool need_all, int prof) {
+        if (rc) return true;
+        ConvShape s;
+        s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
+        if (w.transposed) { s.Ho = H; s.Wo = W; }
+        else {
+            s.Ho = (H + 2 * w.pad - w.KH) / w.stride + 1;
+            s.Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
+        }
+        s.B = B; s.need_all_cout = need_all; s.lnload = o.pre_mean != nullptr;
+        if (need_all && (w.Cout % 32)) return false;
+        ConvPlan plan;
+        if (!conv_make_plan(s, &plan)) {
+            if (need_all) return false;
+            rc = fail(h, CDC_ERR_UNSUPPORTED, "no launch plan for conv Cin=%d Cout=%d k=%dx%d out=%dx%d",
+                      w.Cin, w.Cout, w.KH, w.KW, s.Ho, s.Wo);
+            return true;
+        }
+        Op op;
+        op.kind = Op::CONV; op.prof = prof; op.plan = plan; op.nz = w.nz;
+        ConvArgs &a = op.conv;
+        memset(&a, 0, sizeof a);
+        a.src0 = s0; a.src1 = s1; a.src0_bs = bs0; a.src1_bs = bs1;
+        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
+        a.ln_mean = o.pre_mean; a.ln_rstd = o.pre_rstd; a.ln_g = o.pre_g; a.ln_b = o.pre_b;
+        a.wp = w.wp; a.w_bs = o.w_bs; a.w_zs = w.w_zs;
+        a.KH = w.KH; a.KW = w.KW; a.stride = w.stride;
+        a.Cin_pad = w.Cin_pad; a.COP = w.COP; a.Cout = w.Cout;
+        a.out = out; a.out_bs = out_bs;
+        if (w.transposed) {
+            for (int z = 0; z < 4; ++z) {
+                const int py = z >> 1, px = z & 1;
+                a.pad_y[z] = 1 - py; a.pad_x[z] = 1 - px;
+                a.out_zoff[z] = py * 2 * W + px;
+            }
+            a.out_cs = (long long)4 * H * W; a.out_ys = 4 * W; a.out_xs = 2;
+        } else {
+            a.pad_y[0] = a.pad_x[0] = w.pad;
+            a.out_cs = (long long)s.Ho * s.Wo; a.out_ys = s.Wo; a.out_xs = 1;
+        }
+        a.Ho = s.Ho; a.Wo = s.Wo;
+        a.bias = o.no_bias ? nullptr : w.bias;
+        a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu;
+        a.shift = o.shift; a.shift_bs = h->shift_bs;
+        a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
+        a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
+        const double px = (double)B * s.Ho * s.Wo * w.nz;
+        op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
+        op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
+        h->ops.push_back(op);
+        return true;
+    }
+
+    void ln(const float *in, float *out, int C, int HW, const float *g, const float *b, int relu,
+            const float *shift, const float *resid, float *sm, float *sr) {
+        if (rc) return;
+        Op op;
+        op.kind = Op::LN; op.prof = PC_LN;
+        LnArgs &a = op.ln;
+        a.in = in; a.out = out; a.C = C; a.HW = HW; a.g = g; a.b = b; a.eps = 1e-5f; a.relu = relu;
+        a.shift = shift; a.shift_bs = h->shift_bs; a.resid = resid; a.stat_mean = sm; a.stat_rstd = sr;
+        op.bytes = 4.0 * B * C * HW * (out ? 2 : 1);
+        h->ops.push_back(op);
+    }
+
+    // ResnetBlock.forward (network_components.py:107-114)
+    Act resblock(const ResBlockW &rb, Act a0, const Act *a1, float *sm, float *sr) {
+        if (rc) return Act();
+        const int H = a0.H, W = a0.W, HW = H * W;
+        const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
+        Act cat;
+        const float *s0 = a0.p, *s1 = a1 ? a1->p : nullptr;
+        int C0 = a0.C;
+        long long bs0 = a0.bs(), bs1 = a1 ? a1->bs() : 0;
+        if (!rb.has_res && a1) {
+            // identity residual over a concatenated input (downs.1.0: 64+64 -> 128): materialise
+            cat = new_act(a0.C + a1->C, H, W);
+            Op c0; c0.kind = Op::COPY; c0.prof = PC_SMALL;
+            c0.cp = {a0.p, a0.bs(), cat.p, cat.bs(), a0.bs()};
+            c0.bytes = 8.0 * B * a0.bs();
+            h->ops.push_back(c0);
+            Op c1; c1.kind = Op::COPY; c1.prof = PC_SMALL;
+            c1.cp = {a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs()};
+            c1.bytes = 8.0 * B * a1->bs();
+            h->ops.push_back(c1);
+            s0 = cat.p; s1 = nullptr; C0 = cat.C; bs0 = cat.bs(); bs1 = 0;
+        }
+        const float *shift = h->shift + rb.shift_off;
+        Act h1 = new_act(rb.cout, H, W);
+        ConvOpts o1;
+        o1.ln_g = rb.g1; o1.ln_b = rb.b1; o1.relu = 1; o1.shift = shift;
+        if (!prefer_fused(rb.c1, H, W) ||
+            !conv(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), o1, true, prof1)) {
+            conv(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), ConvOpts(), false, prof1);
+            ln(h1.p, h1.p, rb.cout, HW, rb.g1, rb.b1, 1, shift, nullptr, nullptr, nullptr);
+        }
+        const float *res = s0;
+        long long res_bs = bs0;
+        if (rb.has_res) {
+            Act r = new_act(rb.cout, H, W);
+            conv(rb.cres, s0, C0, bs0, s1, bs1, H, W, r.p, r.bs(), ConvOpts(), false, PC_CONV1);
+            res = r.p; res_bs = r.bs();
+        }
+        Act out = new_act(rb.cout, H, W);
+        ConvOpts o2;
+        o2.ln_g = rb.g2; o2.ln_b = rb.b2; o2.relu = 1;
+        o2.resid = res; o2.resid_bs = res_bs; o2.resid_cs = HW;
+        o2.stat_mean = sm; o2.stat_rstd = sr;
+        if (!prefer_fused(rb.c2, H, W) ||
+            !conv(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), o2, true, PC_CONV3)) {
+            conv(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), ConvOpts(), false,
+                 PC_CONV3);
+            ln(out.p, out.p, rb.cout, HW, rb.g2, rb.b2, 1, nullptr, res, sm, sr);
+        }
+        return out;
+    }
+
+    // Fused LayerNorm epilogue needs every output channel in one workgroup; at few-pixel levels that
+    // leaves most CUs idle, so split channels over workgroups and run the standalone LN instead.
+    bool prefer_fused(const ConvW &w, int H, int W) {
+        if (w.Cout % 32 || w.Cout > 384) return false;
+        ConvShape s;
+        s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
+        s.Ho = H; s.Wo = W; s.B = B; s.lnload = false;
+        ConvPlan pf, pu;
+        s.need_all_cout = true;
+        if (!conv_make_plan(s, &pf)) return false;
+        s.need_all_cout = false;
+        if (!conv_make_plan(s, &pu)) return true;
+        const double wf = (double)pf.tiles_x * pf.tiles_y * B * pf.WN;
+        const double wu = (double)pu.tiles_x * pu.tiles_y * B * pu.groups * pu.WN;
+        if (wf >= 512) return true;              // >= half of the chip's 1024 SIMDs busy
+        return wu < 1.5 * wf;
+    }
+
+    // Residual(PreNorm(LinearAttention)) (network_components.py:10-16,69-77,117-139)
+    Act attention(const AttnW &at, Act x, float *sm, float *sr) {
+        if (rc) return Act();
+        const int C = at.C, H = x.H, W = x.W, N = H * W;
+        Act qkv = new_act(3 * C, H, W);
+        ConvOpts oq;
+        oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_g = at.ng; oq.pre_b = at.nb; oq.no_bias = true;
+        conv(at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
+        float *kmax = dalloc((size_t)B * C), *ksum = dalloc((size_t)B * C);
+        const int tiles = ceil_div(C, 64);
+        int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
+        nsplit = std::min(nsplit, std::max(1, N / 64));
+        float *S = dalloc((size_t)B * nsplit * C * C);
+        const int Cin_pad = round_up(C, 16), COP = round_up(C, 32);
+        float *ctxw = dalloc((size_t)B * Cin_pad * COP);
+        if (rc) return Act();
+        Op k; k.kind = Op::KSTATS; k.prof = PC_SMALL;
+        k.at = {qkv.p + (size_t)C * N, qkv.p + (size_t)2 * C * N, qkv.bs(), C, N, kmax, ksum, S, ctxw,
+                nsplit, Cin_pad, COP, 1.0f / sqrtf((float)C)};
+        k.bytes = 8.0 * B * C * N;
+        h->ops.push_back(k);
+        Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
+        p.flops = 2.0 * B * (double)C * C * N; p.bytes = 8.0 * B * C * N;
+        h->ops.push_back(p);
+        Op r = k; r.kind = Op::CTXR; r.prof = PC_SMALL; r.bytes = 4.0 * B * nsplit * C * C;
+        h->ops.push_back(r);
+        // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
+        ConvW cw;
+        cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
+        cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.bias = nullptr; cw.nz = 1;
+        Act o = new_act(C, H, W);
+        ConvOpts oo; oo.w_bs = (long long)Cin_pad * COP; oo.no_bias = true;
+        conv(cw, qkv.p, C, qkv.bs(), nullptr, 0, H, W, o.p, o.bs(), oo, false, PC_CONV1);
+        Act y = new_act(C, H, W);
+        ConvOpts oy; oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
+        conv(at.out, o.p, C, o.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
+        return y;
+    }
+};
+
+void free_program(cdc_handle *h) {
+    free_pool(&h->act_allocs);
+    h->ops.clear();
+    h->in_ctx.clear();
+    h->act_bytes = 0;
+    h->pB = h->pH = h->pW = 0;
+    h->d_time_steps = nullptr;
+    h->time_steps_B = 0;
+}
+
+// Builds the launch program of Unet.forward for batch B at H x W (unet.py:106-135).
+int build_program(cdc_handle *h, int B, int H, int W) {
+    if (h->pB == B && h->pH == H && h->pW == W) return CDC_OK;
+    free_program(h);
+    const int n = h->n_res;
+    const int down = 1 << (n - 1);
+    if (H % down || W % down)
+        return fail(h, CDC_ERR_INVALID, "H=%d, W=%d must be multiples of %d (%d downsamples)", H, W,
+                    down, n - 1);
+    Builder bd{h, B, &h->act_allocs};
+    h->in_x = bd.dalloc((size_t)B * h->cfg.channels * H * W);
+    h->in_time = bd.dalloc(B);
+    h->shift = bd.dalloc((size_t)B * h->shift_bs);
+    h->xa = bd.dalloc((size_t)B * h->cfg.channels * H * W);
+    h->xb = bd.dalloc((size_t)B * h->cfg.channels * H * W);
+    h->noise_buf = bd.dalloc((size_t)B * h->cfg.channels * H * W);
+    const int n_ctx = std::min(n - 1, (int)h->context_dims.size() - 1);   // unet.py:65-68,109
+    for (int l = 0; l < n_ctx; ++l) h->in_ctx.push_back(bd.new_act(h->context_dims[l], H >> l, W >> l));
+    if (bd.rc) return bd.rc;
+
+    Op t; t.kind = Op::TEMB; t.prof = PC_SMALL;
+    t.temb.time = h->in_time; t.temb.w0 = h->tm_w0; t.temb.b0 = h->tm_b0; t.temb.w2 = h->tm_w2;
+    t.temb.b2 = h->tm_b2; t.temb.dim = h->cfg.dim; t.temb.layers = h->d_temb_layers;
+    t.temb.n_layers = (int)h->rbs.size(); t.temb.shift = h->shift; t.temb.shift_bs = h->shift_bs;
+    h->ops.push_back(t);
+
+    Act x; x.p = h->in_x; x.C = h->cfg.channels; x.H = H; x.W = W;
+    std::vector<Act> skips;
+    size_t rbi = 0, ati = 0;
+    for (int i = 0; i < n; ++i) {
+        const int HWl = x.H * x.W;
+        float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
+        const bool has_ctx = i < n_ctx;
+        x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, sm, sr);
+        x = bd.attention(h->attns[ati++], x, sm, sr);
+        skips.push_back(x);
+        if (i < n - 1) {
+            const ConvW &dw = h->downs[i];
+            Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2);
+            bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false,
+                    PC_DOWN);
+            x = y;
+        }
+        if (bd.rc) return bd.rc;
+    }
+    {
+        const int HWl = x.H * x.W;
+        float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
+        // forward order: mid_block1, mid_attn, mid_block2 are packed after the ups in rbs/attns?
+        // No: rbs/attns are stored in FORWARD order (see cdc_finalize_weights).
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, sm, sr);
+        x = bd.attention(h->attns[ati++], x, sm, sr);
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, nullptr, nullptr);
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        Act skip = skips.back();
+        skips.pop_back();
+        const int HWl = x.H * x.W;
+        float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
+        x = bd.resblock(h->rbs[rbi++], x, &skip, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, sm, sr);
+        x = bd.attention(h->attns[ati++], x, sm, sr);
+        const ConvW &uw = h->ups[i];
+        Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2);
+        bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false,
+                PC_UP);
+        x = y;
+        if (bd.rc) return bd.rc;
+    }
+    // final_conv = Sequential(LayerNorm(dim), Conv2d(dim, out_dim, 7, padding=3))  (unet.py:104)
+    Act nrm = bd.new_act(x.C, x.H, x.W);
+    bd.ln(x.p, nrm.p, x.C, x.H * x.W, h->fin_g, h->fin_b, 0, nullptr, nullptr, nullptr, nullptr);
+    h->out_fx = bd.dalloc((size_t)B * h->out_dim * H * W);
+    bd.conv(h->fin_conv, nrm.p, nrm.C, nrm.bs(), nullptr, 0, H, W, h->out_fx,
+            (long long)h->out_dim * H * W, Builder::ConvOpts(), false, PC_CONV7);
+    if (bd.rc) return bd.rc;
+    h->pB = B; h->pH = H; h->pW = W;
+    return CDC_OK;
+}
+
+int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
+    if (h->prof) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    switch (op.kind) {
+        case Op::CONV: HIP_TRY(h, conv_launch(op.conv, op.plan, B, op.nz, st)); break;
+        case Op::LN: HIP_TRY(h, ln_launch(op.ln, B, st)); break;
+        case Op::TEMB: HIP_TRY(h, temb_launch(op.temb, B, st)); break;
+        case Op::KSTATS:
+            HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, op.at.ksum, B, st));
+            break;
+        case Op::CTXP:
+            HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
+                                          op.at.S, op.at.nsplit, B, st));
+            break;
+        case Op::CTXR:
+            HIP_TRY(h, ctx_reduce_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale,
+                                         op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
+            break;
+        case Op::DDIM: HIP_TRY(h, ddim_launch(op.ddim, st)); break;
+        case Op::COPY:
+            HIP_TRY(h, copy_channels_launch(op.cp.src, op.cp.src_bs, op.cp.dst, op.cp.dst_bs, op.cp.n,
+                                            B, st));
+            break;
+    }
+    if (h->prof) {
+        HIP_TRY(h, hipEventRecord(h->ev1, st));
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->prof_ms[op.prof] += ms;
+        h->prof_launches[op.prof] += 1;
+        h->prof_flops[op.prof] += op.flops;
+        h->prof_bytes[op.prof] += op.bytes;
+    }
+    return CDC_OK;
+}
+
+int run_unet(cdc_handle *h, hipStream_t st, const float *time_override) {
+    for (const Op &op : h->ops) {
+        if (op.kind == Op::TEMB && time_override) {
+            Op t = op;
+            t.temb.time = time_override;
+            int rc = run_op(h, t, h->pB, st);
+            if (rc) return rc;
+            continue;
+        }
+        int rc = run_op(h, op, h->pB, st);
+        if (rc) return rc;
+    }
+    return CDC_OK;
+}
+
+int copy_in(cdc_handle *h, float *dst, const float *src, size_t n, int mem, hipStream_t st) {
+    if (mem == CDC_MEM_HOST)
+        HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, st));
+    else
+        HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CDC_OK;
+}
+
+int copy_out(cdc_handle *h, float *dst, const float *src, size_t n, int mem, hipStream_t st) {
+    if (mem == CDC_MEM_HOST) {
+        HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    return CDC_OK;
+}
+
+int stage_ctx(cdc_handle *h, const float *const *ctx, int n_ctx, int B, int mem, hipStream_t st) {
+    if (n_ctx != (int)h->in_ctx.size())
+        return fail(h, CDC_ERR_INVALID, "expected %d context tensors, got %d", (int)h->in_ctx.size(),
+                    n_ctx);
+    for (int l = 0; l < n_ctx; ++l) {
+        int rc = copy_in(h, h->in_ctx[l].p, ctx[l], (size_t)B * h->in_ctx[l].bs(), mem, st);
+        if (rc) return rc;
+    }
+    return CDC_OK;
+}
+
+int ensure_device(cdc_handle *h) {
+    if (!h) return CDC_ERR_INVALID;
+    if (!h->own_stream) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0)
+            return fail(h, CDC_ERR_HIP, "no HIP device available: %s (there is no CPU fallback)",
+                        hipGetErrorString(e));
+        if (h->device >= ndev)
+            return fail(h, CDC_ERR_INVALID, "device %d out of range (%d devices)", h->device, ndev);
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreate(&h->ev0));
+        HIP_TRY(h, hipEventCreate(&h->ev1));
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return CDC_OK;
+}
+
+int check_ready(cdc_handle *h) {
+    if (!h) return CDC_ERR_INVALID;
+    if (!h->finalized) return fail(h, CDC_ERR_STATE, "weights not finalized (cdc_finalize_weights)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return CDC_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+const char *cdc_version(void) { return "cdc_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+const char *cdc_last_error(const cdc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int cdc_create(const cdc_unet_config *cfg, int device, cdc_handle **out) {
+    if (!cfg || !out) return fail(nullptr, CDC_ERR_INVALID, "null argument");
+    if (cfg->dim <= 0 || cfg->n_dim_mults < 1 || cfg->n_dim_mults > CDC_MAX_LEVELS ||
+        cfg->n_context_dim_mults < 0 || cfg->n_context_dim_mults > CDC_MAX_LEVELS || cfg->channels < 1)
+        return fail(nullptr, CDC_ERR_INVALID, "bad cdc_unet_config");
+    if (device < 0) return fail(nullptr, CDC_ERR_INVALID, "device %d out of range", device);
+    std::unique_ptr<cdc_handle> h(new cdc_handle);
+    h->cfg = *cfg;
+    h->device = device;
+    h->out_dim = cfg->out_dim > 0 ? cfg->out_dim : cfg->channels;
+    h->dims.push_back(cfg->channels);
+    for (int i = 0; i < cfg->n_dim_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);
+    h->context_dims.push_back(cfg->context_channels);
+    for (int i = 0; i < cfg->n_context_dim_mults; ++i)
+        h->context_dims.push_back(cfg->dim * cfg->context_dim_mults[i]);
+    h->n_res = cfg->n_dim_mults;
+    build_manifest(h.get());
+    // The HIP device is first touched by cdc_finalize_weights / cdc_op_* (ensure_device), so the
+    // manifest and load_tensor calls work on a host without a GPU; compute never does.
+    *out = h.release();
+    return CDC_OK;
+}
+
+void cdc_destroy(cdc_handle *h) {
+    if (!h) return;
+    if (!h->own_stream) { delete h; return; }
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_program(h);
+    free_pool(&h->weight_allocs);
+    if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int cdc_num_tensors(const cdc_handle *h) { return h ? (int)h->params.size() : CDC_ERR_INVALID; }
+
+int cdc_tensor_info(const cdc_handle *h, int index, const char **name, int64_t shape[4], int *ndim) {
+    if (!h || index < 0 || index >= (int)h->params.size()) return CDC_ERR_INVALID;
+    const Param &p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape)
+        for (size_t i = 0; i < p.shape.size() && i < 4; ++i) shape[i] = p.shape[i];
+    return CDC_OK;
+}
+
+int cdc_load_tensor(cdc_handle *h, const char *name, const float *data, const int64_t *shape,
+                    int ndim) {
+    if (!h || !name || !data || !shape) return CDC_ERR_INVALID;
+    auto it = h->pindex.find(name);
+    if (it == h->pindex.end()) return fail(h, CDC_ERR_INVALID, "unexpected key \"%s\"", name);
+    Param &p = h->params[it->second];
+    bool same = (int)p.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = p.shape[i] == shape[i];
+    if (!same) {
+        std::string got, want;
+        for (int i = 0; i < ndim; ++i) got += (i ? "," : "") + std::to_string(shape[i]);
+        for (auto d : p.shape) want += (want.empty() ? "" : ",") + std::to_string(d);
+        return fail(h, CDC_ERR_INVALID, "size mismatch for %s: got [%s], expected [%s]", name,
+                    got.c_str(), want.c_str());
+    }
+    p.host.assign(data, data + p.numel());
+    p.loaded = true;
+    h->finalized = false;
+    return CDC_OK;
+}
+
+int cdc_finalize_weights(cdc_handle *h) {
+    if (!h) return CDC_ERR_INVALID;
+    for (const Param &p : h->params)
+        if (!p.loaded) return fail(h, CDC_ERR_STATE, "missing key \"%s\"", p.name.c_str());
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    free_program(h);
+    free_pool(&h->weight_allocs);
+    h->rbs.clear(); h->attns.clear(); h->downs.clear(); h->ups.clear();
+    if ((rc = upload_param(h, "time_mlp.0.weight", &h->tm_w0))) return rc;
+    if ((rc = upload_param(h, "time_mlp.0.bias", &h->tm_b0))) return rc;
+    if ((rc = upload_param(h, "time_mlp.2.weight", &h->tm_w2))) return rc;
+    if ((rc = upload_param(h, "time_mlp.2.bias", &h->tm_b2))) return rc;
+    const int n = h->n_res;
+    int shift_off = 0;
+    // FORWARD order: downs (rb, rb, attn, down) x n ; mid_block1, mid_attn, mid_block2 ; ups
+    for (int i = 0; i < n; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        const int dout = h->dims[i + 1];
+        if ((rc = pack_resblock(h, p + ".0", down_in_channels(h, i), dout, i == 0 ? 7 : 3, &shift_off)))
+            return rc;
+        if ((rc = pack_resblock(h, p + ".1", dout, dout, 3, &shift_off))) return rc;
+        if ((rc = pack_attn(h, p + ".2", dout))) return rc;
+        if (i < n - 1) {
+            ConvW dw;
+            if ((rc = pack_named_conv(h, p + ".3.conv.weight", p + ".3.conv.bias", 2, 1, false, &dw)))
+                return rc;
+            h->downs.push_back(dw);
+        }
+    }
+    const int mid = h->dims[n];
+    if ((rc = pack_resblock(h, "mid_block1", mid, mid, 3, &shift_off))) return rc;
+    if ((rc = pack_attn(h, "mid_attn", mid))) return rc;
+    if ((rc = pack_resblock(h, "mid_block2", mid, mid, 3, &shift_off))) return rc;
+    for (int i = 0; i < n - 1; ++i) {
+        const int lvl = n - 1 - i;
+        const int din = h->dims[lvl], dout = h->dims[lvl + 1];
+        const std::string p = "ups." + std::to_string(i);
+        if ((rc = pack_resblock(h, p + ".0", dout * 2, din, 3, &shift_off))) return rc;
+        if ((rc = pack_resblock(h, p + ".1", din, din, 3, &shift_off))) return rc;
+        if ((rc = pack_attn(h, p + ".2", din))) return rc;
+        ConvW uw;
+        if ((rc = pack_named_conv(h, p + ".3.conv.weight", p + ".3.conv.bias", 2, 1, true, &uw)))
+            return rc;
+        h->ups.push_back(uw);
+    }
+    if ((rc = upload_param(h, "final_conv.0.g", &h->fin_g))) return rc;
+    if ((rc = upload_param(h, "final_conv.0.b", &h->fin_b))) return rc;
+    if ((rc = pack_named_conv(h, "final_conv.1.weight", "final_conv.1.bias", 1, 3, false, &h->fin_conv)))
+        return rc;
+    h->shift_bs = shift_off;
+    std::vector<TembLayer> tl;
+    for (const ResBlockW &rb : h->rbs) tl.push_back({rb.mlp_w, rb.mlp_b, rb.cout, rb.shift_off});
+    float *dl = nullptr;
+    if ((rc = upload(h, nullptr, tl.size() * sizeof(TembLayer) / sizeof(float) + 1, &dl,
+                     &h->weight_allocs))) return rc;
+    HIP_TRY(h, hipMemcpy(dl, tl.data(), tl.size() * sizeof(TembLayer), hipMemcpyHostToDevice));
+    h->d_temb_layers = (TembLayer *)dl;
+    h->finalized = true;
+    return CDC_OK;
+}
+
+int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const float *const *ctx,
+                     int n_ctx, float *out, int B, int H, int W, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!x || !time || !out || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    if ((rc = build_program(h, B, H, W))) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    if ((rc = copy_in(h, h->in_x, x, (size_t)B * h->cfg.channels * H * W, mem, st))) return rc;
+    if ((rc = copy_in(h, h->in_time, time, B, mem, st))) return rc;
+    if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    if ((rc = run_unet(h, st, nullptr))) return rc;
+    return copy_out(h, out, h->out_fx, (size_t)B * h->out_dim * H * W, mem, st);
+}
+
+int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float *sqrt_recip,
+                     const float *sqrt_recipm1, const float *sqrt_ac_prev,
+                     const float *one_minus_ac_prev, const float *sigma) {
+    if (!h || steps < 1 || !time_in || !sqrt_recip || !sqrt_recipm1 || !sqrt_ac_prev ||
+        !one_minus_ac_prev || !sigma)
+        return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    int rc0 = ensure_device(h);
+    if (rc0) return rc0;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (h->d_tab) { (void)hipFree(h->d_tab); h->d_tab = nullptr; }
+    std::vector<float> tab((size_t)5 * steps);
+    const float *srcs[5] = {sqrt_recip, sqrt_recipm1, sqrt_ac_prev, one_minus_ac_prev, sigma};
+    for (int k = 0; k < 5; ++k) memcpy(&tab[(size_t)k * steps], srcs[k], sizeof(float) * steps);
+    HIP_TRY(h, hipMalloc((void **)&h->d_tab, tab.size() * sizeof(float)));
+    HIP_TRY(h, hipMemcpy(h->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->h_time_in.assign(time_in, time_in + steps);
+    h->steps = steps;
+    h->time_steps_B = 0;     // forces re-upload of the per-step time rows
+    return CDC_OK;
+}
+
+static int ensure_time_rows(cdc_handle *h, int B) {
+    if (h->d_time_steps && h->time_steps_B == B) return CDC_OK;
+    std::vector<float> rows((size_t)h->steps * B);
+    for (int i = 0; i < h->steps; ++i)
+        for (int b = 0; b < B; ++b) rows[(size_t)i * B + b] = h->h_time_in[i];
+    void *p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, rows.size() * sizeof(float)));
+    h->act_allocs.push_back(p);
+    HIP_TRY(h, hipMemcpy(p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->d_time_steps = (float *)p;
+    h->time_steps_B = B;
+    return CDC_OK;
+}
+
+static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *noise, float eta,
+                          float *x_out, int B, int H, int W, int pred_mode, int clip,
+                          hipStream_t st) {
+    int rc;
+    const size_t n = (size_t)B * h->cfg.channels * H * W;
+    if (x_in != h->in_x)
+        HIP_TRY(h, hipMemcpyAsync(h->in_x, x_in, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = run_unet(h, st, h->d_time_steps + (size_t)i * B))) return rc;
+    Op op;
+    op.kind = Op::DDIM; op.prof = PC_SMALL;
+    op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i,
+               pred_mode, clip, eta, (long long)n};
+    op.bytes = 16.0 * n;
+    return run_op(h, op, B, st);
+}
+
+int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *ctx, int n_ctx,
+                  const float *noise, float eta, float *x_out, int B, int H, int W, int pred_mode,
+                  int clip, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!h->steps) return fail(h, CDC_ERR_STATE, "cdc_set_schedule has not been called");
+    if (i < 0 || i >= h->steps) return fail(h, CDC_ERR_INVALID, "step index %d out of [0,%d)", i, h->steps);
+    if (h->out_dim != h->cfg.channels)
+        return fail(h, CDC_ERR_UNSUPPORTED, "sampler needs out_dim == channels");
+    if (eta != 0.f && !noise) return fail(h, CDC_ERR_INVALID, "eta != 0 needs the noise draw");
+    if ((rc = build_program(h, B, H, W))) return rc;
+    if ((rc = ensure_time_rows(h, B))) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    const size_t n = (size_t)B * h->cfg.channels * H * W;
+    if ((rc = copy_in(h, h->in_x, x_in, n, mem, st))) return rc;
+    if (ctx && (rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    if (eta != 0.f && (rc = copy_in(h, h->noise_buf, noise, n, mem, st))) return rc;
+    if ((rc = ddim_on_device(h, h->in_x, i, h->noise_buf, eta, h->xa, B, H, W, pred_mode, clip, st)))
+        return rc;
+    return copy_out(h, x_out, h->xa, n, mem, st);
+}
+
+int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_ctx, float *out, int B,
+               int H, int W, int pred_mode, int clip, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!h->steps) return fail(h, CDC_ERR_STATE, "cdc_set_schedule has not been called");
+    if (h->out_dim != h->cfg.channels)
+        return fail(h, CDC_ERR_UNSUPPORTED, "sampler needs out_dim == channels");
+    if (!out || !ctx) return fail(h, CDC_ERR_INVALID, "null argument");
+    if ((rc = build_program(h, B, H, W))) return rc;
+    if ((rc = ensure_time_rows(h, B))) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    const size_t n = (size_t)B * h->cfg.channels * H * W;
+    if (init) { if ((rc = copy_in(h, h->in_x, init, n, mem, st))) return rc; }
+    else HIP_TRY(h, hipMemsetAsync(h->in_x, 0, n * sizeof(float), st));
+    if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    // for i in reversed(range(steps)): img = ddim(img, i)      (x: :188-200 ; eps: :174-190)
+    for (int i = h->steps - 1; i >= 0; --i)
+        if ((rc = ddim_on_device(h, h->in_x, i, nullptr, 0.f, h->in_x, B, H, W, pred_mode, clip, st)))
+            return rc;
+    return copy_out(h, out, h->in_x, n, mem, st);
+}
+
+int cdc_prof_enable(cdc_handle *h, int on) { if (!h) return CDC_ERR_INVALID; h->prof = on != 0; return CDC_OK; }
+int cdc_prof_num_classes(void) { return PC_COUNT; }
+const char *cdc_prof_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *flops, double *bytes) {
+    if (!h || cls < 0 || cls >= PC_COUNT) return CDC_ERR_INVALID;
+    if (ms) *ms = h->prof_ms[cls];
+    if (launches) *launches = h->prof_launches[cls];
+    if (flops) *flops = h->prof_flops[cls];
+    if (bytes) *bytes = h->prof_bytes[cls];
+    return CDC_OK;
+}
+int cdc_prof_reset(cdc_handle *h) {
+    if (!h) return CDC_ERR_INVALID;
+    for (int i = 0; i < PC_COUNT; ++i) {
+        h->prof_ms[i] = h->prof_flops[i] = h->prof_bytes[i] = 0;
+        h->prof_launches[i] = 0;
+    }
+    return CDC_OK;
+}
+
+}  // extern "C"
+
+// ---- single operators ----------------------------------------------------------------------------
+namespace {
+
+struct OpScope {                 // temporary device pool + op list for the cdc_op_* entry points
+    cdc_handle *h;
+    std::vector<void *> pool;
+    std::vector<Op> saved_ops;
+    int saved_shift_bs;
+    explicit OpScope(cdc_handle *hh) : h(hh), saved_shift_bs(hh->shift_bs) { saved_ops.swap(h->ops); }
+    ~OpScope() {
+        (void)hipDeviceSynchronize();
+        free_pool(&pool);
+        h->ops.swap(saved_ops);
+        h->shift_bs = saved_shift_bs;
+    }
+    int up(const float *src, size_t n, float **dst) { return upload(h, src, n, dst, &pool); }
+    int run(int B, float *host_out, const float *dev_out, size_t n) {
+        hipStream_t st = h->own_stream;
+        for (const Op &op : h->ops) {
+            int rc = run_op(h, op, B, st);
+            if (rc) return rc;
+        }
+        HIP_TRY(h, hipStreamSynchronize(st));
+        HIP_TRY(h, hipMemcpy(host_out, dev_out, n * sizeof(float), hipMemcpyDeviceToHost));
+        return CDC_OK;
+    }
+};
+
+int op_ready(cdc_handle *h) { return ensure_device(h); }
+
+}  // namespace
+
+extern "C" {
+
+int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y, int B,
+                  int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                  const float *ln_g, const float *ln_b, int relu, const float *shift,
+                  const float *resid) {
+    int rc = op_ready(h);
+    if (rc) return rc;
+    if (!x || !w || !y) return fail(h, CDC_ERR_INVALID, "null argument");
+    OpScope sc(h);
+    Builder bd{h, B, &sc.pool};
+    ConvW cw;
+    if ((rc = pack_conv(h, w, bias, Cout, Cin, KH, KW, stride, pad, false, &cw, &sc.pool))) return rc;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    float *dx, *dg = nullptr, *db = nullptr, *ds = nullptr, *dr = nullptr;
+    if ((rc = sc.up(x, (size_t)B * Cin * H * W, &dx))) return rc;
+    if (ln_g && (rc = sc.up(ln_g, Cout, &dg))) return rc;
+    if (ln_b && (rc = sc.up(ln_b, Cout, &db))) return rc;
+    if (shift && (rc = sc.up(shift, (size_t)B * Cout, &ds))) return rc;
+    if (resid && (rc = sc.up(resid, (size_t)B * Cout * Ho * Wo, &dr))) return rc;
+    h->shift_bs = Cout;
+    float *dy = bd.dalloc((size_t)B * Cout * Ho * Wo);
+    if (bd.rc) return bd.rc;
+    Builder::ConvOpts o;
+    o.ln_g = dg; o.ln_b = db; o.relu = relu; o.shift = ds;
+    o.resid = dr; o.resid_bs = (long long)Cout * Ho * Wo; o.resid_cs = (long long)Ho * Wo;
+    const long long obs = (long long)Cout * Ho * Wo;
+    const int prof = KH == 7 ? PC_CONV7 : (KH == 1 ? PC_CONV1 : PC_CONV3);
+    if (dg) {
+        if (!bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, o, true, prof)) {
+            bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, Builder::ConvOpts(),
+                    false, prof);
+            bd.ln(dy, dy, Cout, Ho * Wo, dg, db, relu, ds, dr, nullptr, nullptr);
+        }
+    } else {
+        bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, o, false, prof);
+    }
+    if (bd.rc) return bd.rc;
+    return sc.run(B, y, dy, (size_t)B * Cout * Ho * Wo);
+}
+
+int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y,
+                            int B, int Cin, int H, int W, int Cout) {
+    int rc = op_ready(h);
+    if (rc) return rc;
+    if (!x || !w || !y) return fail(h, CDC_ERR_INVALID, "null argument");
+    OpScope sc(h);
+    Builder bd{h, B, &sc.pool};
+    ConvW cw;
+    if ((rc = pack_conv(h, w, bias, Cout, Cin, 4, 4, 2, 1, true, &cw, &sc.pool))) return rc;
+    float *dx;
+    if ((rc = sc.up(x, (size_t)B * Cin * H * W, &dx))) return rc;
+    const size_t ny = (size_t)B * Cout * 4 * H * W;
+    float *dy = bd.dalloc(ny);
+    if (bd.rc) return bd.rc;
+    bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, (long long)Cout * 4 * H * W,
+            Builder::ConvOpts(), false, PC_UP);
+    if (bd.rc) return bd.rc;
+    return sc.run(B, y, dy, ny);
+}
+
+int cdc_op_chan_layernorm(cdc_handle *h, const float *x, const float *g, const float *b, float *y, int B,
+                          int C, int HW) {
+    int rc = op_ready(h);
+    if (rc) return rc;
+    if (!x || !g || !b || !y) return fail(h, CDC_ERR_INVALID, "null argument");
+    OpScope sc(h);
+    Builder bd{h, B, &sc.pool};
+    float *dx, *dg, *db;
+    if ((rc = sc.up(x, (size_t)B * C * HW, &dx))) return rc;
+    if ((rc = sc.up(g, C, &dg))) return rc;
+    if ((rc = sc.up(b, C, &db))) return rc;
+    float *dy = bd.dalloc((size_t)B * C * HW);
+    if (bd.rc) return bd.rc;
+    bd.ln(dx, dy, C, HW, dg, db, 0, nullptr, nullptr, nullptr, nullptr);
+    return sc.run(B, y, dy, (size_t)B * C * HW);
+}
+
+int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, const float *norm_b,
+                            const float *w_qkv, const float *w_out, const float *b_out, float *y, int B,
+                            int C, int H, int W) {
+    int rc = op_ready(h);
+    if (rc) return rc;
+    if (!x || !norm_g || !norm_b || !w_qkv || !w_out || !b_out || !y)
+        return fail(h, CDC_ERR_INVALID, "null argument");
+    OpScope sc(h);
+    Builder bd{h, B, &sc.pool};
+    AttnW at;
+    at.C = C;
+    if ((rc = pack_conv(h, w_qkv, nullptr, 3 * C, C, 1, 1, 1, 0, false, &at.qkv, &sc.pool))) return rc;
+    if ((rc = pack_conv(h, w_out, b_out, C, C, 1, 1, 1, 0, false, &at.out, &sc.pool))) return rc;
+    if ((rc = sc.up(norm_g, C, &at.ng))) return rc;
+    if ((rc = sc.up(norm_b, C, &at.nb))) return rc;
+    Act ax;
+    ax.C = C; ax.H = H; ax.W = W;
+    if ((rc = sc.up(x, (size_t)B * C * H * W, &ax.p))) return rc;
+    float *sm = bd.dalloc((size_t)B * H * W), *sr = bd.dalloc((size_t)B * H * W);
+    if (bd.rc) return bd.rc;
+    bd.ln(ax.p, nullptr, C, H * W, nullptr, nullptr, 0, nullptr, nullptr, sm, sr);   // statistics only
+    Act ay = bd.attention(at, ax, sm, sr);
+    if (bd.rc) return bd.rc;
+    return sc.run(B, y, ay.p, (size_t)B * C * H * W);
+}
+
+}  // extern "C"

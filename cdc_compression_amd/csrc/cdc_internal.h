@@ -1,0 +1,91 @@
+// cdc_internal.h -- host-side declarations shared by the translation units of libcdc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "conv_args.h"
+
+namespace cdc {
+
+// ---- convolution (conv_launch.hip) ---------------------------------------------------------------
+typedef void (*conv_kernel_fn)(const ConvArgs);
+conv_kernel_fn conv_lookup_a(int MB, int NPW, bool lnload);   // MB 1..3
+conv_kernel_fn conv_lookup_b(int MB, int NPW, bool lnload);   // MB 4..6
+conv_kernel_fn conv_lookup_c(int MB, int NPW, bool lnload);   // MB 7..12
+
+struct ConvShape {
+    int Cin, Cout, KH, KW, stride;
+    int Ho, Wo;          // output extent (per phase for ConvTranspose)
+    int B;
+    bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel
+    bool lnload;
+};
+// Chooses MB/NPW/WN/KC/tiling.  Returns false if need_all_cout cannot be honoured.
+bool conv_make_plan(const ConvShape &s, ConvPlan *plan);
+// Fills the tiling-dependent fields of `a` from the plan and launches (nz = gridDim.z).
+hipError_t conv_launch(ConvArgs a, const ConvPlan &plan, int B, int nz, hipStream_t st);
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- auxiliary kernels (aux_kernels.hip) ---------------------------------------------------------
+struct LnArgs {
+    const float *in;
+    float *out;               // may alias `in`; null = statistics only
+    int C, HW;
+    const float *g, *b;       // [C]
+    float eps;
+    int relu;
+    const float *shift;       // [B][shift_bs] or null
+    int shift_bs;
+    const float *resid;       // same layout as in, or null
+    float *stat_mean, *stat_rstd;   // [B][HW] statistics of the FINAL values, or null
+};
+hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st);
+
+struct TembLayer {            // one ResnetBlock.mlp (network_components.py:96-100)
+    const float *w, *bias;    // Linear(dim -> cout): [cout][dim], [cout]
+    int cout;
+    int out_off;              // offset of this block's row inside shift[b]
+};
+struct TembArgs {
+    const float *time;        // [B]
+    const float *w0, *b0;     // Linear(1 -> 4d)
+    const float *w2, *b2;     // Linear(4d -> d)
+    int dim;
+    const TembLayer *layers;  // device array
+    int n_layers;
+    float *shift;             // [B][shift_bs]
+    int shift_bs;
+};
+hipError_t temb_launch(const TembArgs &a, int B, hipStream_t st);
+
+// k-softmax statistics over the spatial axis (network_components.py:134): per (b, channel) row
+hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, float *ksum,
+                         int B, hipStream_t st);
+// S[b][split][d][e] = sum_{n in split} exp(k[d,n]-kmax[d]) * v[e,n]      (:135, unnormalised)
+hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
+                              const float *kmax, float *S, int nsplit, int B, hipStream_t st);
+// ctxw[b][d][e] = scale * sum_split S / ksum[d], written as per-image packed 1x1 weights
+// [Cin_pad][COP] (rows d >= C and cols e >= C zeroed)
+hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
+                             float *ctxw, int Cin_pad, int COP, int B, hipStream_t st);
+
+struct DdimArgs {
+    const float *fx, *x, *noise;
+    float *x_next;
+    const float *tab;   // device table [5][steps]: sqrt_recip, sqrt_recipm1, sqrt_ac_prev,
+                        //                          one_minus_ac_prev, sigma
+    int steps, i;
+    int pred_mode, clip;
+    float eta;
+    long long n;
+};
+hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
+hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
+                                long long n_per_image, int B, hipStream_t st);
+
+}  // namespace cdc

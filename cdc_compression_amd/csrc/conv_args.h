@@ -1,0 +1,69 @@
+// conv_args.h -- kernel argument block + launch plan of the implicit-GEMM convolution kernel.
+//
+// One kernel family implements every dense contraction of the U-Net
+// (reference call sites: Block conv k x k  network_components.py:87, res_conv 1x1 :105,
+//  to_qkv / to_out 1x1 :125-126, Downsample 3x3 s2 :50, Upsample ConvTranspose 4x4 s2 :39 as four
+//  2x2 phase convolutions, final 7x7 unet.py:104, and the per-image ctx^T.q product :137).
+//
+// GEMM orientation: D[cout][pixel] = sum_k Wp[k][cout] * X[k][pixel], k = (tap, cin), computed
+// with v_mfma_f32_32x32x2_f32 (A = weights, B = pixels).  Each lane then owns ONE pixel and 16
+// output channels per 32x32 block, so the channel-LayerNorm reduction is in-lane adds plus one
+// cross-half exchange, and NCHW rows are written as 128-byte segments.
+#pragma once
+#include <stdint.h>
+
+namespace cdc {
+
+constexpr int kWaveSize = 64;
+constexpr int kXE = 24;   // per-thread prefetch registers for the input patch (floats)
+constexpr int kWE = 16;   // per-thread prefetch registers for the weight chunk (float4)
+
+struct ConvArgs {
+    // input: channel-concatenation of up to two NCHW sources (torch.cat sites unet.py:109,124)
+    const float *src0, *src1;
+    long long src0_bs, src1_bs;     // batch strides in floats (0 = broadcast over batch)
+    int C0, Cin;                    // channels taken from src0; total input channels
+    int H, W;                       // input spatial size
+    // optional LayerNorm applied while staging the input (PreNorm, network_components.py:69-77)
+    const float *ln_mean, *ln_rstd; // [B][H*W] statistics of the (single) source
+    const float *ln_g, *ln_b;       // [Cin]
+    // packed weights [z][taps][Cin_pad][COP] (zero padded); w_bs = per-image stride (0 = shared)
+    const float *wp;
+    long long w_bs, w_zs;
+    int KH, KW, stride;
+    int pad_y[4], pad_x[4];         // per blockIdx.z (ConvTranspose phases); z = 0 otherwise
+    int KC, logKC, nchunk, Cin_pad, COP, Cout;
+    // output tensor addressing (floats): b*out_bs + co*out_cs + oy*out_ys + ox*out_xs + out_zoff[z]
+    float *out;
+    long long out_bs, out_cs;
+    int out_ys, out_xs, out_zoff[4];
+    int Ho, Wo;                     // logical output extent of one phase
+    // tiling
+    int lognbw;                     // a 32-pixel N-block is (32>>lognbw) rows x (1<<lognbw) cols
+    int tiles_x, tiles_y;
+    int PH, PW, PWp;                // staged input patch: rows, cols, padded row stride
+    unsigned magic_hw, magic_w;     // fast division by PH*PW and by PW (0 => divisor is 1)
+    // epilogue
+    const float *bias;              // [Cout] or null
+    const float *ep_g, *ep_b;       // channel LayerNorm after bias (needs gridDim.y == 1)
+    float eps;
+    int relu;
+    const float *shift;             // [B][shift_bs] added after ReLU (time-embedding add)
+    int shift_bs;
+    const float *resid;             // same addressing as out, added last (ResnetBlock / Residual)
+    long long resid_bs, resid_cs;
+    float *stat_mean, *stat_rstd;   // [B][Ho*Wo]: LN statistics of the final values (for the next
+                                    // PreNorm); needs gridDim.y == 1
+};
+
+// Host-side launch plan for one convolution.
+struct ConvPlan {
+    int MB, NPW, WN;        // cout blocks per wave, pixel blocks per wave, waves per workgroup
+    int groups;             // cout groups (gridDim.y)
+    int KC, nchunk;
+    int lognbw, tiles_x, tiles_y, PH, PW, PWp;
+    size_t lds_bytes;
+    bool lnload;
+};
+
+}  // namespace cdc

@@ -1,0 +1,122 @@
+// conv_launch.hip -- launch-plan chooser and launcher of the implicit-GEMM convolution kernel.
+#include <algorithm>
+
+#include "cdc_internal.h"
+
+namespace cdc {
+
+static unsigned magic_of(unsigned d) {
+    if (d <= 1) return 0u;                       // kernel treats 0 as "divide by 1"
+    return (unsigned)(((1ull << 32) + d - 1) / d);
+}
+
+static conv_kernel_fn lookup(int MB, int NPW, bool lnload) {
+    if (MB <= 3) return conv_lookup_a(MB, NPW, lnload);
+    if (MB <= 6) return conv_lookup_b(MB, NPW, lnload);
+    return conv_lookup_c(MB, NPW, lnload);
+}
+
+// LDS budget per workgroup.  The register-staged pipeline keeps ONE buffer set in LDS (the next
+// chunk sits in registers), so up to two workgroups fit a CU's 160 KiB.
+static constexpr size_t kLdsBudget = 72 * 1024;
+
+static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p) {
+    const int nblocks = ceil_div(s.Cout, 32);
+    if (nblocks % MB) return false;
+    if (!lookup(MB, NPW, s.lnload)) return false;
+    const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
+    const int nb_rows = ceil_div(s.Ho, NBH);
+    int WN = std::min(4, ceil_div(nb_rows, NPW));
+    if (WN == 3) WN = 4;
+    const int nthr = 64 * WN;
+    const int TH = WN * NPW * NBH;
+    const int PH = (TH - 1) * s.stride + s.KH;
+    const int PW = (NBW - 1) * s.stride + s.KW;
+    const int PWp = PW | 1;
+    const int taps = s.KH * s.KW;
+    const int COPT = MB * 32;
+    int KC = 0;
+    for (int kc : {16, 8, 4}) {
+        if (kc > round_up(s.Cin, 4) && kc > 4) continue;      // do not over-pad tiny Cin
+        const bool x_ok = kc * PH * PW <= kXE * nthr;
+        const bool w_ok = taps * kc * (COPT / 4) <= kWE * nthr;
+        const size_t lds = sizeof(float) * ((size_t)taps * kc * COPT + (size_t)kc * PH * PWp);
+        if (x_ok && w_ok && lds <= kLdsBudget) { KC = kc; break; }
+    }
+    if (!KC) return false;
+    p->MB = MB; p->NPW = NPW; p->WN = WN;
+    p->groups = nblocks / MB;
+    p->KC = KC;
+    p->nchunk = ceil_div(s.Cin, KC);
+    p->lognbw = lognbw;
+    p->tiles_x = ceil_div(s.Wo, NBW);
+    p->tiles_y = ceil_div(s.Ho, TH);
+    p->PH = PH; p->PW = PW; p->PWp = PWp;
+    p->lds_bytes = std::max(sizeof(float) * ((size_t)taps * KC * COPT + (size_t)KC * PH * PWp),
+                            sizeof(float) * 4 * COPT);
+    p->lnload = s.lnload;
+    return true;
+}
+
+bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
+    const int nblocks = ceil_div(s.Cout, 32);
+    int lognbw = 5;
+    while (lognbw > 2 && (1 << (lognbw - 1)) >= s.Wo) --lognbw;   // NBW = smallest pow2 >= Wo (<=32, >=4)
+    std::vector<int> mbs;
+    if (s.need_all_cout) {
+        if (nblocks > 12) return false;
+        mbs.push_back(nblocks);
+    } else {
+        for (int mb = std::min(6, nblocks); mb >= 1; --mb)
+            if (nblocks % mb == 0) mbs.push_back(mb);
+    }
+    const int NBH = 32 >> lognbw;
+    const int nb_rows = ceil_div(s.Ho, NBH);
+    ConvPlan best;
+    double best_score = -1;
+    for (int MB : mbs) {
+        for (int NPW : {4, 2, 1}) {
+            if (MB * NPW > 12) continue;
+            if (NPW > 1 && NPW > nb_rows) continue;
+            ConvPlan p;
+            if (!try_plan(s, MB, NPW, lognbw, &p)) continue;
+            // score: prefer register blocking (fewer LDS reads per MFMA) but keep the chip filled
+            const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups;
+            const double fill = std::min(1.0, wgs * p.WN / (256.0 * 4.0));
+            const double reuse = (double)(MB * NPW) / (MB + NPW);
+            const double kc_f = p.KC >= 8 ? 1.0 : 0.9;
+            const double score = fill * (0.6 + 0.1 * std::min(reuse, 4.0)) * kc_f;
+            if (score > best_score) { best_score = score; best = p; }
+        }
+        if (s.need_all_cout) break;
+    }
+    if (best_score < 0) return false;
+    *plan = best;
+    return true;
+}
+
+hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t st) {
+    a.KC = p.KC;
+    a.logKC = p.KC == 16 ? 4 : (p.KC == 8 ? 3 : 2);
+    a.nchunk = p.nchunk;
+    a.lognbw = p.lognbw;
+    a.tiles_x = p.tiles_x;
+    a.tiles_y = p.tiles_y;
+    a.PH = p.PH; a.PW = p.PW; a.PWp = p.PWp;
+    a.magic_hw = magic_of((unsigned)(p.PH * p.PW));
+    a.magic_w = magic_of((unsigned)p.PW);
+    conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnload);
+    if (!fn) return hipErrorInvalidValue;
+    if (p.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
+    dim3 block(64 * p.WN);
+    hipLaunchKernelGGL(fn, grid, block, p.lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace cdc

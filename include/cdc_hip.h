@@ -1,0 +1,150 @@
+/*
+ * cdc_hip.h -- C-ABI of libcdc_hip.so: the MI355X (gfx950) decode hot path of CDC
+ * (conditional-diffusion image compression), i.e. the N-step DDIM loop over the denoising U-Net.
+ *
+ * The reference (buggyyang/CDC_compression) has no FFI: the path sits behind Python methods.
+ * Each entry point below names the reference interface it replaces (paths relative to the
+ * reference root).  A drop-in binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; tensors are dense float32, NCHW, exactly as the reference passes them;
+ *   - every function returns CDC_OK (0) or a negative cdc_status; it never throws;
+ *     cdc_last_error(h) returns a human-readable message for the last failure on that handle;
+ *   - a handle is bound to one HIP device and is NOT thread-safe (one handle per GPU per thread);
+ *   - pointers tagged `mem` are host pointers (CDC_MEM_HOST: the library stages them through
+ *     its own device buffers) or device pointers on the handle's device (CDC_MEM_DEVICE: used in
+ *     place, zero copy); `stream` is a hipStream_t passed as void* (NULL = the library's own
+ *     stream).  Calls are asynchronous on `stream` when all pointers are device pointers, and
+ *     synchronous (result valid on return) when any host pointer is involved.
+ */
+#ifndef CDC_HIP_H
+#define CDC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cdc_handle cdc_handle;
+
+typedef enum {
+    CDC_OK = 0,
+    CDC_ERR_INVALID = -1,      /* bad argument / shape / name */
+    CDC_ERR_STATE = -2,        /* call order (weights not finalized, schedule not set, ...) */
+    CDC_ERR_HIP = -3,          /* HIP runtime error (message has the hipError string) */
+    CDC_ERR_UNSUPPORTED = -4,  /* configuration outside what the kernels implement */
+    CDC_ERR_NOMEM = -5
+} cdc_status;
+
+enum { CDC_MEM_HOST = 0, CDC_MEM_DEVICE = 1 };
+enum { CDC_PRED_X = 0, CDC_PRED_NOISE = 1 };
+enum { CDC_MAX_LEVELS = 8 };
+
+/* Unet.__init__ arguments: xparam/modules/unet.py:19-29 (epsilonparam/modules/unet.py:18-27).
+ * with_time_emb is always true on the tested path; embd_type "01" only (unet.py:39-41). */
+typedef struct {
+    int32_t dim;
+    int32_t channels;
+    int32_t context_channels;
+    int32_t out_dim;                                /* 0 -> channels (unet.py:103) */
+    int32_t n_dim_mults;
+    int32_t dim_mults[CDC_MAX_LEVELS];
+    int32_t n_context_dim_mults;
+    int32_t context_dim_mults[CDC_MAX_LEVELS];
+} cdc_unet_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* Builds the layer graph of Unet.__init__ (unet.py:19-104) for `device`. */
+int cdc_create(const cdc_unet_config *cfg, int device, cdc_handle **out);
+void cdc_destroy(cdc_handle *h);
+const char *cdc_last_error(const cdc_handle *h);   /* h may be NULL: last cdc_create error */
+const char *cdc_version(void);
+
+/* ---- parameters: replaces nn.Module.load_state_dict on the Unet (test_xparam.py:62-68) ------- */
+
+/* Manifest of the reference Unet.state_dict(): count, then (name, shape) per index. */
+int cdc_num_tensors(const cdc_handle *h);
+int cdc_tensor_info(const cdc_handle *h, int index, const char **name, int64_t shape[4],
+                    int *ndim);
+/* `name` = reference state_dict key (e.g. "downs.0.0.block1.block.0.weight"), data in the
+ * reference's layout (Conv2d OIHW, ConvTranspose2d IOHW, Linear [out][in], LayerNorm [1,C,1,1]);
+ * the library repacks into its MFMA operand layout.  Host pointer only. */
+int cdc_load_tensor(cdc_handle *h, const char *name, const float *data, const int64_t *shape,
+                    int ndim);
+/* Fails (CDC_ERR_STATE) listing the first missing tensor if any manifest entry was not loaded. */
+int cdc_finalize_weights(cdc_handle *h);
+
+/* ---- Unet.forward(x, time, context): xparam/modules/unet.py:131-135 -------------------------- */
+
+/* x [B,channels,H,W]; time [B] (the reference passes [B,1]); ctx[l] [B,C_l,H>>l,W>>l] for
+ * l < n_ctx (C_l = context_dims[l], unet.py:34,109); out [B,out_dim,H,W]. */
+int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const float *const *ctx,
+                     int n_ctx, float *out, int B, int H, int W, int mem, void *stream);
+
+/* ---- sampler: GaussianDiffusion.set_sample_schedule / ddim / p_sample_loop ------------------- */
+
+/* Per-sample-step scalars, index i = 0..steps-1 in the reference's `t` indexing
+ * (xparam/modules/denoising_diffusion.py:89-108 ; epsilonparam/...:81-97).  The host computes
+ * them (float64 beta schedule -> float32 tables) and hands them over:
+ *   time_in[i]         value fed to the U-Net:  x-param index[i]/num_timesteps (:154),
+ *                                               eps-param i/sample_steps (eps :138)
+ *   sqrt_recip[i], sqrt_recipm1[i]   sqrt(1/ac), sqrt(1/ac-1)
+ *   sqrt_ac_prev[i], one_minus_ac_prev[i], sigma[i]                                        */
+int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float *sqrt_recip,
+                     const float *sqrt_recipm1, const float *sqrt_ac_prev,
+                     const float *one_minus_ac_prev, const float *sigma);
+
+/* One DDIM update x_t -> x_{t-1} at sample index i (x: :152-174 ; eps: :137-152).
+ * clip: x-param clamp of x0 to [-1,1] (clip_denoised=True in compress, :223);
+ *       eps-param clip_noise "full" -> 1, anything else -> 0.
+ * noise: the torch.randn_like draw of that step (used only when eta != 0; may be NULL). */
+int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *ctx, int n_ctx,
+                  const float *noise, float eta, float *x_out, int B, int H, int W,
+                  int pred_mode, int clip, int mem, void *stream);
+
+/* p_sample_loop with eta = 0 (x: :179-205 ; eps: :166-192): for i = steps-1 .. 0: ddim.
+ * init may be NULL (zeros, :183).  This is the timed hot path of bench.py. */
+int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_ctx, float *out,
+               int B, int H, int W, int pred_mode, int clip, int mem, void *stream);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+/* Kernel-class timing (hipEvents on the launch stream) of the most recent forward/decode when
+ * profiling is enabled; classes are listed by cdc_prof_name.  Off by default. */
+int cdc_prof_enable(cdc_handle *h, int on);
+int cdc_prof_num_classes(void);
+const char *cdc_prof_name(int cls);
+/* ms = accumulated GPU milliseconds, launches = kernel launches, flops = executed MFMA flops,
+ * bytes = algorithmic global bytes (inputs read once + outputs written once per launch). */
+int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *flops,
+                 double *bytes);
+int cdc_prof_reset(cdc_handle *h);
+
+/* ---- single operators (used by the parity tests; same kernels the U-Net graph launches) ------ */
+
+/* F.conv2d(x, w[Cout,Cin,KH,KW], bias, stride, padding) with the fused epilogue options of
+ * Block/ResnetBlock (network_components.py:83-114):
+ *   ln_g/ln_b != NULL: channel LayerNorm (eps 1e-5) after bias;  relu: ReLU after LN;
+ *   shift [B,Cout] != NULL: + shift[b,co] after ReLU (the time-embedding add, :110-111);
+ *   resid [B,Cout,Ho,Wo] != NULL: + resid at the end (:114).  Host pointers. */
+int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y,
+                  int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                  const float *ln_g, const float *ln_b, int relu, const float *shift,
+                  const float *resid);
+/* F.conv_transpose2d(x, w[Cin,Cout,4,4], bias, stride=2, padding=1) (Upsample, :34-42). */
+int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const float *bias,
+                            float *y, int B, int Cin, int H, int W, int Cout);
+/* LayerNorm.forward (:56-66). */
+int cdc_op_chan_layernorm(cdc_handle *h, const float *x, const float *g, const float *b, float *y,
+                          int B, int C, int HW);
+/* Residual(PreNorm(LinearAttention)) (:10-16,69-77,117-139): y = to_out(attn(to_qkv(LN(x)))) + x. */
+int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g,
+                            const float *norm_b, const float *w_qkv, const float *w_out,
+                            const float *b_out, float *y, int B, int C, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDC_HIP_H */

@@ -1,0 +1,106 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+mirrors reproduce the reference's state_dict manifest and sampling schedules, and compute entry
+points fail loudly (no CPU fallback) when no GPU is present."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cdc_compression_amd as cdc
+from cdc_compression_amd import _lib, schedule
+from helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cdc_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(cdc_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"libcdc_hip.so does not export {name}"
+    assert sorted(_lib.EXPORTS) == declared
+    assert b"gfx950" in L.cdc_version()
+
+
+@pytest.mark.parametrize("name", ["small_x", "small_eps", "odd_x", "full_x", "full_eps"])
+def test_manifest_matches_reference_state_dict(name):
+    mj = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    kw = dict(mj["unet_kwargs"])
+    kw.pop("embd_type", None)
+    un = cdc.Unet(**kw)
+    got = [(n, list(s)) for n, s in un.manifest()]
+    assert got == [(n, list(s)) for n, s in mj["manifest"]]
+
+
+def test_schedule_tables_match_reference():
+    g = np.load(os.path.join(GOLDEN, "schedules.npz"))
+    for tag, T, vs in (("x", 8193, "cosine"), ("eps", 20000, "linear")):
+        for steps in (1, 2, 4, 7, 65, 200, 500, 1000):
+            s = schedule.SampleSchedule(T, vs, tag, steps)
+            np.testing.assert_array_equal(s.alphas_cumprod, g[f"{tag}_{steps}_alphas_cumprod"])
+            np.testing.assert_array_equal(s.one_minus_ac_prev,
+                                          g[f"{tag}_{steps}_one_minus_alphas_cumprod_prev"])
+            # sqrt-derived tables: torch's vectorised CPU sqrt is not correctly rounded (1-ulp misses)
+            np.testing.assert_array_max_ulp(s.sqrt_recip, g[f"{tag}_{steps}_sqrt_recip_alphas_cumprod"], 2)
+            np.testing.assert_array_max_ulp(s.sqrt_recipm1,
+                                            g[f"{tag}_{steps}_sqrt_recipm1_alphas_cumprod"], 2)
+            np.testing.assert_array_max_ulp(s.sqrt_ac_prev, g[f"{tag}_{steps}_sqrt_alphas_cumprod_prev"], 2)
+            np.testing.assert_array_max_ulp(s.sigma, g[f"{tag}_{steps}_sigma"], 6)
+            if tag == "x":
+                np.testing.assert_array_equal(s.index, g[f"x_{steps}_index"])
+                np.testing.assert_array_equal(
+                    s.time_in, (g[f"x_{steps}_index"].astype(np.float32) / np.float32(8193)))
+
+
+def test_linspace_index_matches_torch():
+    torch = pytest.importorskip("torch")
+    for T in (8193, 20000):
+        for steps in list(range(1, 130)) + [200, 333, 500, 777, 1000]:
+            np.testing.assert_array_equal(schedule.linspace_index(T, steps),
+                                          torch.linspace(0, T - 1, steps).long().numpy())
+
+
+def test_load_state_dict_is_strict():
+    un = cdc.Unet(dim=16, channels=3, context_channels=8, dim_mults=(1, 2, 3), context_dim_mults=(1, 2))
+    man = un.manifest()
+    sd = {k: np.zeros(s, np.float32) for k, s in man}
+    bad = dict(sd)
+    bad.pop("final_conv.1.bias")
+    with pytest.raises(RuntimeError, match="missing"):
+        un.load_state_dict(bad)
+    bad = dict(sd)
+    bad["downs.0.0.block1.block.0.weight"] = np.zeros((16, 11, 3, 3), np.float32)
+    with pytest.raises(_lib.CdcError, match="size mismatch"):
+        un.load_state_dict(bad)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a host without a GPU")
+def test_compute_fails_loudly_without_gpu():
+    un = cdc.Unet(dim=16, channels=3, context_channels=8, dim_mults=(1, 2, 3), context_dim_mults=(1, 2))
+    sd = {k: np.zeros(s, np.float32) for k, s in un.manifest()}
+    with pytest.raises(_lib.CdcError, match="no HIP device"):
+        un.load_state_dict(sd)
+    from cdc_compression_amd.ops import Ops
+    with pytest.raises(_lib.CdcError, match="no HIP device"):
+        Ops().chan_layernorm(np.zeros((1, 4, 2, 2), np.float32), np.ones(4), np.zeros(4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cdc_compression_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f == "synth.py", f"{f} mentions the oracle"
