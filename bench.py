@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- decode throughput of the CDC hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: a full `sample_steps`-iteration DDIM decode
+(GaussianDiffusion.p_sample_loop) of `batch` synthetic 256x256 images per GPU, inputs (init noise +
+context pyramid) resident in HBM when the timed region starts.  Default workload = BASELINE.json
+configs[1]: x-param, batch 32, 256x256, 500 steps, 1 MI355X.  Multi-GPU: one process per GPU
+(torchrun), the image batch is sharded (weak scaling: 32 images per GPU), the only collective is
+the final all_gather of the decoded images over RCCL.
+
+    python bench.py                      # N=1, 1 timed decode (~1 min) + CPU baseline sample
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 1 --warmup 0
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FULL = {
+    "x": dict(kw=dict(dim=64, channels=3, context_channels=64, dim_mults=(1, 2, 3, 4, 5, 6),
+                      context_dim_mults=(1, 2, 3, 4)), ctx=[64, 64, 128, 192], T=8193, vs="cosine",
+              gflop_per_image_step=128.97),
+    "eps": dict(kw=dict(dim=64, channels=3, context_channels=3, dim_mults=(1, 2, 3, 4, 5, 6),
+                        context_dim_mults=(1, 2, 3, 4)), ctx=[3, 64, 128, 192], T=20000, vs="linear",
+                gflop_per_image_step=103.39),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def cpu_baseline(param, size, sample_steps, n_iter=2):
+    """Oracle (CPU restatement of the reference, kind="port") on the host cores: B=1, n_iter DDIM
+    iterations, extrapolated linearly to `sample_steps` (time is iteration-linear)."""
+    from cdc_compression_amd import synth
+    from oracle import model as om
+    from oracle import ops as oops
+    cfgd = FULL[param]
+    cfg = om.UnetConfig(**cfgd["kw"])
+    sd = synth.unet_state_dict(om.unet_manifest(cfg), seed=0, final_gain=0.2 if param == "eps" else 1.0)
+    O = oops.OrcOps("f32")
+    rng = np.random.default_rng(0)
+    ctx = [rng.standard_normal((1, c, size >> l, size >> l)).astype(np.float32) * 0.5
+           for l, c in enumerate(cfgd["ctx"])]
+    x = rng.standard_normal((1, 3, size, size)).astype(np.float32) * 0.8
+    sched = om.Schedule(cfgd["T"], cfgd["vs"], param).set_sample_schedule(sample_steps)
+    t0 = time.time()
+    for i in range(n_iter):
+        x = om.ddim_step(O, cfg, sd, sched, x, sample_steps - 1 - i, ctx, None,
+                         True if param == "x" else "none")
+    dt = (time.time() - t0) / n_iter
+    return {"value": 1.0 / (dt * sample_steps), "unit": "images/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"oracle/ (C+OpenMP restatement), 1 image x {n_iter} of {sample_steps} DDIM "
+                      f"iterations at {size}x{size}, {dt:.2f} s/iteration, extrapolated linearly"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1, help="timed batch decodes")
+    ap.add_argument("--warmup", type=int, default=0, help="untimed batch decodes")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--sample-steps", type=int, default=500)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--param", choices=["x", "eps"], default="x")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-every", type=int, default=50)
+    a = ap.parse_args()
+
+    import torch
+    import cdc_compression_amd as cdc
+    from cdc_compression_amd import _lib, synth
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfgd = FULL[a.param]
+    un = cdc.Unet(**cfgd["kw"], device=local)
+    un.load_state_dict(synth.unet_state_dict(un.manifest(), seed=0,
+                                             final_gain=0.2 if a.param == "eps" else 1.0))
+    if a.param == "x":
+        diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=cfgd["T"], pred_mode="x",
+                                      var_schedule=cfgd["vs"])
+    else:
+        diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=cfgd["T"], clip_noise="none",
+                                        pred_mode="noise", var_schedule=cfgd["vs"])
+    B, S = a.batch, a.size
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    init = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8          # gamma 0.8
+    ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5
+           for l, c in enumerate(cfgd["ctx"])]
+    shape = (B, 3, S, S)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    diff.decompress(ctx, shape, sample_steps=2, init=init)      # builds the launch program, pages in code
+    for _ in range(a.warmup):
+        diff.decompress(ctx, shape, sample_steps=a.sample_steps, init=init)
+    L, h = _lib.lib(), un._handle()
+    L.cdc_prof_reset(h)
+    L.cdc_prof_enable(h, max(2, a.prof_every))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rec = diff.decompress(ctx, shape, sample_steps=a.sample_steps, init=init)
+        if world > 1:
+            gathered = [torch.empty_like(rec) for _ in range(world)]
+            dist.all_gather(gathered, rec)                      # the trivial result gather (RCCL)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = bool(torch.isfinite(rec).all().item())
+
+    import ctypes
+    classes = {}
+    for c in range(L.cdc_prof_num_classes()):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        L.cdc_prof_get(h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+        classes[L.cdc_prof_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value,
+                                                   bytes=by.value)
+    L.cdc_prof_enable(h, 0)
+
+    if rank == 0:
+        images = B * world * a.steps
+        value = images / dt
+        dom = classes["conv3x3"]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        tot_ms = sum(c["ms"] for c in classes.values())
+        out = {
+            "metric": f"decoded images/sec at {S}x{S}, {a.sample_steps}-step {a.param}-param",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.param}-param decode, batch={B}/GPU synthetic {S}x{S}, "
+                                   f"{a.sample_steps} DDIM steps (BASELINE configs[1] shape)",
+                       "batch_per_gpu": B, "global_batch": B * world, "sample_steps": a.sample_steps,
+                       "parallelism": f"batch-shard x{world}", "finite": ok},
+            "roofline": {
+                "bound": "mfma", "kernel": "conv_mfma_kernel (3x3 Block convolutions, fused LN epilogue)",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+                "traffic": None,
+                "whole_path_tflops": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value,
+                "class_ms_share": {k: (v["ms"] / tot_ms if tot_ms else 0) for k, v in classes.items()},
+                "class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
+                                 for k, v in classes.items()},
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,13 @@ struct cdc_handle {
     double prof_ms[PC_COUNT] = {0}, prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0};
     int64_t prof_launches[PC_COUNT] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // deferred (non-blocking) event timing: pairs recorded on the launch stream, resolved at
+    // cdc_prof_get.  prof_every = n profiles only the DDIM iterations with i % n == 0.
+    struct Pending { hipEvent_t a, b; int cls; double flops, bytes; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_free;
+    int prof_every = 1;
+    bool prof_now = false;
 };
 
 namespace {
@@ -635,8 +642,36 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     return CDC_OK;
 }
 
+hipEvent_t get_event(cdc_handle *h) {
+    if (!h->ev_free.empty()) { hipEvent_t e = h->ev_free.back(); h->ev_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int resolve_pending(cdc_handle *h) {
+    for (auto &p : h->pending) {
+        HIP_TRY(h, hipEventSynchronize(p.b));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, p.a, p.b));
+        h->prof_ms[p.cls] += ms;
+        h->prof_launches[p.cls] += 1;
+        h->prof_flops[p.cls] += p.flops;
+        h->prof_bytes[p.cls] += p.bytes;
+        h->ev_free.push_back(p.a);
+        h->ev_free.push_back(p.b);
+    }
+    h->pending.clear();
+    return CDC_OK;
+}
+
 int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
-    if (h->prof) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    const bool prof = h->prof && h->prof_now;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (prof) {
+        ea = get_event(h); eb = get_event(h);
+        HIP_TRY(h, hipEventRecord(ea, st));
+    }
     switch (op.kind) {
         case Op::CONV: HIP_TRY(h, conv_launch(op.conv, op.plan, B, op.nz, st)); break;
         case Op::LN: HIP_TRY(h, ln_launch(op.ln, B, st)); break;
@@ -658,15 +693,9 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
                                             B, st));
             break;
     }
-    if (h->prof) {
-        HIP_TRY(h, hipEventRecord(h->ev1, st));
-        HIP_TRY(h, hipEventSynchronize(h->ev1));
-        float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        h->prof_ms[op.prof] += ms;
-        h->prof_launches[op.prof] += 1;
-        h->prof_flops[op.prof] += op.flops;
-        h->prof_bytes[op.prof] += op.bytes;
+    if (prof) {
+        HIP_TRY(h, hipEventRecord(eb, st));
+        h->pending.push_back({ea, eb, op.prof, op.flops, op.bytes});
     }
     return CDC_OK;
 }
@@ -783,6 +812,8 @@ void cdc_destroy(cdc_handle *h) {
     free_program(h);
     free_pool(&h->weight_allocs);
     if (h->d_tab) (void)hipFree(h->d_tab);
+    (void)resolve_pending(h);
+    for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -895,6 +926,7 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
     if ((rc = copy_in(h, h->in_x, x, (size_t)B * h->cfg.channels * H * W, mem, st))) return rc;
     if ((rc = copy_in(h, h->in_time, time, B, mem, st))) return rc;
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    h->prof_now = true;
     if ((rc = run_unet(h, st, nullptr))) return rc;
     return copy_out(h, out, h->out_fx, (size_t)B * h->out_dim * H * W, mem, st);
 }
@@ -988,17 +1020,28 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     else HIP_TRY(h, hipMemsetAsync(h->in_x, 0, n * sizeof(float), st));
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
     // for i in reversed(range(steps)): img = ddim(img, i)      (x: :188-200 ; eps: :174-190)
-    for (int i = h->steps - 1; i >= 0; --i)
+    for (int i = h->steps - 1; i >= 0; --i) {
+        h->prof_now = (i % h->prof_every) == 0;
         if ((rc = ddim_on_device(h, h->in_x, i, nullptr, 0.f, h->in_x, B, H, W, pred_mode, clip, st)))
             return rc;
+    }
+    h->prof_now = true;
     return copy_out(h, out, h->in_x, n, mem, st);
 }
 
-int cdc_prof_enable(cdc_handle *h, int on) { if (!h) return CDC_ERR_INVALID; h->prof = on != 0; return CDC_OK; }
+int cdc_prof_enable(cdc_handle *h, int on) {
+    if (!h) return CDC_ERR_INVALID;
+    h->prof = on != 0;
+    h->prof_every = on > 1 ? on : 1;     // on = n > 1: sample the DDIM iterations with i % n == 0
+    h->prof_now = true;
+    return CDC_OK;
+}
 int cdc_prof_num_classes(void) { return PC_COUNT; }
 const char *cdc_prof_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
 int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *flops, double *bytes) {
     if (!h || cls < 0 || cls >= PC_COUNT) return CDC_ERR_INVALID;
+    int rc = resolve_pending(h);
+    if (rc) return rc;
     if (ms) *ms = h->prof_ms[cls];
     if (launches) *launches = h->prof_launches[cls];
     if (flops) *flops = h->prof_flops[cls];
@@ -1007,6 +1050,7 @@ int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *
 }
 int cdc_prof_reset(cdc_handle *h) {
     if (!h) return CDC_ERR_INVALID;
+    (void)resolve_pending(h);
     for (int i = 0; i < PC_COUNT; ++i) {
         h->prof_ms[i] = h->prof_flops[i] = h->prof_bytes[i] = 0;
         h->prof_launches[i] = 0;

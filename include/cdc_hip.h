@@ -111,8 +111,10 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
 
 /* ---- measurement --------------------------------------------------------------------------- */
 
-/* Kernel-class timing (hipEvents on the launch stream) of the most recent forward/decode when
- * profiling is enabled; classes are listed by cdc_prof_name.  Off by default. */
+/* Kernel-class timing: hipEvent pairs recorded (without host synchronisation) on the launch stream
+ * around every kernel of a forward / DDIM iteration and resolved at cdc_prof_get.
+ * on = 0: off (default); on = 1: every launch; on = n > 1: inside cdc_decode only the DDIM
+ * iterations with i % n == 0 are instrumented (sampling inside the timed region). */
 int cdc_prof_enable(cdc_handle *h, int on);
 int cdc_prof_num_classes(void);
 const char *cdc_prof_name(int cls);
