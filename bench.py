@@ -171,6 +171,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
+        out["roofline"]["class_ms_per_ddim_iter"] = {k: v["ms"] / max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps) for k, v in classes.items()}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

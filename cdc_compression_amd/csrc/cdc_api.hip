@@ -763,6 +763,13 @@ int ensure_device(cdc_handle *h) {
     return CDC_OK;
 }
 
+// Host pointers: the library's own stream (the call synchronises before returning).  Device pointers:
+// the caller's stream, where NULL is the HIP null stream (torch's default stream), so that work
+// is ordered with the caller's own kernels and copies.
+hipStream_t pick_stream(cdc_handle *h, void *stream, int mem) {
+    return mem == CDC_MEM_DEVICE ? (hipStream_t)stream : h->own_stream;
+}
+
 int check_ready(cdc_handle *h) {
     if (!h) return CDC_ERR_INVALID;
     if (!h->finalized) return fail(h, CDC_ERR_STATE, "weights not finalized (cdc_finalize_weights)");
@@ -922,7 +929,7 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
     if (rc) return rc;
     if (!x || !time || !out || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
     if ((rc = build_program(h, B, H, W))) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    hipStream_t st = pick_stream(h, stream, mem);
     if ((rc = copy_in(h, h->in_x, x, (size_t)B * h->cfg.channels * H * W, mem, st))) return rc;
     if ((rc = copy_in(h, h->in_time, time, B, mem, st))) return rc;
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
@@ -994,7 +1001,7 @@ int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *c
     if (eta != 0.f && !noise) return fail(h, CDC_ERR_INVALID, "eta != 0 needs the noise draw");
     if ((rc = build_program(h, B, H, W))) return rc;
     if ((rc = ensure_time_rows(h, B))) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    hipStream_t st = pick_stream(h, stream, mem);
     const size_t n = (size_t)B * h->cfg.channels * H * W;
     if ((rc = copy_in(h, h->in_x, x_in, n, mem, st))) return rc;
     if (ctx && (rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
@@ -1014,7 +1021,7 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     if (!out || !ctx) return fail(h, CDC_ERR_INVALID, "null argument");
     if ((rc = build_program(h, B, H, W))) return rc;
     if ((rc = ensure_time_rows(h, B))) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    hipStream_t st = pick_stream(h, stream, mem);
     const size_t n = (size_t)B * h->cfg.channels * H * W;
     if (init) { if ((rc = copy_in(h, h->in_x, init, n, mem, st))) return rc; }
     else HIP_TRY(h, hipMemsetAsync(h->in_x, 0, n * sizeof(float), st));

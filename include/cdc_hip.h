@@ -13,9 +13,10 @@
  *   - a handle is bound to one HIP device and is NOT thread-safe (one handle per GPU per thread);
  *   - pointers tagged `mem` are host pointers (CDC_MEM_HOST: the library stages them through
  *     its own device buffers) or device pointers on the handle's device (CDC_MEM_DEVICE: used in
- *     place, zero copy); `stream` is a hipStream_t passed as void* (NULL = the library's own
- *     stream).  Calls are asynchronous on `stream` when all pointers are device pointers, and
- *     synchronous (result valid on return) when any host pointer is involved.
+ *     place, zero copy).  With device pointers the work is enqueued asynchronously on
+ *     `stream` (a hipStream_t passed as void*; NULL = the HIP null stream, i.e. torch's default
+ *     stream); with host pointers `stream` is ignored, the library uses its own stream and the
+ *     call is synchronous (result valid on return).
  */
 #ifndef CDC_HIP_H
 #define CDC_HIP_H
