@@ -291,6 +291,98 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 }
 
 // ---------------------------------------------------------------------------------------------
+// Attention output folded into per-image 1x1 weights (levels with many pixels):
+//   y = to_out(ctx^T (q*scale)) + x ,  q = Wq LN(x)      (network_components.py:128-139)
+//     = M' LN(x) + b_out + x ,  M'[c][ci] = scale * sum_d (sum_e Wo[c][e] ctx[d][e]) Wq[d][ci]
+// so neither q nor the attention output is ever materialised.  Two tiny per-image GEMMs:
+//   R1: T1[b][d][c]  = sum_e (sum_split S[b][split][d][e]) / ksum[b][d] * WoT[e][c]
+//   R2: Mt[b][ci][c] = scale * sum_d WqT[ci][d] * T1[b][d][c]     (packed 1x1 weights [Cin_pad][COP])
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ctx_r1_kernel(const float *S, const float *ksum, int C,
+                                                     int nsplit, const float *WoT, float *T1) {
+    extern __shared__ float row[];          // ctx[d][:] normalised
+    const int d = blockIdx.x, b = blockIdx.y;
+    const float z = ksum[(size_t)b * C + d];
+    for (int e = threadIdx.x; e < C; e += blockDim.x) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += S[(((size_t)b * nsplit + sp) * C + d) * C + e];
+        row[e] = s / z;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int e = 0; e < C; ++e) s += row[e] * WoT[(size_t)e * C + c];
+        T1[((size_t)b * C + d) * C + c] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const float *WqT, int C,
+                                                     float scale, float *Mt, int Cin_pad, int COP) {
+    extern __shared__ float row[];          // WqT[ci][:]
+    const int ci = blockIdx.x, b = blockIdx.y;
+    float *out = Mt + ((size_t)b * Cin_pad + ci) * COP;
+    if (ci >= C) {
+        for (int c = threadIdx.x; c < COP; c += blockDim.x) out[c] = 0.f;
+        return;
+    }
+    for (int d = threadIdx.x; d < C; d += blockDim.x) row[d] = WqT[(size_t)ci * C + d];
+    __syncthreads();
+    for (int c = threadIdx.x; c < COP; c += blockDim.x) {
+        float s = 0.f;
+        if (c < C) {
+            const float *t = T1 + (size_t)b * C * C + c;
+            for (int d = 0; d < C; ++d) s += row[d] * t[(size_t)d * C];
+            s *= scale;
+        }
+        out[c] = s;
+    }
+}
+
+hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
+                           const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
+                           int COP, int B, hipStream_t st) {
+    const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(ctx_r1_kernel, dim3(C, B), dim3(blk), sizeof(float) * C, st, S, ksum, C, nsplit,
+                       WoT, T1);
+    hipLaunchKernelGGL(ctx_r2_kernel, dim3(Cin_pad, B), dim3(blk), sizeof(float) * C, st, T1, WqT, C,
+                       scale, Mt, Cin_pad, COP);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-folded k x k convolution, second half: the MFMA kernel computed, per INPUT row r, the
+// "virtual channels" P[(co,ky)][r][x] = sum_{kx,ci} w[co][ci][ky][kx] in[ci][r][x+kx-pad]
+// (a 1 x KW convolution with Cout*KH outputs, which fills an MFMA M-block far better than Cout = 3);
+// here out[co][y][x] = bias[co] + sum_ky P[(co,ky)][y+ky-pad][x]   (unet.py:104 final 7x7 conv).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_combine_kernel(const float *P, const float *bias,
+                                                           float *out, int Cout, int KH, int pad,
+                                                           int H, int W) {
+    const int b = blockIdx.z, co = blockIdx.y;
+    const size_t HW = (size_t)H * W;
+    const float *p = P + ((size_t)b * Cout + co) * KH * HW;
+    const float bv = bias ? bias[co] : 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < HW;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / W);
+        float s = bv;
+        for (int ky = 0; ky < KH; ++ky) {
+            const int r = y + ky - pad;
+            if (r >= 0 && r < H) s += p[(size_t)ky * HW + idx + (size_t)(ky - pad) * W];
+        }
+        out[((size_t)b * Cout + co) * HW + idx] = s;
+    }
+}
+
+hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
+                               int pad, int H, int W, int B, hipStream_t st) {
+    const int gx = (int)std::min<size_t>(((size_t)H * W + 255) / 256, 1024);
+    hipLaunchKernelGGL(fold_combine_kernel, dim3(gx, Cout, B), dim3(256), 0, st, P, bias, out, Cout, KH,
+                       pad, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // DDIM update.  x-param: xparam/modules/denoising_diffusion.py:152-174 ; eps-param:
 // epsilonparam/modules/denoising_diffusion.py:137-152.  Same operation order as the reference.
 // ---------------------------------------------------------------------------------------------

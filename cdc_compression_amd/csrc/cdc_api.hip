@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -34,6 +35,7 @@ struct Param {                    // one state_dict entry
 
 struct ConvW {                    // packed convolution weights (device)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    int pad_y = -1, pad_x = -1;   // override `pad` per axis when >= 0 (row-folded convolutions)
     bool transposed = false;      // ConvTranspose2d 4x4 s2 p1 as four 2x2 phase convolutions
     int Cin_pad = 0, COP = 0, nz = 1;
     float *wp = nullptr, *bias = nullptr;
@@ -44,18 +46,25 @@ struct Act { float *p = nullptr; int C = 0, H = 0, W = 0;
              long long bs() const { return (long long)C * H * W; } };
 
 struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift_off;
-                   ConvW c1, c2, cres; float *g1, *b1, *g2, *b2, *mlp_w, *mlp_b; };
-struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb; };
+                   ConvW c1, c2, cres; float *g1, *b1, *g2, *b2, *mlp_w, *mlp_b;
+                   // context hoisting: input = cat(x [hoist_cx ch], ctx); the ctx halves of block1 and
+                   // res_conv are step-invariant, so they are split off and evaluated once per decode
+                   int hoist_cx = 0; ConvW c1x, c1c, cresx, cresc; };
+struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
+               ConvW kv; float *WoT = nullptr, *WqT = nullptr; };   // folded form (many-pixel levels)
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, DDIM, COPY } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY } kind;
     int prof = PC_SMALL;
+    int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
+    char label[96] = {0};
     double flops = 0, bytes = 0;
     ConvArgs conv; ConvPlan plan; int nz = 1;
     LnArgs ln;
     TembArgs temb;
     struct { const float *k, *v; long long bs; int C, N; float *kmax, *ksum, *S, *ctxw;
-             int nsplit, Cin_pad, COP; float scale; } at;
+             int nsplit, Cin_pad, COP; float scale; const float *WoT, *WqT; float *T1; } at;
+    struct { const float *P, *bias; float *out; int Cout, KH, pad, H, W; } cb;
     DdimArgs ddim;
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
 };
@@ -80,12 +89,15 @@ struct cdc_handle {
     std::vector<AttnW> attns;
     std::vector<ConvW> downs, ups;
     float *fin_g = nullptr, *fin_b = nullptr;
-    ConvW fin_conv;
+    ConvW fin_conv;               // row-folded: 1 x 7 taps, out_dim*7 virtual channels
+    float *fin_bias = nullptr;
+    float *fin_P = nullptr;
     TembLayer *d_temb_layers = nullptr;
     int shift_bs = 0;
     // program
     int pB = 0, pH = 0, pW = 0;
-    std::vector<Op> ops;
+    std::vector<Op> ops;          // per DDIM iteration (depends on x_t and t)
+    std::vector<Op> pre_ops;      // depends on the context pyramid only: once per decode / forward
     std::vector<void *> act_allocs;
     size_t act_bytes = 0;
     float *in_x = nullptr, *in_time = nullptr, *out_fx = nullptr, *shift = nullptr;
@@ -104,7 +116,11 @@ struct cdc_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // deferred (non-blocking) event timing: pairs recorded on the launch stream, resolved at
     // cdc_prof_get.  prof_every = n profiles only the DDIM iterations with i % n == 0.
-    struct Pending { hipEvent_t a, b; int cls; double flops, bytes; };
+    struct Pending { hipEvent_t a, b; int cls; double flops, bytes; int id; };
+    std::vector<double> op_ms;
+    std::vector<long> op_n;
+    std::vector<std::string> op_label;
+    std::vector<double> op_flops;
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_free;
     int prof_every = 1;
@@ -236,9 +252,13 @@ int upload_param(cdc_handle *h, const std::string &name, float **dst) {
     return upload(h, v.data(), v.size(), dst, &h->weight_allocs);
 }
 
-// Conv2d OIHW -> [tap][Cin_pad][COP]; ConvTranspose2d IOHW(4x4,s2,p1) -> [phase][2x2 tap][Cin_pad][COP]
-int pack_conv(cdc_handle *h, const float *w, const float *bias, int Cout, int Cin, int KH, int KW,
-              int stride, int pad, bool transposed, ConvW *cw, std::vector<void *> *pool) {
+// Conv2d OIHW -> [tap][Cin_pad][COP]; ConvTranspose2d IOHW(4x4,s2,p1) -> [phase][2x2 tap][Cin_pad][COP].
+// (ci0, ncin) / (co0, ncout) select an input / output channel slice of the full weight (hoisted
+// context halves, the k,v rows of to_qkv); ncin/ncout = 0 take everything.
+int pack_conv(cdc_handle *h, const float *w, const float *bias, int CoutF, int CinF, int KH, int KW,
+              int stride, int pad, bool transposed, ConvW *cw, std::vector<void *> *pool, int ci0 = 0,
+              int ncin = 0, int co0 = 0, int ncout = 0) {
+    const int Cin = ncin ? ncin : CinF, Cout = ncout ? ncout : CoutF;
     cw->Cin = Cin; cw->Cout = Cout; cw->stride = stride; cw->pad = pad;
     cw->transposed = transposed;
     cw->Cin_pad = round_up(Cin, 16);
@@ -252,7 +272,7 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int Cout, int Ci
             for (int ci = 0; ci < Cin; ++ci)
                 for (int t = 0; t < taps; ++t)
                     packed[((size_t)t * cw->Cin_pad + ci) * cw->COP + co] =
-                        w[((size_t)co * Cin + ci) * taps + t];
+                        w[((size_t)(co0 + co) * CinF + ci0 + ci) * taps + t];
         cw->w_zs = 0;
     } else {
         // out[2m+py][2n+px] = sum_{a,b in {0,1}} x[m+a-(1-py)][n+b-(1-px)] * w[ci][co][3-py-2a][3-px-2b]
@@ -268,33 +288,36 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int Cout, int Ci
                         for (int co = 0; co < Cout; ++co)
                             packed[(size_t)z * cw->w_zs +
                                    ((size_t)(a * 2 + b) * cw->Cin_pad + ci) * cw->COP + co] =
-                                w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+                                w[(((size_t)(ci0 + ci) * CoutF + co0 + co) * 4 + ky) * 4 + kx];
                 }
         }
     }
     int rc = upload(h, packed.data(), packed.size(), &cw->wp, pool);
     if (rc) return rc;
     cw->bias = nullptr;
-    if (bias) rc = upload(h, bias, Cout, &cw->bias, pool);
+    if (bias) rc = upload(h, bias + co0, Cout, &cw->bias, pool);
     return rc;
 }
 
 int pack_named_conv(cdc_handle *h, const std::string &wname, const std::string &bname, int stride,
-                    int pad, bool transposed, ConvW *cw) {
+                    int pad, bool transposed, ConvW *cw, int ci0 = 0, int ncin = 0, int co0 = 0,
+                    int ncout = 0) {
     const Param &p = h->params[h->pindex.at(wname)];
     const float *bias = bname.empty() ? nullptr : hostp(h, bname).data();
     const int d0 = (int)p.shape[0], d1 = (int)p.shape[1];
     const int KH = (int)p.shape[2], KW = (int)p.shape[3];
     if (!transposed)
         return pack_conv(h, p.host.data(), bias, d0, d1, KH, KW, stride, pad, false, cw,
-                         &h->weight_allocs);
+                         &h->weight_allocs, ci0, ncin, co0, ncout);
     return pack_conv(h, p.host.data(), bias, d1, d0, KH, KW, stride, pad, true, cw,
-                     &h->weight_allocs);
+                     &h->weight_allocs, ci0, ncin, co0, ncout);
 }
 
-int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k, int *shift_off) {
+int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k, int *shift_off,
+                  int hoist_cx = 0) {
     ResBlockW rb;
     rb.prefix = p; rb.cin = cin; rb.cout = cout; rb.k = k; rb.has_res = cin != cout;
+    rb.hoist_cx = hoist_cx;
     rb.shift_off = *shift_off;
     *shift_off += round_up(cout, 32);
     int rc;
@@ -305,6 +328,18 @@ int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k,
     if (rb.has_res &&
         (rc = pack_named_conv(h, p + ".res_conv.weight", p + ".res_conv.bias", 1, 0, false, &rb.cres)))
         return rc;
+    if (hoist_cx > 0) {
+        const std::string w1 = p + ".block1.block.0.weight", b1 = p + ".block1.block.0.bias";
+        if ((rc = pack_named_conv(h, w1, "", 1, k / 2, false, &rb.c1x, 0, hoist_cx))) return rc;
+        if ((rc = pack_named_conv(h, w1, b1, 1, k / 2, false, &rb.c1c, hoist_cx, cin - hoist_cx)))
+            return rc;
+        if (rb.has_res) {
+            const std::string wr = p + ".res_conv.weight", br = p + ".res_conv.bias";
+            if ((rc = pack_named_conv(h, wr, "", 1, 0, false, &rb.cresx, 0, hoist_cx))) return rc;
+            if ((rc = pack_named_conv(h, wr, br, 1, 0, false, &rb.cresc, hoist_cx, cin - hoist_cx)))
+                return rc;
+        }
+    }
     if ((rc = upload_param(h, p + ".block1.block.1.g", &rb.g1))) return rc;
     if ((rc = upload_param(h, p + ".block1.block.1.b", &rb.b1))) return rc;
     if ((rc = upload_param(h, p + ".block2.block.1.g", &rb.g2))) return rc;
@@ -324,6 +359,21 @@ int pack_attn(cdc_handle *h, const std::string &p, int c) {
                               &a.out))) return rc;
     if ((rc = upload_param(h, p + ".fn.norm.g", &a.ng))) return rc;
     if ((rc = upload_param(h, p + ".fn.norm.b", &a.nb))) return rc;
+    // folded form: k,v rows of to_qkv as their own convolution; Wo^T [e][c] and Wq^T [ci][d]
+    if ((rc = pack_named_conv(h, p + ".fn.fn.to_qkv.weight", "", 1, 0, false, &a.kv, 0, 0, c, 2 * c)))
+        return rc;
+    {
+        const auto &wo = hostp(h, p + ".fn.fn.to_out.weight");   // [c][e]
+        const auto &wq = hostp(h, p + ".fn.fn.to_qkv.weight");   // rows 0..C-1 = Wq [d][ci]
+        std::vector<float> woT((size_t)c * c), wqT((size_t)c * c);
+        for (int i = 0; i < c; ++i)
+            for (int j = 0; j < c; ++j) {
+                woT[(size_t)j * c + i] = wo[(size_t)i * c + j];
+                wqT[(size_t)j * c + i] = wq[(size_t)i * c + j];
+            }
+        if ((rc = upload(h, woT.data(), woT.size(), &a.WoT, &h->weight_allocs))) return rc;
+        if ((rc = upload(h, wqT.data(), wqT.size(), &a.WqT, &h->weight_allocs))) return rc;
+    }
     h->attns.push_back(a);
     return CDC_OK;
 }
@@ -341,6 +391,27 @@ struct Builder {
     int B;
     std::vector<void *> *pool;      // where device allocations are recorded
     int rc = CDC_OK;
+    std::vector<Op> *cur = nullptr; // op list being emitted to (h->ops unless set)
+
+    void emit(Op op) {
+        op.id = (int)h->op_ms.size();
+        h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
+        char buf[160];
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy"};
+        if (op.kind == Op::CONV)
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d%s%s%s", op.conv.KH,
+                     op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.conv.ep_g ? " LN" : "",
+                     op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
+        else if (op.kind == Op::LN)
+            snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
+        else if (op.kind == Op::KSTATS || op.kind == Op::CTXP || op.kind == Op::CTXR || op.kind == Op::CTXF)
+            snprintf(buf, sizeof buf, "%s C=%d N=%d nsplit=%d", kinds[op.kind], op.at.C, op.at.N, op.at.nsplit);
+        else
+            snprintf(buf, sizeof buf, "%s", kinds[op.kind]);
+        h->op_label.push_back(buf);
+        (cur ? cur : &h->ops)->push_back(op);
+    }
 
     float *dalloc(size_t nfloats) {
         if (rc) return nullptr;
@@ -366,24 +437,26 @@ struct Builder {
         int relu = 0;
         const float *shift = nullptr;                  // + shift[b][co]
         const float *resid = nullptr; long long resid_bs = 0, resid_cs = 0;
+        const float *pre_add = nullptr;                // hoisted partial sums (same layout as out)
         float *stat_mean = nullptr, *stat_rstd = nullptr;
         const float *pre_mean = nullptr, *pre_rstd = nullptr, *pre_g = nullptr, *pre_b = nullptr;
         long long w_bs = 0;
         bool no_bias = false;
     };
 
-    // Emits one convolution.  a1 (optional) is the second concat source.  Returns false when
+    // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
     bool conv(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1,
               long long bs1, int H, int W, float *out, long long out_bs, const ConvOpts &o,
               bool need_all, int prof) {
         if (rc) return true;
+        const int pad_y = w.pad_y >= 0 ? w.pad_y : w.pad, pad_x = w.pad_x >= 0 ? w.pad_x : w.pad;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
-            s.Ho = (H + 2 * w.pad - w.KH) / w.stride + 1;
-            s.Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
+            s.Ho = (H + 2 * pad_y - w.KH) / w.stride + 1;
+            s.Wo = (W + 2 * pad_x - w.KW) / w.stride + 1;
         }
         s.B = B; s.need_all_cout = need_all; s.lnload = o.pre_mean != nullptr;
         if (need_all && (w.Cout % 32)) return false;
@@ -394,6 +467,13 @@ struct Builder {
                       w.Cin, w.Cout, w.KH, w.KW, s.Ho, s.Wo);
             return true;
         }
+        if (getenv("CDC_DEBUG_PLAN"))
+            fprintf(stderr, "[plan] %-10s Cin=%4d Cout=%4d k=%dx%d s=%d in=%3dx%-3d out=%3dx%-3d %s%s%s| MB=%2d NPW=%d "
+                    "WN=%d groups=%2d KC=%2d nchunk=%3d tiles=%dx%d wgs=%6d lds=%6zu\n", kProfNames[prof], w.Cin,
+                    w.Cout, w.KH, w.KW, w.stride, H, W, s.Ho, s.Wo, need_all ? "LN " : "   ",
+                    s.lnload ? "pre " : "    ", cur == &h->pre_ops ? "HOIST " : "", plan.MB, plan.NPW, plan.WN,
+                    plan.groups, plan.KC, plan.nchunk, plan.tiles_x, plan.tiles_y,
+                    plan.tiles_x * plan.tiles_y * B * plan.groups * w.nz, plan.lds_bytes);
         Op op;
         op.kind = Op::CONV; op.prof = prof; op.plan = plan; op.nz = w.nz;
         ConvArgs &a = op.conv;
@@ -413,11 +493,12 @@ struct Builder {
             }
             a.out_cs = (long long)4 * H * W; a.out_ys = 4 * W; a.out_xs = 2;
         } else {
-            a.pad_y[0] = a.pad_x[0] = w.pad;
+            a.pad_y[0] = pad_y; a.pad_x[0] = pad_x;
             a.out_cs = (long long)s.Ho * s.Wo; a.out_ys = s.Wo; a.out_xs = 1;
         }
         a.Ho = s.Ho; a.Wo = s.Wo;
         a.bias = o.no_bias ? nullptr : w.bias;
+        a.pre_add = o.pre_add;
         a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu;
         a.shift = o.shift; a.shift_bs = h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
@@ -425,7 +506,7 @@ struct Builder {
         const double px = (double)B * s.Ho * s.Wo * w.nz;
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
-        h->ops.push_back(op);
+        emit(op);
         return true;
     }
 
@@ -438,59 +519,14 @@ struct Builder {
         a.in = in; a.out = out; a.C = C; a.HW = HW; a.g = g; a.b = b; a.eps = 1e-5f; a.relu = relu;
         a.shift = shift; a.shift_bs = h->shift_bs; a.resid = resid; a.stat_mean = sm; a.stat_rstd = sr;
         op.bytes = 4.0 * B * C * HW * (out ? 2 : 1);
-        h->ops.push_back(op);
+        emit(op);
     }
 
-    // ResnetBlock.forward (network_components.py:107-114)
-    Act resblock(const ResBlockW &rb, Act a0, const Act *a1, float *sm, float *sr) {
-        if (rc) return Act();
-        const int H = a0.H, W = a0.W, HW = H * W;
-        const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
-        Act cat;
-        const float *s0 = a0.p, *s1 = a1 ? a1->p : nullptr;
-        int C0 = a0.C;
-        long long bs0 = a0.bs(), bs1 = a1 ? a1->bs() : 0;
-        if (!rb.has_res && a1) {
-            // identity residual over a concatenated input (downs.1.0: 64+64 -> 128): materialise
-            cat = new_act(a0.C + a1->C, H, W);
-            Op c0; c0.kind = Op::COPY; c0.prof = PC_SMALL;
-            c0.cp = {a0.p, a0.bs(), cat.p, cat.bs(), a0.bs()};
-            c0.bytes = 8.0 * B * a0.bs();
-            h->ops.push_back(c0);
-            Op c1; c1.kind = Op::COPY; c1.prof = PC_SMALL;
-            c1.cp = {a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs()};
-            c1.bytes = 8.0 * B * a1->bs();
-            h->ops.push_back(c1);
-            s0 = cat.p; s1 = nullptr; C0 = cat.C; bs0 = cat.bs(); bs1 = 0;
-        }
-        const float *shift = h->shift + rb.shift_off;
-        Act h1 = new_act(rb.cout, H, W);
-        ConvOpts o1;
-        o1.ln_g = rb.g1; o1.ln_b = rb.b1; o1.relu = 1; o1.shift = shift;
-        if (!prefer_fused(rb.c1, H, W) ||
-            !conv(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), o1, true, prof1)) {
-            conv(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), ConvOpts(), false, prof1);
-            ln(h1.p, h1.p, rb.cout, HW, rb.g1, rb.b1, 1, shift, nullptr, nullptr, nullptr);
-        }
-        const float *res = s0;
-        long long res_bs = bs0;
-        if (rb.has_res) {
-            Act r = new_act(rb.cout, H, W);
-            conv(rb.cres, s0, C0, bs0, s1, bs1, H, W, r.p, r.bs(), ConvOpts(), false, PC_CONV1);
-            res = r.p; res_bs = r.bs();
-        }
-        Act out = new_act(rb.cout, H, W);
-        ConvOpts o2;
-        o2.ln_g = rb.g2; o2.ln_b = rb.b2; o2.relu = 1;
-        o2.resid = res; o2.resid_bs = res_bs; o2.resid_cs = HW;
-        o2.stat_mean = sm; o2.stat_rstd = sr;
-        if (!prefer_fused(rb.c2, H, W) ||
-            !conv(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), o2, true, PC_CONV3)) {
-            conv(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), ConvOpts(), false,
-                 PC_CONV3);
-            ln(out.p, out.p, rb.cout, HW, rb.g2, rb.b2, 1, nullptr, res, sm, sr);
-        }
-        return out;
+    void copy(const float *src, long long src_bs, float *dst, long long dst_bs, long long n) {
+        Op c; c.kind = Op::COPY; c.prof = PC_SMALL;
+        c.cp = {src, src_bs, dst, dst_bs, n};
+        c.bytes = 8.0 * B * n;
+        emit(c);
     }
 
     // Fused LayerNorm epilogue needs every output channel in one workgroup; at few-pixel levels that
@@ -511,14 +547,101 @@ struct Builder {
         return wu < 1.5 * wf;
     }
 
+    // conv -> channel LN -> ReLU (+shift) (+resid) (+stats), fused when possible (Block.forward,
+    // network_components.py:83-91, plus the adds of ResnetBlock.forward :107-114)
+    void block(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1,
+               int H, int W, Act out, const float *g, const float *b, const float *shift,
+               const float *pre_add, const float *resid, long long resid_bs, float *sm, float *sr,
+               int prof) {
+        ConvOpts o;
+        o.ln_g = g; o.ln_b = b; o.relu = 1; o.shift = shift; o.pre_add = pre_add;
+        o.no_bias = pre_add != nullptr;          // the hoisted partial already carries the bias
+        o.resid = resid; o.resid_bs = resid_bs; o.resid_cs = (long long)H * W;
+        o.stat_mean = sm; o.stat_rstd = sr;
+        if (prefer_fused(w, H, W) && conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), o, true, prof))
+            return;
+        ConvOpts u;
+        u.pre_add = pre_add; u.no_bias = o.no_bias;
+        conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), u, false, prof);
+        ln(out.p, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr);
+    }
+
+    // ResnetBlock.forward (network_components.py:107-114).  a1 = second concat source.  If
+    // `a1_is_context` the block was packed with split weights: the context halves are evaluated into
+    // h->pre_ops (once per decode) and enter the per-step convolutions as `pre_add`.
+    Act resblock(const ResBlockW &rb, Act a0, const Act *a1, bool a1_is_context, float *sm, float *sr) {
+        if (rc) return Act();
+        const int H = a0.H, W = a0.W, HW = H * W;
+        const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
+        const float *shift = h->shift + rb.shift_off;
+        Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W);
+        if (a1 && a1_is_context && rb.hoist_cx == a0.C) {
+            std::vector<Op> *saved = cur;
+            Act p1 = new_act(rb.cout, H, W);
+            cur = &h->pre_ops;
+            conv(rb.c1c, a1->p, a1->C, a1->bs(), nullptr, 0, H, W, p1.p, p1.bs(), ConvOpts(), false, prof1);
+            const float *res = nullptr;
+            long long res_bs = 0;
+            Act pr, cat;
+            if (rb.has_res) {
+                pr = new_act(rb.cout, H, W);
+                conv(rb.cresc, a1->p, a1->C, a1->bs(), nullptr, 0, H, W, pr.p, pr.bs(), ConvOpts(), false,
+                     PC_CONV1);
+            } else {
+                // identity residual over the concatenation (downs.1.0): context half copied once
+                cat = new_act(a0.C + a1->C, H, W);
+                copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
+            }
+            cur = saved;
+            block(rb.c1x, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
+                  nullptr, nullptr, prof1);
+            if (rb.has_res) {
+                Act r = new_act(rb.cout, H, W);
+                ConvOpts orr; orr.pre_add = pr.p; orr.no_bias = true;
+                conv(rb.cresx, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, r.p, r.bs(), orr, false, PC_CONV1);
+                res = r.p; res_bs = r.bs();
+            } else {
+                copy(a0.p, a0.bs(), cat.p, cat.bs(), a0.bs());
+                res = cat.p; res_bs = cat.bs();
+            }
+            block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
+                  res_bs, sm, sr, PC_CONV3);
+            return out;
+        }
+        const float *s0 = a0.p, *s1 = a1 ? a1->p : nullptr;
+        int C0 = a0.C;
+        long long bs0 = a0.bs(), bs1 = a1 ? a1->bs() : 0;
+        if (!rb.has_res && a1) {
+            Act cat = new_act(a0.C + a1->C, H, W);
+            copy(a0.p, a0.bs(), cat.p, cat.bs(), a0.bs());
+            copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
+            s0 = cat.p; s1 = nullptr; C0 = cat.C; bs0 = cat.bs(); bs1 = 0;
+        }
+        block(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1, rb.g1, rb.b1, shift, nullptr, nullptr, 0, nullptr,
+              nullptr, prof1);
+        const float *res = s0;
+        long long res_bs = bs0;
+        if (rb.has_res) {
+            Act r = new_act(rb.cout, H, W);
+            conv(rb.cres, s0, C0, bs0, s1, bs1, H, W, r.p, r.bs(), ConvOpts(), false, PC_CONV1);
+            res = r.p; res_bs = r.bs();
+        }
+        block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
+              res_bs, sm, sr, PC_CONV3);
+        return out;
+    }
+
     // Residual(PreNorm(LinearAttention)) (network_components.py:10-16,69-77,117-139)
     Act attention(const AttnW &at, Act x, float *sm, float *sr) {
         if (rc) return Act();
         const int C = at.C, H = x.H, W = x.W, N = H * W;
-        Act qkv = new_act(3 * C, H, W);
+        const bool fold = at.WoT && N >= 4 * C && !getenv("CDC_NO_ATTN_FOLD");
+        const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
+        Act qkv = new_act(kvc, H, W);
         ConvOpts oq;
         oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_g = at.ng; oq.pre_b = at.nb; oq.no_bias = true;
-        conv(at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
+        conv(fold ? at.kv : at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
+        const float *kp = qkv.p + (size_t)(fold ? 0 : C) * N, *vp = kp + (size_t)C * N;
         float *kmax = dalloc((size_t)B * C), *ksum = dalloc((size_t)B * C);
         const int tiles = ceil_div(C, 64);
         int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
@@ -526,25 +649,38 @@ struct Builder {
         float *S = dalloc((size_t)B * nsplit * C * C);
         const int Cin_pad = round_up(C, 16), COP = round_up(C, 32);
         float *ctxw = dalloc((size_t)B * Cin_pad * COP);
+        float *T1 = fold ? dalloc((size_t)B * C * C) : nullptr;
         if (rc) return Act();
         Op k; k.kind = Op::KSTATS; k.prof = PC_SMALL;
-        k.at = {qkv.p + (size_t)C * N, qkv.p + (size_t)2 * C * N, qkv.bs(), C, N, kmax, ksum, S, ctxw,
-                nsplit, Cin_pad, COP, 1.0f / sqrtf((float)C)};
+        k.at = {kp, vp, qkv.bs(), C, N, kmax, ksum, S, ctxw, nsplit, Cin_pad, COP,
+                1.0f / sqrtf((float)C), at.WoT, at.WqT, T1};
         k.bytes = 8.0 * B * C * N;
-        h->ops.push_back(k);
+        emit(k);
         Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
         p.flops = 2.0 * B * (double)C * C * N; p.bytes = 8.0 * B * C * N;
-        h->ops.push_back(p);
-        Op r = k; r.kind = Op::CTXR; r.prof = PC_SMALL; r.bytes = 4.0 * B * nsplit * C * C;
-        h->ops.push_back(r);
-        // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
-        ConvW cw;
+        emit(p);
+        Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
+        r.bytes = 4.0 * B * nsplit * C * C;
+        r.flops = fold ? 4.0 * B * (double)C * C * C : 0.0;
+        emit(r);
+        ConvW cw;    // per-image weights produced above
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
-        cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.bias = nullptr; cw.nz = 1;
+        cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1;
+        Act y = new_act(C, H, W);
+        if (fold) {
+            // y = M' LN(x) + b_out + x
+            cw.bias = at.out.bias;
+            ConvOpts oy = oq;
+            oy.no_bias = false; oy.w_bs = (long long)Cin_pad * COP;
+            oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
+            conv(cw, x.p, C, x.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
+            return y;
+        }
+        // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
+        cw.bias = nullptr;
         Act o = new_act(C, H, W);
         ConvOpts oo; oo.w_bs = (long long)Cin_pad * COP; oo.no_bias = true;
         conv(cw, qkv.p, C, qkv.bs(), nullptr, 0, H, W, o.p, o.bs(), oo, false, PC_CONV1);
-        Act y = new_act(C, H, W);
         ConvOpts oy; oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
         conv(at.out, o.p, C, o.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
         return y;
@@ -554,6 +690,8 @@ struct Builder {
 void free_program(cdc_handle *h) {
     free_pool(&h->act_allocs);
     h->ops.clear();
+    h->pre_ops.clear();
+    h->op_ms.clear(); h->op_n.clear(); h->op_label.clear(); h->op_flops.clear();
     h->in_ctx.clear();
     h->act_bytes = 0;
     h->pB = h->pH = h->pW = 0;
@@ -585,7 +723,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     t.temb.time = h->in_time; t.temb.w0 = h->tm_w0; t.temb.b0 = h->tm_b0; t.temb.w2 = h->tm_w2;
     t.temb.b2 = h->tm_b2; t.temb.dim = h->cfg.dim; t.temb.layers = h->d_temb_layers;
     t.temb.n_layers = (int)h->rbs.size(); t.temb.shift = h->shift; t.temb.shift_bs = h->shift_bs;
-    h->ops.push_back(t);
+    bd.emit(t);
 
     Act x; x.p = h->in_x; x.C = h->cfg.channels; x.H = H; x.W = W;
     std::vector<Act> skips;
@@ -594,8 +732,8 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
         const bool has_ctx = i < n_ctx;
-        x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, nullptr, nullptr);
-        x = bd.resblock(h->rbs[rbi++], x, nullptr, sm, sr);
+        x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, true, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         x = bd.attention(h->attns[ati++], x, sm, sr);
         skips.push_back(x);
         if (i < n - 1) {
@@ -610,33 +748,56 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     {
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
-        // forward order: mid_block1, mid_attn, mid_block2 are packed after the ups in rbs/attns?
-        // No: rbs/attns are stored in FORWARD order (see cdc_finalize_weights).
-        x = bd.resblock(h->rbs[rbi++], x, nullptr, sm, sr);
-        x = bd.attention(h->attns[ati++], x, sm, sr);
-        x = bd.resblock(h->rbs[rbi++], x, nullptr, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);          // mid_block1
+        x = bd.attention(h->attns[ati++], x, sm, sr);                       // mid_attn
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, false, nullptr, nullptr); // mid_block2
     }
+    float *fsm = nullptr, *fsr = nullptr;       // LN statistics of the last Upsample output
     for (int i = 0; i < n - 1; ++i) {
         Act skip = skips.back();
         skips.pop_back();
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
-        x = bd.resblock(h->rbs[rbi++], x, &skip, nullptr, nullptr);
-        x = bd.resblock(h->rbs[rbi++], x, nullptr, sm, sr);
+        x = bd.resblock(h->rbs[rbi++], x, &skip, false, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         x = bd.attention(h->attns[ati++], x, sm, sr);
         const ConvW &uw = h->ups[i];
         Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2);
-        bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false,
-                PC_UP);
+        Builder::ConvOpts ou;
+        bool done = false;
+        if (i == n - 2) {
+            // the final LayerNorm (unet.py:104) needs per-pixel statistics of this output: emit them
+            // from the epilogue when one workgroup owns all channels
+            fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl);
+            ou.stat_mean = fsm; ou.stat_rstd = fsr;
+            done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, true, PC_UP);
+            if (!done) { ou.stat_mean = ou.stat_rstd = nullptr; }
+        }
+        if (!done) {
+            bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, false, PC_UP);
+            if (i == n - 2) bd.ln(y.p, nullptr, y.C, y.H * y.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
+        }
         x = y;
         if (bd.rc) return bd.rc;
     }
-    // final_conv = Sequential(LayerNorm(dim), Conv2d(dim, out_dim, 7, padding=3))  (unet.py:104)
-    Act nrm = bd.new_act(x.C, x.H, x.W);
-    bd.ln(x.p, nrm.p, x.C, x.H * x.W, h->fin_g, h->fin_b, 0, nullptr, nullptr, nullptr, nullptr);
+    if (n == 1) {       // no Upsample stage: statistics of the last attention output
+        fsm = bd.dalloc((size_t)B * H * W); fsr = bd.dalloc((size_t)B * H * W);
+        bd.ln(x.p, nullptr, x.C, x.H * x.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
+    }
+    // final_conv = Sequential(LayerNorm(dim), Conv2d(dim, out_dim, 7, padding=3))  (unet.py:104):
+    // LN applied while staging; the 7x7 conv runs row-folded (1x7 taps, out_dim*7 virtual channels)
+    // followed by the 7-row combine.
+    const int KHf = 7;
+    h->fin_P = bd.dalloc((size_t)B * h->out_dim * KHf * H * W);
     h->out_fx = bd.dalloc((size_t)B * h->out_dim * H * W);
-    bd.conv(h->fin_conv, nrm.p, nrm.C, nrm.bs(), nullptr, 0, H, W, h->out_fx,
-            (long long)h->out_dim * H * W, Builder::ConvOpts(), false, PC_CONV7);
+    Builder::ConvOpts of;
+    of.pre_mean = fsm; of.pre_rstd = fsr; of.pre_g = h->fin_g; of.pre_b = h->fin_b; of.no_bias = true;
+    bd.conv(h->fin_conv, x.p, x.C, x.bs(), nullptr, 0, H, W, h->fin_P, (long long)h->out_dim * KHf * H * W,
+            of, false, PC_CONV7);
+    Op cb; cb.kind = Op::COMBINE; cb.prof = PC_SMALL;
+    cb.cb = {h->fin_P, h->fin_bias, h->out_fx, h->out_dim, KHf, 3, H, W};
+    cb.bytes = 4.0 * B * h->out_dim * (KHf + 1) * H * W;
+    bd.emit(cb);
     if (bd.rc) return bd.rc;
     h->pB = B; h->pH = H; h->pW = W;
     return CDC_OK;
@@ -658,6 +819,7 @@ int resolve_pending(cdc_handle *h) {
         h->prof_launches[p.cls] += 1;
         h->prof_flops[p.cls] += p.flops;
         h->prof_bytes[p.cls] += p.bytes;
+        if (p.id >= 0 && p.id < (int)h->op_ms.size()) { h->op_ms[p.id] += ms; h->op_n[p.id] += 1; }
         h->ev_free.push_back(p.a);
         h->ev_free.push_back(p.b);
     }
@@ -687,6 +849,14 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             HIP_TRY(h, ctx_reduce_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale,
                                          op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
             break;
+        case Op::CTXF:
+            HIP_TRY(h, ctx_fold_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale, op.at.WoT,
+                                       op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
+            break;
+        case Op::COMBINE:
+            HIP_TRY(h, fold_combine_launch(op.cb.P, op.cb.bias, op.cb.out, op.cb.Cout, op.cb.KH, op.cb.pad,
+                                           op.cb.H, op.cb.W, B, st));
+            break;
         case Op::DDIM: HIP_TRY(h, ddim_launch(op.ddim, st)); break;
         case Op::COPY:
             HIP_TRY(h, copy_channels_launch(op.cp.src, op.cp.src_bs, op.cp.dst, op.cp.dst_bs, op.cp.n,
@@ -695,7 +865,16 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
     }
     if (prof) {
         HIP_TRY(h, hipEventRecord(eb, st));
-        h->pending.push_back({ea, eb, op.prof, op.flops, op.bytes});
+        h->pending.push_back({ea, eb, op.prof, op.flops, op.bytes, op.id});
+    }
+    return CDC_OK;
+}
+
+// Context-only part of the program (hoisted context halves): once per decode / forward.
+int run_pre(cdc_handle *h, hipStream_t st) {
+    for (const Op &op : h->pre_ops) {
+        int rc = run_op(h, op, h->pB, st);
+        if (rc) return rc;
     }
     return CDC_OK;
 }
@@ -880,7 +1059,9 @@ int cdc_finalize_weights(cdc_handle *h) {
     for (int i = 0; i < n; ++i) {
         const std::string p = "downs." + std::to_string(i);
         const int dout = h->dims[i + 1];
-        if ((rc = pack_resblock(h, p + ".0", down_in_channels(h, i), dout, i == 0 ? 7 : 3, &shift_off)))
+        const int cin0 = down_in_channels(h, i);
+        const int hoist_cx = (cin0 != h->dims[i] && !getenv("CDC_NO_HOIST")) ? h->dims[i] : 0;
+        if ((rc = pack_resblock(h, p + ".0", cin0, dout, i == 0 ? 7 : 3, &shift_off, hoist_cx)))
             return rc;
         if ((rc = pack_resblock(h, p + ".1", dout, dout, 3, &shift_off))) return rc;
         if ((rc = pack_attn(h, p + ".2", dout))) return rc;
@@ -909,8 +1090,22 @@ int cdc_finalize_weights(cdc_handle *h) {
     }
     if ((rc = upload_param(h, "final_conv.0.g", &h->fin_g))) return rc;
     if ((rc = upload_param(h, "final_conv.0.b", &h->fin_b))) return rc;
-    if ((rc = pack_named_conv(h, "final_conv.1.weight", "final_conv.1.bias", 1, 3, false, &h->fin_conv)))
-        return rc;
+    {
+        // row-folded final convolution: w'[(co*7+ky)][ci][0][kx] = w[co][ci][ky][kx]
+        const Param &pw = h->params[h->pindex.at("final_conv.1.weight")];
+        const int co_n = (int)pw.shape[0], ci_n = (int)pw.shape[1], kh = (int)pw.shape[2], kw = (int)pw.shape[3];
+        std::vector<float> wf((size_t)co_n * kh * ci_n * kw);
+        for (int co = 0; co < co_n; ++co)
+            for (int ci = 0; ci < ci_n; ++ci)
+                for (int ky = 0; ky < kh; ++ky)
+                    for (int kx = 0; kx < kw; ++kx)
+                        wf[(((size_t)(co * kh + ky)) * ci_n + ci) * kw + kx] =
+                            pw.host[(((size_t)co * ci_n + ci) * kh + ky) * kw + kx];
+        if ((rc = pack_conv(h, wf.data(), nullptr, co_n * kh, ci_n, 1, kw, 1, 0, false, &h->fin_conv,
+                            &h->weight_allocs))) return rc;
+        h->fin_conv.pad_y = 0; h->fin_conv.pad_x = kw / 2;
+        if ((rc = upload_param(h, "final_conv.1.bias", &h->fin_bias))) return rc;
+    }
     h->shift_bs = shift_off;
     std::vector<TembLayer> tl;
     for (const ResBlockW &rb : h->rbs) tl.push_back({rb.mlp_w, rb.mlp_b, rb.cout, rb.shift_off});
@@ -934,6 +1129,7 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
     if ((rc = copy_in(h, h->in_time, time, B, mem, st))) return rc;
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
     h->prof_now = true;
+    if ((rc = run_pre(h, st))) return rc;
     if ((rc = run_unet(h, st, nullptr))) return rc;
     return copy_out(h, out, h->out_fx, (size_t)B * h->out_dim * H * W, mem, st);
 }
@@ -1004,7 +1200,11 @@ int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *c
     hipStream_t st = pick_stream(h, stream, mem);
     const size_t n = (size_t)B * h->cfg.channels * H * W;
     if ((rc = copy_in(h, h->in_x, x_in, n, mem, st))) return rc;
-    if (ctx && (rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    if (ctx) {
+        if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+        h->prof_now = true;
+        if ((rc = run_pre(h, st))) return rc;
+    }
     if (eta != 0.f && (rc = copy_in(h, h->noise_buf, noise, n, mem, st))) return rc;
     if ((rc = ddim_on_device(h, h->in_x, i, h->noise_buf, eta, h->xa, B, H, W, pred_mode, clip, st)))
         return rc;
@@ -1026,6 +1226,8 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     if (init) { if ((rc = copy_in(h, h->in_x, init, n, mem, st))) return rc; }
     else HIP_TRY(h, hipMemsetAsync(h->in_x, 0, n * sizeof(float), st));
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    h->prof_now = false;
+    if ((rc = run_pre(h, st))) return rc;       // hoisted context halves: once per decode
     // for i in reversed(range(steps)): img = ddim(img, i)      (x: :188-200 ; eps: :174-190)
     for (int i = h->steps - 1; i >= 0; --i) {
         h->prof_now = (i % h->prof_every) == 0;
@@ -1049,6 +1251,13 @@ int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *
     if (!h || cls < 0 || cls >= PC_COUNT) return CDC_ERR_INVALID;
     int rc = resolve_pending(h);
     if (rc) return rc;
+    if (cls == 0 && getenv("CDC_PROF_OPS")) {        // per-op table of the instrumented iterations
+        for (size_t i = 0; i < h->op_ms.size(); ++i)
+            if (h->op_n[i])
+                fprintf(stderr, "[op %3zu] %8.3f ms  %7.1f TF  x%ld  %s\n", i, h->op_ms[i] / h->op_n[i],
+                        h->op_flops[i] / (h->op_ms[i] / h->op_n[i] * 1e-3) / 1e12, h->op_n[i],
+                        h->op_label[i].c_str());
+    }
     if (ms) *ms = h->prof_ms[cls];
     if (launches) *launches = h->prof_launches[cls];
     if (flops) *flops = h->prof_flops[cls];
@@ -1058,6 +1267,8 @@ int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *
 int cdc_prof_reset(cdc_handle *h) {
     if (!h) return CDC_ERR_INVALID;
     (void)resolve_pending(h);
+    std::fill(h->op_ms.begin(), h->op_ms.end(), 0.0);
+    std::fill(h->op_n.begin(), h->op_n.end(), 0L);
     for (int i = 0; i < PC_COUNT; ++i) {
         h->prof_ms[i] = h->prof_flops[i] = h->prof_bytes[i] = 0;
         h->prof_launches[i] = 0;
@@ -1073,13 +1284,17 @@ namespace {
 struct OpScope {                 // temporary device pool + op list for the cdc_op_* entry points
     cdc_handle *h;
     std::vector<void *> pool;
-    std::vector<Op> saved_ops;
+    std::vector<Op> saved_ops, saved_pre;
     int saved_shift_bs;
-    explicit OpScope(cdc_handle *hh) : h(hh), saved_shift_bs(hh->shift_bs) { saved_ops.swap(h->ops); }
+    explicit OpScope(cdc_handle *hh) : h(hh), saved_shift_bs(hh->shift_bs) {
+        saved_ops.swap(h->ops);
+        saved_pre.swap(h->pre_ops);
+    }
     ~OpScope() {
         (void)hipDeviceSynchronize();
         free_pool(&pool);
         h->ops.swap(saved_ops);
+        h->pre_ops.swap(saved_pre);
         h->shift_bs = saved_shift_bs;
     }
     int up(const float *src, size_t n, float **dst) { return upload(h, src, n, dst, &pool); }
@@ -1192,6 +1407,18 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
     if ((rc = pack_conv(h, w_out, b_out, C, C, 1, 1, 1, 0, false, &at.out, &sc.pool))) return rc;
     if ((rc = sc.up(norm_g, C, &at.ng))) return rc;
     if ((rc = sc.up(norm_b, C, &at.nb))) return rc;
+    if ((rc = pack_conv(h, w_qkv, nullptr, 3 * C, C, 1, 1, 1, 0, false, &at.kv, &sc.pool, 0, 0, C, 2 * C)))
+        return rc;
+    {
+        std::vector<float> woT((size_t)C * C), wqT((size_t)C * C);
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < C; ++j) {
+                woT[(size_t)j * C + i] = w_out[(size_t)i * C + j];
+                wqT[(size_t)j * C + i] = w_qkv[(size_t)i * C + j];
+            }
+        if ((rc = sc.up(woT.data(), woT.size(), &at.WoT))) return rc;
+        if ((rc = sc.up(wqT.data(), wqT.size(), &at.WqT))) return rc;
+    }
     Act ax;
     ax.C = C; ax.H = H; ax.W = W;
     if ((rc = sc.up(x, (size_t)B * C * H * W, &ax.p))) return rc;

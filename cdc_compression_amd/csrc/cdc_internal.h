@@ -74,6 +74,12 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
 hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                              float *ctxw, int Cin_pad, int COP, int B, hipStream_t st);
 
+hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
+                           const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
+                           int COP, int B, hipStream_t st);
+hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
+                               int pad, int H, int W, int B, hipStream_t st);
+
 struct DdimArgs {
     const float *fx, *x, *noise;
     float *x_next;

@@ -15,8 +15,7 @@
 namespace cdc {
 
 constexpr int kWaveSize = 64;
-constexpr int kXE = 24;   // per-thread prefetch registers for the input patch (floats)
-constexpr int kWE = 16;   // per-thread prefetch registers for the weight chunk (float4)
+constexpr int kXS = 20;   // max LDS-DMA slots per thread for the input patch (4 B each)
 
 struct ConvArgs {
     // input: channel-concatenation of up to two NCHW sources (torch.cat sites unet.py:109,124)
@@ -41,10 +40,11 @@ struct ConvArgs {
     // tiling
     int lognbw;                     // a 32-pixel N-block is (32>>lognbw) rows x (1<<lognbw) cols
     int tiles_x, tiles_y;
-    int PH, PW, PWp;                // staged input patch: rows, cols, padded row stride
+    int PH, PW;                     // staged input patch: rows, cols
     unsigned magic_hw, magic_w;     // fast division by PH*PW and by PW (0 => divisor is 1)
     // epilogue
     const float *bias;              // [Cout] or null
+    const float *pre_add;           // hoisted partial sums, added before LN (addressing = out)
     const float *ep_g, *ep_b;       // channel LayerNorm after bias (needs gridDim.y == 1)
     float eps;
     int relu;
@@ -61,7 +61,7 @@ struct ConvPlan {
     int MB, NPW, WN;        // cout blocks per wave, pixel blocks per wave, waves per workgroup
     int groups;             // cout groups (gridDim.y)
     int KC, nchunk;
-    int lognbw, tiles_x, tiles_y, PH, PW, PWp;
+    int lognbw, tiles_x, tiles_y, PH, PW;
     size_t lds_bytes;
     bool lnload;
 };

@@ -13,10 +13,23 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) {
     return magic ? __umulhi(n, magic) : n;
 }
 
+__device__ __attribute__((aligned(16))) float g_zeros[64];   // DMA source of zero padding
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+constexpr int conv_min_waves(int MB, int NPW) { return MB * NPW <= 8 ? 2 : 1; }
+
 // Workgroup = WN waves (blockDim.x = 64*WN).  Wave w owns NPW N-blocks (32 pixels each) stacked
 // vertically and all MB*32 output channels of the workgroup's cout group.
+//
+// Staging: both operands go global -> LDS by LDS-DMA (global_load_lds, no staging registers): the
+// weight slab [taps][KC][MB*32] in 16-byte pieces, the haloed input patch [KC][PH][PW] in 4-byte
+// pieces whose per-lane source address is either the tensor element or a zero word (padding,
+// channel tail).  Two LDS buffer sets; chunk c+1 streams in while chunk c feeds the MFMAs; one
+// barrier per chunk (hipcc drains vmcnt(0) in front of it).
 template <int MB, int NPW, bool LNLOAD>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
+__global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel(const ConvArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COPT = MB * 32;
     const int tid = threadIdx.x;
@@ -39,37 +52,37 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
     const int oy0 = ty * TH, ox0 = tx * NBW;
     const int iy0 = oy0 * P.stride - P.pad_y[z];
     const int ix0 = ox0 * P.stride - P.pad_x[z];
-    const int PH = P.PH, PW = P.PW, PWp = P.PWp;
+    const int PH = P.PH, PW = P.PW;
     const int taps = P.KH * P.KW;
     const int KC = P.KC;
-    const int plane = PH * PWp;
+    const int plane = PH * PW;
 
-    float *w_lds = smem;
-    float *x_lds = smem + taps * KC * COPT;
+    const int n_x = KC * plane;                       // staged input elements per chunk
+    const int n_w4 = taps * KC * (COPT / 4);          // staged weight float4 per chunk
+    const int xs = (n_x + nthr - 1) / nthr;           // DMA slots per thread
+    const int ws = (n_w4 + nthr - 1) / nthr;
+    const int w_floats = ws * nthr * 4;
+    const int buf_floats = w_floats + xs * nthr;
 
-    // ---- chunk-invariant descriptors of this thread's input-patch elements --------------------
-    const int n_x = KC * PH * PW;
-    int xd[kXE];    // lds index | c_local << 20   (-1: slot unused)
-    int xg[kXE];    // iy*W+ix inside the plane    (-1: zero padding)
-    float xmean[LNLOAD ? kXE : 1], xrstd[LNLOAD ? kXE : 1];
+    // ---- chunk-invariant descriptors of this thread's input-patch slots --------------------------
+    int xo[kXS];       // (c_local << 24) | (iy*W+ix) ; -1: zero (padding / beyond the patch)
+    float xmean[LNLOAD ? kXS : 1], xrstd[LNLOAD ? kXS : 1];
 #pragma unroll
-    for (int i = 0; i < kXE; ++i) {
+    for (int i = 0; i < kXS; ++i) {
         const unsigned e = tid + i * nthr;
-        xd[i] = -1;
-        xg[i] = -1;
+        xo[i] = -1;
         if constexpr (LNLOAD) { xmean[i] = 0.f; xrstd[i] = 0.f; }
-        if (e < (unsigned)n_x) {
+        if (i < xs && e < (unsigned)n_x) {
             const unsigned c = fdiv(e, P.magic_hw);
-            const unsigned rem = e - c * (unsigned)(PH * PW);
+            const unsigned rem = e - c * (unsigned)plane;
             const unsigned r = fdiv(rem, P.magic_w);
             const unsigned col = rem - r * (unsigned)PW;
-            xd[i] = (int)((c * PH + r) * PWp + col) | (int)(c << 20);
             const int iy = iy0 + (int)r, ix = ix0 + (int)col;
             if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {
-                xg[i] = iy * P.W + ix;
+                xo[i] = (int)(c << 24) | (iy * P.W + ix);
                 if constexpr (LNLOAD) {
-                    xmean[i] = P.ln_mean[(size_t)b * P.H * P.W + xg[i]];
-                    xrstd[i] = P.ln_rstd[(size_t)b * P.H * P.W + xg[i]];
+                    xmean[i] = P.ln_mean[(size_t)b * P.H * P.W + iy * P.W + ix];
+                    xrstd[i] = P.ln_rstd[(size_t)b * P.H * P.W + iy * P.W + ix];
                 }
             }
         }
@@ -78,57 +91,37 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
     const float *s0 = P.src0 + (size_t)b * P.src0_bs;
     const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
     const float *wsrc = P.wp + (size_t)b * P.w_bs + (size_t)z * P.w_zs + (size_t)cog * COPT;
-    const int n_w4 = taps * KC * (COPT / 4);
 
-    float xr[kXE];
-    float4 wr[kWE];
-
-    auto prefetch = [&](int chunk) {
+    auto issue = [&](int chunk, float *buf) {
         const int cbase = chunk * KC;
-#pragma unroll
-        for (int i = 0; i < kXE; ++i) {
-            float v = 0.f;
-            if (xg[i] >= 0) {
-                const int c = cbase + (xd[i] >> 20);
-                if (c < P.C0) v = s0[(size_t)c * HW + xg[i]];
-                else if (c < P.Cin) v = s1[(size_t)(c - P.C0) * HW + xg[i]];
-            }
-            xr[i] = v;
-        }
-        const float *wc = wsrc + (size_t)chunk * KC * P.COP;
-#pragma unroll
-        for (int i = 0; i < kWE; ++i) {
+        // weights: slot i covers float4 index e4 = tid + i*nthr of the slab [taps*KC][COPT/4]
+        const float *wc = wsrc + (size_t)cbase * P.COP;
+        for (int i = 0; i < ws; ++i) {
             const int e4 = tid + i * nthr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *src = g_zeros;
             if (e4 < n_w4) {
-                const int row = e4 / (COPT / 4);       // (tap, kc) row of the chunk
+                const int row = e4 / (COPT / 4);
                 const int c4 = e4 - row * (COPT / 4);
                 const int tap = row >> P.logKC, kcl = row & (KC - 1);
-                v = *reinterpret_cast<const float4 *>(
-                    wc + ((size_t)tap * P.Cin_pad + kcl) * P.COP + c4 * 4);
+                src = wc + ((size_t)tap * P.Cin_pad + kcl) * P.COP + c4 * 4;
             }
-            wr[i] = v;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + (i * nthr + wave * 64) * 4),
+                                             16, 0, 0);
         }
-    };
-
-    auto commit = [&](int chunk) {
-        const int cbase = chunk * KC;
+        float *xb = buf + w_floats;
 #pragma unroll
-        for (int i = 0; i < kXE; ++i) {
-            if (xd[i] >= 0) {
-                float v = xr[i];
-                if constexpr (LNLOAD) {
-                    const int c = cbase + (xd[i] >> 20);
-                    if (xg[i] >= 0 && c < P.Cin)
-                        v = (v - xmean[i]) * xrstd[i] * P.ln_g[c] + P.ln_b[c];
+        for (int i = 0; i < kXS; ++i) {
+            if (i < xs) {
+                const float *src = g_zeros;
+                if (xo[i] >= 0) {
+                    const int c = cbase + (xo[i] >> 24);
+                    const int sp = xo[i] & 0xFFFFFF;
+                    if (c < P.C0) src = s0 + (size_t)c * HW + sp;
+                    else if (c < P.Cin) src = s1 + (size_t)(c - P.C0) * HW + sp;
                 }
-                x_lds[xd[i] & 0xFFFFF] = v;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xb + i * nthr + wave * 64), 4, 0,
+                                                 0);
             }
-        }
-#pragma unroll
-        for (int i = 0; i < kWE; ++i) {
-            const int e4 = tid + i * nthr;
-            if (e4 < n_w4) *reinterpret_cast<float4 *>(w_lds + e4 * 4) = wr[i];
         }
     };
 
@@ -144,19 +137,35 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
     const int j = lane & 31;
     const int pr = j >> P.lognbw, pc = j & (NBW - 1);
     const int a_lane = half * COPT + j;
-    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PWp + pc * P.stride;
-    const int nb_stride = NBH * P.stride * PWp;
+    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride;
+    const int nb_stride = NBH * P.stride * PW;
 
-    prefetch(0);
+    issue(0, smem);
     for (int chunk = 0; chunk < P.nchunk; ++chunk) {
-        __syncthreads();
-        commit(chunk);
-        __syncthreads();
-        if (chunk + 1 < P.nchunk) prefetch(chunk + 1);
+        float *buf = smem + (chunk & 1) * buf_floats;
+        __syncthreads();          // chunk's DMA landed (vmcnt(0) precedes the barrier); other buffer free
+        if (chunk + 1 < P.nchunk) issue(chunk + 1, smem + ((chunk + 1) & 1) * buf_floats);
+        float *w_lds = buf;
+        float *x_lds = buf + w_floats;
+        if constexpr (LNLOAD) {
+            // PreNorm LayerNorm applied in place on the landed patch (network_components.py:69-77)
+            const int cbase = chunk * KC;
+#pragma unroll
+            for (int i = 0; i < kXS; ++i) {
+                if (i < xs && xo[i] >= 0) {
+                    const int c = cbase + (xo[i] >> 24);
+                    if (c < P.Cin) {
+                        const int e = tid + i * nthr;
+                        x_lds[e] = (x_lds[e] - xmean[i]) * xrstd[i] * P.ln_g[c] + P.ln_b[c];
+                    }
+                }
+            }
+            __syncthreads();
+        }
         for (int ky = 0; ky < P.KH; ++ky) {
             for (int kx = 0; kx < P.KW; ++kx) {
                 const float *wl = w_lds + (ky * P.KW + kx) * KC * COPT + a_lane;
-                const float *xl = x_lds + b_lane + ky * PWp + kx;
+                const float *xl = x_lds + b_lane + ky * PW + kx;
                 for (int kc = 0; kc < KC; kc += 4) {
 #pragma unroll
                     for (int k2 = 0; k2 < 4; k2 += 2) {
@@ -207,6 +216,28 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[m][n][r] += epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+        const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
+        if (P.pre_add) {
+            // hoisted partial sums (context half of a concatenated input), same addressing as out
+            const float *pp = P.pre_add + (size_t)b * P.out_bs + pix +
+                              (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m * 32 + 32 <= nvalid) {
+                    if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[m][n][r] += pp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs];
+                    }
+                } else if (m * 32 < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (valid && ci + 4 * half < nvalid) acc[m][n][r] += pp[(size_t)ci * P.out_cs];
+                    }
+                }
+            }
+        }
         if (P.ep_g) {
             float s = 0.f;
 #pragma unroll
@@ -246,7 +277,6 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
                 for (int r = 0; r < 16; ++r)
                     acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
         }
-        const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
         if (P.resid) {
             const float *rp = P.resid + (size_t)b * P.resid_bs + pix +
                               (size_t)(cobase + 4 * half) * P.resid_cs;
@@ -284,10 +314,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs P) {
                     q += d * d;
                 }
             q += __shfl_xor(q, 32);
-            if (valid && half == 0) {
-                P.stat_mean[(size_t)b * P.Ho * P.Wo + oy * P.Wo + ox] = mean;
-                P.stat_rstd[(size_t)b * P.Ho * P.Wo + oy * P.Wo + ox] =
-                    1.0f / sqrtf(q * inv_c + P.eps);
+            if (valid && half == 0) {     // one plane of the output tensor (phase-aware addressing)
+                P.stat_mean[(size_t)b * P.out_cs + pix] = mean;
+                P.stat_rstd[(size_t)b * P.out_cs + pix] = 1.0f / sqrtf(q * inv_c + P.eps);
             }
         }
         float *op = P.out + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;

@@ -18,7 +18,15 @@ static conv_kernel_fn lookup(int MB, int NPW, bool lnload) {
 
 // LDS budget per workgroup.  The register-staged pipeline keeps ONE buffer set in LDS (the next
 // chunk sits in registers), so up to two workgroups fit a CU's 160 KiB.
-static constexpr size_t kLdsBudget = 72 * 1024;
+// LDS budget per workgroup: two buffer sets (double-buffered LDS-DMA).  <= 78 KiB lets two
+// workgroups share a CU's 160 KiB when the register budget allows it.
+static constexpr size_t kLdsSmall = 78 * 1024, kLdsBig = 150 * 1024;
+
+static size_t plan_lds(int taps, int kc, int COPT, int PH, int PW, int nthr) {
+    const int n_x = kc * PH * PW, n_w4 = taps * kc * (COPT / 4);
+    const size_t buf = (size_t)ceil_div(n_w4, nthr) * nthr * 4 + (size_t)ceil_div(n_x, nthr) * nthr;
+    return std::max(sizeof(float) * 2 * buf, sizeof(float) * 4 * (size_t)COPT);
+}
 
 static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p) {
     const int nblocks = ceil_div(s.Cout, 32);
@@ -32,16 +40,19 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     const int TH = WN * NPW * NBH;
     const int PH = (TH - 1) * s.stride + s.KH;
     const int PW = (NBW - 1) * s.stride + s.KW;
-    const int PWp = PW | 1;
     const int taps = s.KH * s.KW;
     const int COPT = MB * 32;
+    // prefer a footprint that lets two workgroups share a CU (when registers allow it), then the
+    // largest K-chunk; fall back to one workgroup per CU
     int KC = 0;
-    for (int kc : {16, 8, 4}) {
-        if (kc > round_up(s.Cin, 4) && kc > 4) continue;      // do not over-pad tiny Cin
-        const bool x_ok = kc * PH * PW <= kXE * nthr;
-        const bool w_ok = taps * kc * (COPT / 4) <= kWE * nthr;
-        const size_t lds = sizeof(float) * ((size_t)taps * kc * COPT + (size_t)kc * PH * PWp);
-        if (x_ok && w_ok && lds <= kLdsBudget) { KC = kc; break; }
+    const bool two_wg = MB * NPW <= 8;
+    for (size_t budget : {two_wg ? kLdsSmall : kLdsBig, kLdsBig}) {
+        for (int kc : {16, 8, 4}) {
+            if (kc > round_up(s.Cin, 4) && kc > 4) continue;      // do not over-pad tiny Cin
+            const bool x_ok = kc * PH * PW <= kXS * nthr;
+            if (x_ok && plan_lds(taps, kc, COPT, PH, PW, nthr) <= budget) { KC = kc; break; }
+        }
+        if (KC) break;
     }
     if (!KC) return false;
     p->MB = MB; p->NPW = NPW; p->WN = WN;
@@ -51,9 +62,8 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     p->lognbw = lognbw;
     p->tiles_x = ceil_div(s.Wo, NBW);
     p->tiles_y = ceil_div(s.Ho, TH);
-    p->PH = PH; p->PW = PW; p->PWp = PWp;
-    p->lds_bytes = std::max(sizeof(float) * ((size_t)taps * KC * COPT + (size_t)KC * PH * PWp),
-                            sizeof(float) * 4 * COPT);
+    p->PH = PH; p->PW = PW;
+    p->lds_bytes = plan_lds(taps, KC, COPT, PH, PW, nthr);
     p->lnload = s.lnload;
     return true;
 }
@@ -102,7 +112,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.lognbw = p.lognbw;
     a.tiles_x = p.tiles_x;
     a.tiles_y = p.tiles_y;
-    a.PH = p.PH; a.PW = p.PW; a.PWp = p.PWp;
+    a.PH = p.PH; a.PW = p.PW;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW));
     a.magic_w = magic_of((unsigned)p.PW);
     conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnload);
