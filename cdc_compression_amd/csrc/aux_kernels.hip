@@ -71,7 +71,106 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs a) {
     }
 }
 
+// Same operation, 8 channel slices x 32 pixels per workgroup with the pixel's channels cached in
+// registers (C <= 8*kLnCache): the few-pixel levels (8x8, 16x16) otherwise leave the chip idle while
+// single threads walk 384 channels three times.
+constexpr int kLnCache = 48;
+
+__global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
+    __shared__ float red[8][33];
+    const int b = blockIdx.y;
+    const int pl = threadIdx.x & 31, cs = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + pl;
+    const bool pv = p < a.HW;
+    const size_t base = (size_t)b * a.C * a.HW + (pv ? p : 0);
+    const float *x = a.in + base;
+    float v[kLnCache];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnCache; ++i) {
+        const int c = cs + 8 * i;
+        v[i] = (pv && c < a.C) ? x[(size_t)c * a.HW] : 0.f;
+        s += v[i];
+    }
+    red[cs][pl] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][pl];
+    const float mean = tot / (float)a.C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnCache; ++i) {
+        const float d = v[i] - mean;
+        q += (cs + 8 * i < a.C) ? d * d : 0.f;
+    }
+    red[cs][pl] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][pl];
+    const float var = tot / (float)a.C;
+    if (!a.out) {
+        if (pv && cs == 0) {
+            a.stat_mean[(size_t)b * a.HW + p] = mean;
+            a.stat_rstd[(size_t)b * a.HW + p] = 1.0f / sqrtf(var + a.eps);
+        }
+        return;
+    }
+    const float den = sqrtf(var + a.eps);
+    float *y = a.out + base;
+    const float *r = a.resid ? a.resid + base : nullptr;
+    const float *sh = a.shift ? a.shift + (size_t)b * a.shift_bs : nullptr;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnCache; ++i) {
+        const int c = cs + 8 * i;
+        if (c < a.C) {
+            float w = (v[i] - mean) / den * a.g[c] + a.b[c];
+            if (a.relu) w = fmaxf(w, 0.f);
+            if (sh) w += sh[c];
+            if (r && pv) w += r[(size_t)c * a.HW];
+            if (pv) y[(size_t)c * a.HW] = w;
+            v[i] = w;
+            s2 += w;
+        } else {
+            v[i] = 0.f;
+        }
+    }
+    if (a.stat_mean) {
+        __syncthreads();
+        red[cs][pl] = s2;
+        __syncthreads();
+        tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][pl];
+        const float m2 = tot / (float)a.C;
+        __syncthreads();
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnCache; ++i) {
+            const float d = v[i] - m2;
+            q2 += (cs + 8 * i < a.C) ? d * d : 0.f;
+        }
+        red[cs][pl] = q2;
+        __syncthreads();
+        tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][pl];
+        if (pv && cs == 0) {
+            a.stat_mean[(size_t)b * a.HW + p] = m2;
+            a.stat_rstd[(size_t)b * a.HW + p] = 1.0f / sqrtf(tot / (float)a.C + a.eps);
+        }
+    }
+}
+
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
+    if (a.C <= 8 * kLnCache) {
+        hipLaunchKernelGGL(ln_kernel_sliced, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
+                           st, a);
+        return hipGetLastError();
+    }
     const int block = a.HW >= 256 ? 256 : 64;
     dim3 grid((unsigned)ceil_div(a.HW, block), (unsigned)B);
     hipLaunchKernelGGL(ln_kernel, grid, dim3(block), 0, st, a);
@@ -338,14 +437,35 @@ __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const floa
     }
 }
 
+// R3: fold the PreNorm affine into the per-image weights (LNMODE 2 of the conv kernel):
+//   biasB[b][c] = b_out[c] + sum_ci Mt[b][ci][c] * ln_b[ci] ;  Mt[b][ci][c] *= ln_g[ci]
+__global__ void __launch_bounds__(256) ctx_r3_kernel(float *Mt, const float *ln_g, const float *ln_b,
+                                                     const float *b_out, float *biasB, int C,
+                                                     int Cin_pad, int COP) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float *col = Mt + (size_t)b * Cin_pad * COP + c;
+        float acc = 0.f;
+        for (int ci = 0; ci < C; ++ci) {
+            const float v = col[(size_t)ci * COP];
+            acc += v * ln_b[ci];
+            col[(size_t)ci * COP] = v * ln_g[ci];
+        }
+        biasB[(size_t)b * C + c] = b_out[c] + acc;
+    }
+}
+
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
-                           int COP, int B, hipStream_t st) {
+                           int COP, const float *ln_g, const float *ln_b, const float *b_out,
+                           float *biasB, int B, hipStream_t st) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(C, B), dim3(blk), sizeof(float) * C, st, S, ksum, C, nsplit,
                        WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(Cin_pad, B), dim3(blk), sizeof(float) * C, st, T1, WqT, C,
                        scale, Mt, Cin_pad, COP);
+    hipLaunchKernelGGL(ctx_r3_kernel, dim3(B), dim3(blk), 0, st, Mt, ln_g, ln_b, b_out, biasB, C, Cin_pad,
+                       COP);
     return hipGetLastError();
 }
 

@@ -51,7 +51,8 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
                    // res_conv are step-invariant, so they are split off and evaluated once per decode
                    int hoist_cx = 0; ConvW c1x, c1c, cresx, cresc; };
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
-               ConvW kv; float *WoT = nullptr, *WqT = nullptr; };   // folded form (many-pixel levels)
+               // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
+               ConvW kv; float *WoT = nullptr, *WqT = nullptr; };   // folded output (many-pixel levels)
 
 struct Op {
     enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY } kind;
@@ -63,7 +64,8 @@ struct Op {
     LnArgs ln;
     TembArgs temb;
     struct { const float *k, *v; long long bs; int C, N; float *kmax, *ksum, *S, *ctxw;
-             int nsplit, Cin_pad, COP; float scale; const float *WoT, *WqT; float *T1; } at;
+             int nsplit, Cin_pad, COP; float scale; const float *WoT, *WqT; float *T1;
+             const float *ln_g, *ln_b, *b_out; float *biasB; } at;
     struct { const float *P, *bias; float *out; int Cout, KH, pad, H, W; } cb;
     DdimArgs ddim;
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
@@ -107,7 +109,8 @@ struct cdc_handle {
     int steps = 0;
     float *d_tab = nullptr;              // [5][steps]
     std::vector<float> h_time_in;
-    float *d_time_steps = nullptr;       // [steps][B] time value replicated per image
+    float *d_time_steps = nullptr;       // [steps] U-Net time input per sample step
+    float *d_shift_tab = nullptr;        // [steps][shift_bs]: time-embedding shifts of every step
     int time_steps_B = 0;
     // profiling
     bool prof = false;
@@ -350,18 +353,41 @@ int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k,
     return CDC_OK;
 }
 
+// to_qkv rows [co0, co0+nco) with the PreNorm affine folded in: W' = W diag(g), bias' = W b
+// (LNMODE 2 of the conv kernel).
+int pack_qkv_folded(cdc_handle *h, const float *wq, const float *g, const float *bln, int C, int co0,
+                    int nco, ConvW *cw, std::vector<void *> *pool) {
+    std::vector<float> w((size_t)nco * C), bias(nco);
+    for (int co = 0; co < nco; ++co) {
+        double acc = 0;
+        for (int ci = 0; ci < C; ++ci) {
+            const float v = wq[(size_t)(co0 + co) * C + ci];
+            w[(size_t)co * C + ci] = v * g[ci];
+            acc += (double)v * bln[ci];
+        }
+        bias[co] = (float)acc;
+    }
+    return pack_conv(h, w.data(), bias.data(), nco, C, 1, 1, 1, 0, false, cw, pool);
+}
+
 int pack_attn(cdc_handle *h, const std::string &p, int c) {
     AttnW a;
     a.prefix = p; a.C = c;
     int rc;
-    if ((rc = pack_named_conv(h, p + ".fn.fn.to_qkv.weight", "", 1, 0, false, &a.qkv))) return rc;
+    {
+        const auto &wq = hostp(h, p + ".fn.fn.to_qkv.weight");
+        const auto &g = hostp(h, p + ".fn.norm.g");
+        const auto &bn = hostp(h, p + ".fn.norm.b");
+        if ((rc = pack_qkv_folded(h, wq.data(), g.data(), bn.data(), c, 0, 3 * c, &a.qkv, &h->weight_allocs)))
+            return rc;
+        if ((rc = pack_qkv_folded(h, wq.data(), g.data(), bn.data(), c, c, 2 * c, &a.kv, &h->weight_allocs)))
+            return rc;
+    }
     if ((rc = pack_named_conv(h, p + ".fn.fn.to_out.weight", p + ".fn.fn.to_out.bias", 1, 0, false,
                               &a.out))) return rc;
     if ((rc = upload_param(h, p + ".fn.norm.g", &a.ng))) return rc;
     if ((rc = upload_param(h, p + ".fn.norm.b", &a.nb))) return rc;
-    // folded form: k,v rows of to_qkv as their own convolution; Wo^T [e][c] and Wq^T [ci][d]
-    if ((rc = pack_named_conv(h, p + ".fn.fn.to_qkv.weight", "", 1, 0, false, &a.kv, 0, 0, c, 2 * c)))
-        return rc;
+    // folded output: Wo^T [e][c] and Wq^T [ci][d]
     {
         const auto &wo = hostp(h, p + ".fn.fn.to_out.weight");   // [c][e]
         const auto &wq = hostp(h, p + ".fn.fn.to_qkv.weight");   // rows 0..C-1 = Wq [d][ci]
@@ -440,6 +466,8 @@ struct Builder {
         const float *pre_add = nullptr;                // hoisted partial sums (same layout as out)
         float *stat_mean = nullptr, *stat_rstd = nullptr;
         const float *pre_mean = nullptr, *pre_rstd = nullptr, *pre_g = nullptr, *pre_b = nullptr;
+        int pre_mode = 1;                              // 1 in-LDS LN, 2 folded (1x1, weights carry g / W.b)
+        int shift_bs = -1;                             // row stride of `shift` (-1: the U-Net's table)
         long long w_bs = 0;
         bool no_bias = false;
     };
@@ -458,7 +486,7 @@ struct Builder {
             s.Ho = (H + 2 * pad_y - w.KH) / w.stride + 1;
             s.Wo = (W + 2 * pad_x - w.KW) / w.stride + 1;
         }
-        s.B = B; s.need_all_cout = need_all; s.lnload = o.pre_mean != nullptr;
+        s.B = B; s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
         if (need_all && (w.Cout % 32)) return false;
         ConvPlan plan;
         if (!conv_make_plan(s, &plan)) {
@@ -471,7 +499,7 @@ struct Builder {
             fprintf(stderr, "[plan] %-10s Cin=%4d Cout=%4d k=%dx%d s=%d in=%3dx%-3d out=%3dx%-3d %s%s%s| MB=%2d NPW=%d "
                     "WN=%d groups=%2d KC=%2d nchunk=%3d tiles=%dx%d wgs=%6d lds=%6zu\n", kProfNames[prof], w.Cin,
                     w.Cout, w.KH, w.KW, w.stride, H, W, s.Ho, s.Wo, need_all ? "LN " : "   ",
-                    s.lnload ? "pre " : "    ", cur == &h->pre_ops ? "HOIST " : "", plan.MB, plan.NPW, plan.WN,
+                    s.lnmode ? (s.lnmode == 2 ? "pre2 " : "pre1 ") : "     ", cur == &h->pre_ops ? "HOIST " : "", plan.MB, plan.NPW, plan.WN,
                     plan.groups, plan.KC, plan.nchunk, plan.tiles_x, plan.tiles_y,
                     plan.tiles_x * plan.tiles_y * B * plan.groups * w.nz, plan.lds_bytes);
         Op op;
@@ -500,7 +528,7 @@ struct Builder {
         a.bias = o.no_bias ? nullptr : w.bias;
         a.pre_add = o.pre_add;
         a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu;
-        a.shift = o.shift; a.shift_bs = h->shift_bs;
+        a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         const double px = (double)B * s.Ho * s.Wo * w.nz;
@@ -535,7 +563,7 @@ struct Builder {
         if (w.Cout % 32 || w.Cout > 384) return false;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
-        s.Ho = H; s.Wo = W; s.B = B; s.lnload = false;
+        s.Ho = H; s.Wo = W; s.B = B; s.lnmode = 0;
         ConvPlan pf, pu;
         s.need_all_cout = true;
         if (!conv_make_plan(s, &pf)) return false;
@@ -631,6 +659,8 @@ struct Builder {
         return out;
     }
 
+    std::vector<std::pair<const float *, size_t>> dbg_taps;   // debugging aid (CDC_ATTN_TAP)
+
     // Residual(PreNorm(LinearAttention)) (network_components.py:10-16,69-77,117-139)
     Act attention(const AttnW &at, Act x, float *sm, float *sr) {
         if (rc) return Act();
@@ -638,8 +668,8 @@ struct Builder {
         const bool fold = at.WoT && N >= 4 * C && !getenv("CDC_NO_ATTN_FOLD");
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
         Act qkv = new_act(kvc, H, W);
-        ConvOpts oq;
-        oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_g = at.ng; oq.pre_b = at.nb; oq.no_bias = true;
+        ConvOpts oq;                                   // LN(x) folded into the projection (LNMODE 2)
+        oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_mode = 2;
         conv(fold ? at.kv : at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
         const float *kp = qkv.p + (size_t)(fold ? 0 : C) * N, *vp = kp + (size_t)C * N;
         float *kmax = dalloc((size_t)B * C), *ksum = dalloc((size_t)B * C);
@@ -650,10 +680,11 @@ struct Builder {
         const int Cin_pad = round_up(C, 16), COP = round_up(C, 32);
         float *ctxw = dalloc((size_t)B * Cin_pad * COP);
         float *T1 = fold ? dalloc((size_t)B * C * C) : nullptr;
+        float *biasB = fold ? dalloc((size_t)B * C) : nullptr;
         if (rc) return Act();
         Op k; k.kind = Op::KSTATS; k.prof = PC_SMALL;
         k.at = {kp, vp, qkv.bs(), C, N, kmax, ksum, S, ctxw, nsplit, Cin_pad, COP,
-                1.0f / sqrtf((float)C), at.WoT, at.WqT, T1};
+                1.0f / sqrtf((float)C), at.WoT, at.WqT, T1, at.ng, at.nb, at.out.bias, biasB};
         k.bytes = 8.0 * B * C * N;
         emit(k);
         Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
@@ -665,20 +696,23 @@ struct Builder {
         emit(r);
         ConvW cw;    // per-image weights produced above
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
-        cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1;
+        cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1; cw.bias = nullptr;
         Act y = new_act(C, H, W);
+        dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * C},
+                    {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
         if (fold) {
-            // y = M' LN(x) + b_out + x
-            cw.bias = at.out.bias;
-            ConvOpts oy = oq;
-            oy.no_bias = false; oy.w_bs = (long long)Cin_pad * COP;
+            // y = M' LN(x) + b_out + x with g folded into M' and (M' b_ln + b_out) as per-image shift
+            ConvOpts oy;
+            oy.pre_mean = sm; oy.pre_rstd = sr; oy.pre_mode = 2;
+            oy.w_bs = (long long)Cin_pad * COP;
+            oy.shift = biasB; oy.shift_bs = C;
             oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
             conv(cw, x.p, C, x.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
             return y;
         }
         // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
-        cw.bias = nullptr;
         Act o = new_act(C, H, W);
+        dbg_taps.push_back({o.p, (size_t)B * C * N});
         ConvOpts oo; oo.w_bs = (long long)Cin_pad * COP; oo.no_bias = true;
         conv(cw, qkv.p, C, qkv.bs(), nullptr, 0, H, W, o.p, o.bs(), oo, false, PC_CONV1);
         ConvOpts oy; oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
@@ -696,6 +730,7 @@ void free_program(cdc_handle *h) {
     h->act_bytes = 0;
     h->pB = h->pH = h->pW = 0;
     h->d_time_steps = nullptr;
+    h->d_shift_tab = nullptr;
     h->time_steps_B = 0;
 }
 
@@ -851,7 +886,8 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             break;
         case Op::CTXF:
             HIP_TRY(h, ctx_fold_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale, op.at.WoT,
-                                       op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
+                                       op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, op.at.ln_g,
+                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st));
             break;
         case Op::COMBINE:
             HIP_TRY(h, fold_combine_launch(op.cb.P, op.cb.bias, op.cb.out, op.cb.Cout, op.cb.KH, op.cb.pad,
@@ -867,6 +903,8 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
         HIP_TRY(h, hipEventRecord(eb, st));
         h->pending.push_back({ea, eb, op.prof, op.flops, op.bytes, op.id});
     }
+    static const bool sync_each = getenv("CDC_SYNC_EACH_OP") != nullptr;     // debugging aid
+    if (sync_each) HIP_TRY(h, hipStreamSynchronize(st));
     return CDC_OK;
 }
 
@@ -879,12 +917,15 @@ int run_pre(cdc_handle *h, hipStream_t st) {
     return CDC_OK;
 }
 
-int run_unet(cdc_handle *h, hipStream_t st, const float *time_override) {
+// step >= 0: sampler iteration `step` (time-embedding shifts come from the per-decode table);
+// step < 0: plain Unet.forward with the caller's per-image time values.
+int run_unet(cdc_handle *h, hipStream_t st, int step) {
     for (const Op &op : h->ops) {
-        if (op.kind == Op::TEMB && time_override) {
-            Op t = op;
-            t.temb.time = time_override;
-            int rc = run_op(h, t, h->pB, st);
+        if (op.kind == Op::TEMB && step >= 0) {
+            Op c = op;
+            c.kind = Op::COPY;
+            c.cp = {h->d_shift_tab + (size_t)step * h->shift_bs, 0, h->shift, h->shift_bs, h->shift_bs};
+            int rc = run_op(h, c, h->pB, st);
             if (rc) return rc;
             continue;
         }
@@ -1130,7 +1171,7 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
     h->prof_now = true;
     if ((rc = run_pre(h, st))) return rc;
-    if ((rc = run_unet(h, st, nullptr))) return rc;
+    if ((rc = run_unet(h, st, -1))) return rc;
     return copy_out(h, out, h->out_fx, (size_t)B * h->out_dim * H * W, mem, st);
 }
 
@@ -1155,17 +1196,26 @@ int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float
     return CDC_OK;
 }
 
+// All images of a decode share the step's time value, and the time-embedding MLPs (unet.py:41,
+// network_components.py:96-100) depend on nothing else: evaluate them for every sample step in one
+// launch (one workgroup per step) and broadcast row i at iteration i.
 static int ensure_time_rows(cdc_handle *h, int B) {
-    if (h->d_time_steps && h->time_steps_B == B) return CDC_OK;
-    std::vector<float> rows((size_t)h->steps * B);
-    for (int i = 0; i < h->steps; ++i)
-        for (int b = 0; b < B; ++b) rows[(size_t)i * B + b] = h->h_time_in[i];
-    void *p = nullptr;
-    HIP_TRY(h, hipMalloc(&p, rows.size() * sizeof(float)));
+    if (h->d_shift_tab && h->time_steps_B == B) return CDC_OK;
+    void *p = nullptr, *q = nullptr;
+    HIP_TRY(h, hipMalloc(&p, (size_t)h->steps * sizeof(float)));
     h->act_allocs.push_back(p);
-    HIP_TRY(h, hipMemcpy(p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(p, h->h_time_in.data(), (size_t)h->steps * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&q, (size_t)h->steps * h->shift_bs * sizeof(float)));
+    h->act_allocs.push_back(q);
     h->d_time_steps = (float *)p;
+    h->d_shift_tab = (float *)q;
     h->time_steps_B = B;
+    TembArgs t;
+    t.time = h->d_time_steps; t.w0 = h->tm_w0; t.b0 = h->tm_b0; t.w2 = h->tm_w2; t.b2 = h->tm_b2;
+    t.dim = h->cfg.dim; t.layers = h->d_temb_layers; t.n_layers = (int)h->rbs.size();
+    t.shift = h->d_shift_tab; t.shift_bs = h->shift_bs;
+    HIP_TRY(h, temb_launch(t, h->steps, h->own_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
     return CDC_OK;
 }
 
@@ -1176,7 +1226,7 @@ static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *
     const size_t n = (size_t)B * h->cfg.channels * H * W;
     if (x_in != h->in_x)
         HIP_TRY(h, hipMemcpyAsync(h->in_x, x_in, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if ((rc = run_unet(h, st, h->d_time_steps + (size_t)i * B))) return rc;
+    if ((rc = run_unet(h, st, i))) return rc;
     Op op;
     op.kind = Op::DDIM; op.prof = PC_SMALL;
     op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i,
@@ -1403,12 +1453,11 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
     Builder bd{h, B, &sc.pool};
     AttnW at;
     at.C = C;
-    if ((rc = pack_conv(h, w_qkv, nullptr, 3 * C, C, 1, 1, 1, 0, false, &at.qkv, &sc.pool))) return rc;
+    if ((rc = pack_qkv_folded(h, w_qkv, norm_g, norm_b, C, 0, 3 * C, &at.qkv, &sc.pool))) return rc;
+    if ((rc = pack_qkv_folded(h, w_qkv, norm_g, norm_b, C, C, 2 * C, &at.kv, &sc.pool))) return rc;
     if ((rc = pack_conv(h, w_out, b_out, C, C, 1, 1, 1, 0, false, &at.out, &sc.pool))) return rc;
     if ((rc = sc.up(norm_g, C, &at.ng))) return rc;
     if ((rc = sc.up(norm_b, C, &at.nb))) return rc;
-    if ((rc = pack_conv(h, w_qkv, nullptr, 3 * C, C, 1, 1, 1, 0, false, &at.kv, &sc.pool, 0, 0, C, 2 * C)))
-        return rc;
     {
         std::vector<float> woT((size_t)C * C), wqT((size_t)C * C);
         for (int i = 0; i < C; ++i)
@@ -1427,6 +1476,14 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
     bd.ln(ax.p, nullptr, C, H * W, nullptr, nullptr, 0, nullptr, nullptr, sm, sr);   // statistics only
     Act ay = bd.attention(at, ax, sm, sr);
     if (bd.rc) return bd.rc;
+    if (const char *tap = getenv("CDC_ATTN_TAP")) {          // debugging aid: return an intermediate
+        const size_t idx = (size_t)atoi(tap);
+        if (idx < bd.dbg_taps.size()) {
+            const size_t n = std::min(bd.dbg_taps[idx].second, (size_t)B * C * H * W);
+            memset(y, 0, sizeof(float) * (size_t)B * C * H * W);
+            return sc.run(B, y, bd.dbg_taps[idx].first, n);
+        }
+    }
     return sc.run(B, y, ay.p, (size_t)B * C * H * W);
 }
 

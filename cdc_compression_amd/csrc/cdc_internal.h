@@ -12,16 +12,16 @@ namespace cdc {
 
 // ---- convolution (conv_launch.hip) ---------------------------------------------------------------
 typedef void (*conv_kernel_fn)(const ConvArgs);
-conv_kernel_fn conv_lookup_a(int MB, int NPW, bool lnload);   // MB 1..3
-conv_kernel_fn conv_lookup_b(int MB, int NPW, bool lnload);   // MB 4..6
-conv_kernel_fn conv_lookup_c(int MB, int NPW, bool lnload);   // MB 7..12
+conv_kernel_fn conv_lookup_a(int MB, int NPW, int lnmode);   // MB 1..3
+conv_kernel_fn conv_lookup_b(int MB, int NPW, int lnmode);   // MB 4..6
+conv_kernel_fn conv_lookup_c(int MB, int NPW, int lnmode);   // MB 7..12
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;
     int Ho, Wo;          // output extent (per phase for ConvTranspose)
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel
-    bool lnload;
+    int lnmode;          // 0 none, 1 in-LDS LayerNorm of the staged input, 2 folded (1x1 only)
 };
 // Chooses MB/NPW/WN/KC/tiling.  Returns false if need_all_cout cannot be honoured.
 bool conv_make_plan(const ConvShape &s, ConvPlan *plan);
@@ -76,7 +76,8 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
-                           int COP, int B, hipStream_t st);
+                           int COP, const float *ln_g, const float *ln_b, const float *b_out,
+                           float *biasB, int B, hipStream_t st);
 hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
                                int pad, int H, int W, int B, hipStream_t st);
 

@@ -63,7 +63,7 @@ struct ConvPlan {
     int KC, nchunk;
     int lognbw, tiles_x, tiles_y, PH, PW;
     size_t lds_bytes;
-    bool lnload;
+    int lnmode;
 };
 
 }  // namespace cdc

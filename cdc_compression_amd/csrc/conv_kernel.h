@@ -15,8 +15,28 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) {
 
 __device__ __attribute__((aligned(16))) float g_zeros[64];   // DMA source of zero padding
 
-typedef const __attribute__((address_space(1))) void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
+// LDS-DMA (global_load_lds): each lane supplies a global address; the data lands at
+// LDS[M0 + lane*size].  Hand-written so that the wait state between the M0 write and the DMA is
+// explicit: with the compiler builtin the M0 update is emitted back-to-back with the DMA and whole
+// workgroup tiles came out wrong about once per 500 workgroups (stale-M0 signature: a piece lands at
+// the previous piece's base).  M0 is compiler-reserved, hence saved and restored.  hipcc does not
+// count these loads: dma_wait() must precede the barrier that publishes the buffer.
+__device__ __forceinline__ void dma_b128(const float *g, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const float *g, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
 
 constexpr int conv_min_waves(int MB, int NPW) { return MB * NPW <= 8 ? 2 : 1; }
 
@@ -28,8 +48,16 @@ constexpr int conv_min_waves(int MB, int NPW) { return MB * NPW <= 8 ? 2 : 1; }
 // pieces whose per-lane source address is either the tensor element or a zero word (padding,
 // channel tail).  Two LDS buffer sets; chunk c+1 streams in while chunk c feeds the MFMAs; one
 // barrier per chunk (hipcc drains vmcnt(0) in front of it).
-template <int MB, int NPW, bool LNLOAD>
+//
+// LNMODE: PreNorm LayerNorm of the input (network_components.py:69-77) fused into the convolution.
+//   0  none
+//   1  general: the landed patch is normalised in place in LDS (any k x k, zero padding preserved)
+//   2  1x1 only, algebraically folded: LN(x).W = rstd[p] * ((x - mean[p]) . (g*W)) + (W.b); the host
+//      packs g*W and W.b, the kernel subtracts the pixel mean while fetching the B operand and
+//      scales the accumulators by rstd[p] in the epilogue -- no extra LDS pass, no extra barrier.
+template <int MB, int NPW, int LNMODE>
 __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel(const ConvArgs P) {
+    constexpr bool LNLOAD = LNMODE == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COPT = MB * 32;
     const int tid = threadIdx.x;
@@ -92,8 +120,10 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
     const float *wsrc = P.wp + (size_t)b * P.w_bs + (size_t)z * P.w_zs + (size_t)cog * COPT;
 
-    auto issue = [&](int chunk, float *buf) {
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int chunk, int which) {
         const int cbase = chunk * KC;
+        const unsigned buf_lds = smem_lds + (unsigned)(which * buf_floats) * 4u;
         // weights: slot i covers float4 index e4 = tid + i*nthr of the slab [taps*KC][COPT/4]
         const float *wc = wsrc + (size_t)cbase * P.COP;
         for (int i = 0; i < ws; ++i) {
@@ -105,10 +135,9 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
                 const int tap = row >> P.logKC, kcl = row & (KC - 1);
                 src = wc + ((size_t)tap * P.Cin_pad + kcl) * P.COP + c4 * 4;
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + (i * nthr + wave * 64) * 4),
-                                             16, 0, 0);
+            dma_b128(src, buf_lds + (unsigned)(i * nthr + wave * 64) * 16u);
         }
-        float *xb = buf + w_floats;
+        const unsigned xb_lds = buf_lds + (unsigned)w_floats * 4u;
 #pragma unroll
         for (int i = 0; i < kXS; ++i) {
             if (i < xs) {
@@ -119,8 +148,7 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
                     if (c < P.C0) src = s0 + (size_t)c * HW + sp;
                     else if (c < P.Cin) src = s1 + (size_t)(c - P.C0) * HW + sp;
                 }
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xb + i * nthr + wave * 64), 4, 0,
-                                                 0);
+                dma_b32(src, xb_lds + (unsigned)(i * nthr + wave * 64) * 4u);
             }
         }
     };
@@ -140,11 +168,23 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride;
     const int nb_stride = NBH * P.stride * PW;
 
-    issue(0, smem);
+    float pmean[LNMODE == 2 ? NPW : 1], prstd[LNMODE == 2 ? NPW : 1];
+    if constexpr (LNMODE == 2) {
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int oy = oy0 + (wave * NPW + n) * NBH + pr, ox = ox0 + pc;
+            const bool ok = oy < P.Ho && ox < P.Wo;
+            pmean[n] = ok ? P.ln_mean[(size_t)b * P.H * P.W + oy * P.W + ox] : 0.f;
+            prstd[n] = ok ? P.ln_rstd[(size_t)b * P.H * P.W + oy * P.W + ox] : 0.f;
+        }
+    }
+
+    issue(0, 0);
     for (int chunk = 0; chunk < P.nchunk; ++chunk) {
         float *buf = smem + (chunk & 1) * buf_floats;
-        __syncthreads();          // chunk's DMA landed (vmcnt(0) precedes the barrier); other buffer free
-        if (chunk + 1 < P.nchunk) issue(chunk + 1, smem + ((chunk + 1) & 1) * buf_floats);
+        dma_wait();               // this wave's pieces of `chunk` have landed ...
+        __syncthreads();          // ... and so have everyone's; the other buffer is free again
+        if (chunk + 1 < P.nchunk) issue(chunk + 1, (chunk + 1) & 1);
         float *w_lds = buf;
         float *x_lds = buf + w_floats;
         if constexpr (LNLOAD) {
@@ -173,7 +213,10 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
 #pragma unroll
                         for (int m = 0; m < MB; ++m) a[m] = wl[(kc + k2) * COPT + m * 32];
 #pragma unroll
-                        for (int n = 0; n < NPW; ++n) bv[n] = xl[(kc + k2) * plane + n * nb_stride];
+                        for (int n = 0; n < NPW; ++n) {
+                            bv[n] = xl[(kc + k2) * plane + n * nb_stride];
+                            if constexpr (LNMODE == 2) bv[n] -= pmean[n];
+                        }
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -214,8 +257,10 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (LNMODE == 2) acc[m][n][r] *= prstd[n];
                 acc[m][n][r] += epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+            }
         const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
         if (P.pre_add) {
             // hoisted partial sums (context half of a concatenated input), same addressing as out

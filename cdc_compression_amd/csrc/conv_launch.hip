@@ -10,10 +10,10 @@ static unsigned magic_of(unsigned d) {
     return (unsigned)(((1ull << 32) + d - 1) / d);
 }
 
-static conv_kernel_fn lookup(int MB, int NPW, bool lnload) {
-    if (MB <= 3) return conv_lookup_a(MB, NPW, lnload);
-    if (MB <= 6) return conv_lookup_b(MB, NPW, lnload);
-    return conv_lookup_c(MB, NPW, lnload);
+static conv_kernel_fn lookup(int MB, int NPW, int lnmode) {
+    if (MB <= 3) return conv_lookup_a(MB, NPW, lnmode);
+    if (MB <= 6) return conv_lookup_b(MB, NPW, lnmode);
+    return conv_lookup_c(MB, NPW, lnmode);
 }
 
 // LDS budget per workgroup.  The register-staged pipeline keeps ONE buffer set in LDS (the next
@@ -31,7 +31,7 @@ static size_t plan_lds(int taps, int kc, int COPT, int PH, int PW, int nthr) {
 static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p) {
     const int nblocks = ceil_div(s.Cout, 32);
     if (nblocks % MB) return false;
-    if (!lookup(MB, NPW, s.lnload)) return false;
+    if (!lookup(MB, NPW, s.lnmode)) return false;
     const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
     const int nb_rows = ceil_div(s.Ho, NBH);
     int WN = std::min(4, ceil_div(nb_rows, NPW));
@@ -64,7 +64,7 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     p->tiles_y = ceil_div(s.Ho, TH);
     p->PH = PH; p->PW = PW;
     p->lds_bytes = plan_lds(taps, KC, COPT, PH, PW, nthr);
-    p->lnload = s.lnload;
+    p->lnmode = s.lnmode;
     return true;
 }
 
@@ -115,7 +115,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.PH = p.PH; a.PW = p.PW;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW));
     a.magic_w = magic_of((unsigned)p.PW);
-    conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnload);
+    conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnmode);
     if (!fn) return hipErrorInvalidValue;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn,

@@ -220,3 +220,22 @@ def test_full_resolution_256_digest_and_properties():
     y2 = un(x2, t2, ctx2)
     np.testing.assert_array_equal(y2[0], y2[1])
     assert relerr(y2[0], y[0]) < 1e-5
+
+
+def test_run_to_run_determinism(G):
+    """Race screen: identical inputs must give bit-identical outputs on every run.  (Guards the
+    LDS-DMA staging: with a missing M0 wait state whole workgroup tiles came out wrong ~1/500.)"""
+    B, C, H, W = 4, 384, 8, 8
+    x = synth.normal("ax", (B, C, H, W), 24)
+    ng = synth.normal("ag", (1, C, 1, 1), 24, 0.2, 1.0)
+    nb = synth.normal("ab", (1, C, 1, 1), 24, 0.2)
+    wq = synth.normal("aq", (3 * C, C, 1, 1), 24, 2.0 / np.sqrt(C))
+    wo = synth.normal("ao", (C, C, 1, 1), 24, 1.0 / np.sqrt(C))
+    bo = synth.normal("aob", (C,), 24, 0.1)
+    ref = G.linear_attention(x, ng, nb, wq, wo, bo)
+    for _ in range(60):
+        np.testing.assert_array_equal(G.linear_attention(x, ng, nb, wq, wo, bo), ref)
+    un, kw, sd, x, time, ctx, g = make_unet("full_x")
+    y0 = un(x, time, ctx)
+    for _ in range(12):
+        np.testing.assert_array_equal(un(x, time, ctx), y0)
