@@ -479,8 +479,17 @@ struct Builder {
               bool need_all, int prof) {
         if (rc) return true;
         const int pad_y = w.pad_y >= 0 ? w.pad_y : w.pad, pad_x = w.pad_x >= 0 ? w.pad_x : w.pad;
+        if (s1 && (C0 % 4)) {
+            // the kernel wants every K-chunk inside one concat source: materialise odd seams
+            const long long n0 = (long long)C0 * H * W, n1 = (long long)(w.Cin - C0) * H * W;
+            float *cat = dalloc((size_t)B * (n0 + n1));
+            copy(s0, bs0, cat, n0 + n1, n0);
+            copy(s1, bs1, cat + n0, n0 + n1, n1);
+            s0 = cat; bs0 = n0 + n1; s1 = nullptr; bs1 = 0;
+        }
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
+        s.C0 = s1 ? C0 : 0;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
             s.Ho = (H + 2 * pad_y - w.KH) / w.stride + 1;

@@ -15,9 +15,11 @@ typedef void (*conv_kernel_fn)(const ConvArgs);
 conv_kernel_fn conv_lookup_a(int MB, int NPW, int lnmode);   // MB 1..3
 conv_kernel_fn conv_lookup_b(int MB, int NPW, int lnmode);   // MB 4..6
 conv_kernel_fn conv_lookup_c(int MB, int NPW, int lnmode);   // MB 7..12
+conv_kernel_fn conv_lookup_abl(int MB, int NPW, int abl);    // tuning aid (CDC_ABLATE)
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;
+    int C0 = 0;          // channels of the first concat source (0: single source); KC must divide it
     int Ho, Wo;          // output extent (per phase for ConvTranspose)
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel

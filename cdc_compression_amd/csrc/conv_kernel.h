@@ -33,6 +33,25 @@ __device__ __forceinline__ void dma_b32(const float *g, unsigned lds_byte) {
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
 }
+// same, source address = scalar base (SGPR pair) + per-lane unsigned 32-bit byte offset
+__device__ __forceinline__ void dma_b128_s(unsigned voff, const float *sbase, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma_b32_s(unsigned voff, const float *sbase, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ const float *uniform_ptr(const float *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const float *p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
@@ -55,7 +74,9 @@ constexpr int conv_min_waves(int MB, int NPW) { return MB * NPW <= 8 ? 2 : 1; }
 //   2  1x1 only, algebraically folded: LN(x).W = rstd[p] * ((x - mean[p]) . (g*W)) + (W.b); the host
 //      packs g*W and W.b, the kernel subtracts the pixel mean while fetching the B operand and
 //      scales the accumulators by rstd[p] in the epilogue -- no extra LDS pass, no extra barrier.
-template <int MB, int NPW, int LNMODE>
+// ABL (compile-time, tuning aid only): 1 no DMA after chunk 0, 2 no operand fetch, 4 no per-chunk barrier,
+// 8 one store per lane, 16 no prologue descriptors/DMA at all -- timing experiments, wrong results.
+template <int MB, int NPW, int LNMODE, int ABL = 0>
 __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel(const ConvArgs P) {
     constexpr bool LNLOAD = LNMODE == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -93,62 +114,70 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     const int buf_floats = w_floats + xs * nthr;
 
     // ---- chunk-invariant descriptors of this thread's input-patch slots --------------------------
-    int xo[kXS];       // (c_local << 24) | (iy*W+ix) ; -1: zero (padding / beyond the patch)
+    // xo = (c_local << 27) | (iy*W + ix) for an element inside the image, -1 for zero padding and for
+    // slots beyond the patch.  Padding positions are the same in every chunk: they are zeroed once in
+    // both LDS buffers and never written again (their lanes are masked out of the DMA), so the
+    // per-chunk issue needs no bounds logic at all.
+    int xo[kXS];
     float xmean[LNLOAD ? kXS : 1], xrstd[LNLOAD ? kXS : 1];
 #pragma unroll
     for (int i = 0; i < kXS; ++i) {
         const unsigned e = tid + i * nthr;
         xo[i] = -1;
         if constexpr (LNLOAD) { xmean[i] = 0.f; xrstd[i] = 0.f; }
-        if (i < xs && e < (unsigned)n_x) {
-            const unsigned c = fdiv(e, P.magic_hw);
-            const unsigned rem = e - c * (unsigned)plane;
-            const unsigned r = fdiv(rem, P.magic_w);
-            const unsigned col = rem - r * (unsigned)PW;
-            const int iy = iy0 + (int)r, ix = ix0 + (int)col;
-            if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {
-                xo[i] = (int)(c << 24) | (iy * P.W + ix);
-                if constexpr (LNLOAD) {
-                    xmean[i] = P.ln_mean[(size_t)b * P.H * P.W + iy * P.W + ix];
-                    xrstd[i] = P.ln_rstd[(size_t)b * P.H * P.W + iy * P.W + ix];
+        if (i < xs) {
+            if (e < (unsigned)n_x) {
+                const unsigned c = fdiv(e, P.magic_hw);
+                const unsigned rem = e - c * (unsigned)plane;
+                const unsigned r = fdiv(rem, P.magic_w);
+                const unsigned col = rem - r * (unsigned)PW;
+                const int iy = iy0 + (int)r, ix = ix0 + (int)col;
+                if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {
+                    xo[i] = (int)(c << 27) | (iy * P.W + ix);
+                    if constexpr (LNLOAD) {
+                        xmean[i] = P.ln_mean[(size_t)b * P.H * P.W + iy * P.W + ix];
+                        xrstd[i] = P.ln_rstd[(size_t)b * P.H * P.W + iy * P.W + ix];
+                    }
                 }
+            }
+            if (xo[i] < 0) {
+                smem[w_floats + e] = 0.f;
+                smem[buf_floats + w_floats + e] = 0.f;
             }
         }
     }
-    const size_t HW = (size_t)P.H * P.W;
+    const unsigned HW = (unsigned)(P.H * P.W);
     const float *s0 = P.src0 + (size_t)b * P.src0_bs;
     const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
     const float *wsrc = P.wp + (size_t)b * P.w_bs + (size_t)z * P.w_zs + (size_t)cog * COPT;
 
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    // A chunk lies entirely in one concat source (the host guarantees C0 % KC == 0), so the source
+    // address is a scalar base per chunk plus a 32-bit per-lane offset.
     auto issue = [&](int chunk, int which) {
         const int cbase = chunk * KC;
         const unsigned buf_lds = smem_lds + (unsigned)(which * buf_floats) * 4u;
-        // weights: slot i covers float4 index e4 = tid + i*nthr of the slab [taps*KC][COPT/4]
-        const float *wc = wsrc + (size_t)cbase * P.COP;
+        const float *wbase = uniform_ptr(wsrc + (size_t)cbase * P.COP);
         for (int i = 0; i < ws; ++i) {
             const int e4 = tid + i * nthr;
-            const float *src = g_zeros;
             if (e4 < n_w4) {
                 const int row = e4 / (COPT / 4);
                 const int c4 = e4 - row * (COPT / 4);
                 const int tap = row >> P.logKC, kcl = row & (KC - 1);
-                src = wc + ((size_t)tap * P.Cin_pad + kcl) * P.COP + c4 * 4;
+                const unsigned voff = (unsigned)((tap * P.Cin_pad + kcl) * P.COP + c4 * 4) * 4u;
+                dma_b128_s(voff, wbase, buf_lds + (unsigned)(i * nthr + wave * 64) * 16u);
             }
-            dma_b128(src, buf_lds + (unsigned)(i * nthr + wave * 64) * 16u);
         }
-        const unsigned xb_lds = buf_lds + (unsigned)w_floats * 4u;
+        const float *xbase = uniform_ptr(cbase < P.C0 ? s0 + (size_t)cbase * HW
+                                                      : s1 + (size_t)(cbase - P.C0) * HW);
+        const int ncm1 = min(KC, P.Cin - cbase) - 1;       // channel tail: re-read the last valid
+        const unsigned xb_lds = buf_lds + (unsigned)w_floats * 4u;   // channel (its weights are zero)
 #pragma unroll
         for (int i = 0; i < kXS; ++i) {
-            if (i < xs) {
-                const float *src = g_zeros;
-                if (xo[i] >= 0) {
-                    const int c = cbase + (xo[i] >> 24);
-                    const int sp = xo[i] & 0xFFFFFF;
-                    if (c < P.C0) src = s0 + (size_t)c * HW + sp;
-                    else if (c < P.Cin) src = s1 + (size_t)(c - P.C0) * HW + sp;
-                }
-                dma_b32(src, xb_lds + (unsigned)(i * nthr + wave * 64) * 4u);
+            if (i < xs && xo[i] >= 0) {
+                const unsigned c = (unsigned)min(xo[i] >> 27, ncm1);
+                const unsigned voff = (c * HW + (unsigned)(xo[i] & 0x7FFFFFF)) * 4u;
+                dma_b32_s(voff, xbase, xb_lds + (unsigned)(i * nthr + wave * 64) * 4u);
             }
         }
     };
@@ -183,8 +212,9 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     for (int chunk = 0; chunk < P.nchunk; ++chunk) {
         float *buf = smem + (chunk & 1) * buf_floats;
         dma_wait();               // this wave's pieces of `chunk` have landed ...
-        __syncthreads();          // ... and so have everyone's; the other buffer is free again
-        if (chunk + 1 < P.nchunk) issue(chunk + 1, (chunk + 1) & 1);
+        if (!(ABL & 4) || chunk == 0)
+            __syncthreads();      // ... and so have everyone's; the other buffer is free again
+        if (chunk + 1 < P.nchunk && !(ABL & 1)) issue(chunk + 1, (chunk + 1) & 1);
         float *w_lds = buf;
         float *x_lds = buf + w_floats;
         if constexpr (LNLOAD) {
@@ -193,7 +223,7 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
 #pragma unroll
             for (int i = 0; i < kXS; ++i) {
                 if (i < xs && xo[i] >= 0) {
-                    const int c = cbase + (xo[i] >> 24);
+                    const int c = cbase + (xo[i] >> 27);
                     if (c < P.Cin) {
                         const int e = tid + i * nthr;
                         x_lds[e] = (x_lds[e] - xmean[i]) * xrstd[i] * P.ln_g[c] + P.ln_b[c];
@@ -202,28 +232,42 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
             }
             __syncthreads();
         }
-        for (int ky = 0; ky < P.KH; ++ky) {
-            for (int kx = 0; kx < P.KW; ++kx) {
-                const float *wl = w_lds + (ky * P.KW + kx) * KC * COPT + a_lane;
-                const float *xl = x_lds + b_lane + ky * PW + kx;
-                for (int kc = 0; kc < KC; kc += 4) {
+        // Flattened (tap, channel-pair) sequence, software-pipelined by hand: the A/B operands of
+        // step s+1 are fetched from LDS before the MFMAs of step s issue, so one wave alone keeps
+        // the matrix pipe busy (the LDS latency hides behind MB*NPW MFMAs of 64 cycles each).
+        {
+            int nky = 0, nkx = 0, nkc = 0;           // (tap, channel) of the NEXT step to fetch
+            auto fetch = [&](float (&a)[MB], float (&bv)[NPW]) {
+                const float *wl = w_lds + ((nky * P.KW + nkx) * KC + nkc) * COPT + a_lane;
+                const float *xl = x_lds + b_lane + nky * PW + nkx + nkc * plane;
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; k2 += 2) {
-                        float a[MB], bv[NPW];
+                for (int m = 0; m < MB; ++m) a[m] = wl[m * 32];
 #pragma unroll
-                        for (int m = 0; m < MB; ++m) a[m] = wl[(kc + k2) * COPT + m * 32];
+                for (int n = 0; n < NPW; ++n) bv[n] = xl[n * nb_stride];
+                nkc += 2;
+                if (nkc == KC) { nkc = 0; if (++nkx == P.KW) { nkx = 0; ++nky; } }
+            };
+            auto fma = [&](const float (&a)[MB], const float (&bv)[NPW]) {
 #pragma unroll
-                        for (int n = 0; n < NPW; ++n) {
-                            bv[n] = xl[(kc + k2) * plane + n * nb_stride];
-                            if constexpr (LNMODE == 2) bv[n] -= pmean[n];
-                        }
+                for (int n = 0; n < NPW; ++n) {
+                    const float bn = LNMODE == 2 ? bv[n] - pmean[n] : bv[n];
 #pragma unroll
-                        for (int m = 0; m < MB; ++m)
-#pragma unroll
-                            for (int n = 0; n < NPW; ++n)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[n],
-                                                                                acc[m][n], 0, 0, 0);
-                    }
+                    for (int m = 0; m < MB; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bn, acc[m][n], 0, 0, 0);
+                }
+            };
+            const int nsteps = taps * (KC >> 1);     // even: KC is a multiple of 4
+            float a0[MB], b0[NPW], a1[MB], b1[NPW];
+            fetch(a0, b0);
+            if constexpr ((ABL & 2) != 0) {
+                fetch(a1, b1);
+                for (int st = 0; st < nsteps; st += 2) { fma(a0, b0); fma(a1, b1); }
+            } else {
+                for (int st = 0; st < nsteps; st += 2) {
+                    fetch(a1, b1);
+                    fma(a0, b0);
+                    if (st + 2 < nsteps) fetch(a0, b0);
+                    fma(a1, b1);
                 }
             }
         }
@@ -363,6 +407,15 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
                 P.stat_mean[(size_t)b * P.out_cs + pix] = mean;
                 P.stat_rstd[(size_t)b * P.out_cs + pix] = 1.0f / sqrtf(q * inv_c + P.eps);
             }
+        }
+        if constexpr ((ABL & 8) != 0) {          // timing aid: one store per lane instead of MB*16
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[m][n][r];
+            if (valid) P.out[(size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs] = t;
+            continue;
         }
         float *op = P.out + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll

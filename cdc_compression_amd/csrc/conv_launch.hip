@@ -1,4 +1,7 @@
 // conv_launch.hip -- launch-plan chooser and launcher of the implicit-GEMM convolution kernel.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "cdc_internal.h"
@@ -28,7 +31,7 @@ static size_t plan_lds(int taps, int kc, int COPT, int PH, int PW, int nthr) {
     return std::max(sizeof(float) * 2 * buf, sizeof(float) * 4 * (size_t)COPT);
 }
 
-static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p) {
+static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p, int force_kc = 0) {
     const int nblocks = ceil_div(s.Cout, 32);
     if (nblocks % MB) return false;
     if (!lookup(MB, NPW, s.lnmode)) return false;
@@ -48,6 +51,8 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     const bool two_wg = MB * NPW <= 8;
     for (size_t budget : {two_wg ? kLdsSmall : kLdsBig, kLdsBig}) {
         for (int kc : {16, 8, 4}) {
+            if (force_kc && kc != force_kc) continue;
+            if (s.C0 % kc) continue;                              // a chunk never straddles the concat seam
             if (kc > round_up(s.Cin, 4) && kc > 4) continue;      // do not over-pad tiny Cin
             const bool x_ok = kc * PH * PW <= kXS * nthr;
             if (x_ok && plan_lds(taps, kc, COPT, PH, PW, nthr) <= budget) { KC = kc; break; }
@@ -84,18 +89,24 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     const int nb_rows = ceil_div(s.Ho, NBH);
     ConvPlan best;
     double best_score = -1;
+    // tuning aid: CDC_PLAN="MB,NPW,KC" (0 = free) restricts the candidates
+    int f_mb = 0, f_npw = 0, f_kc = 0;
+    if (const char *e = getenv("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
     for (int MB : mbs) {
+        if (f_mb && !s.need_all_cout && MB != f_mb) continue;
         for (int NPW : {4, 2, 1}) {
             if (MB * NPW > 12) continue;
             if (NPW > 1 && NPW > nb_rows) continue;
+            if (f_npw && NPW != f_npw) continue;
             ConvPlan p;
-            if (!try_plan(s, MB, NPW, lognbw, &p)) continue;
+            if (!try_plan(s, MB, NPW, lognbw, &p, f_kc)) continue;
             // score: prefer register blocking (fewer LDS reads per MFMA) but keep the chip filled
             const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups;
             const double fill = std::min(1.0, wgs * p.WN / (256.0 * 4.0));
+            // measured (tools/gpu_conv_tune.py): register blocking matters more than the chunk depth
+            // (MB2/NPW4/KC4 99 TF vs MB2/NPW2/KC8 91 TF; MB4/NPW2/KC4 103 TF vs KC8 with one WG/CU 91 TF)
             const double reuse = (double)(MB * NPW) / (MB + NPW);
-            const double kc_f = p.KC >= 8 ? 1.0 : 0.9;
-            const double score = fill * (0.6 + 0.1 * std::min(reuse, 4.0)) * kc_f;
+            const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0));
             if (score > best_score) { best_score = score; best = p; }
         }
         if (s.need_all_cout) break;
@@ -115,7 +126,10 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.PH = p.PH; a.PW = p.PW;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW));
     a.magic_w = magic_of((unsigned)p.PW);
+    static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
     conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnmode);
+    if (ablate && p.lnmode == 0)
+        if (conv_kernel_fn f2 = conv_lookup_abl(p.MB, p.NPW, ablate)) fn = f2;
     if (!fn) return hipErrorInvalidValue;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn,

@@ -35,6 +35,21 @@ class Ops:
         except Exception:
             pass
 
+    def prof(self, on=True):
+        L = _lib.lib()
+        L.cdc_prof_reset(self._h)
+        L.cdc_prof_enable(self._h, 1 if on else 0)
+
+    def prof_total_ms(self):
+        """(total ms, launches, flops) accumulated since prof(True) over all kernel classes."""
+        L = _lib.lib()
+        tot, n, fl = 0.0, 0, 0.0
+        for c in range(L.cdc_prof_num_classes()):
+            ms, k, f, b = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            L.cdc_prof_get(self._h, c, ctypes.byref(ms), ctypes.byref(k), ctypes.byref(f), ctypes.byref(b))
+            tot += ms.value; n += k.value; fl += f.value
+        return tot, n, fl
+
     def conv2d(self, x, w, b=None, stride=1, padding=0, ln_g=None, ln_b=None, relu=False, shift=None,
                resid=None):
         x, w, b, ln_g, ln_b, shift, resid = map(_c, (x, w, b, ln_g, ln_b, shift, resid))
