@@ -217,58 +217,69 @@ hipError_t temb_launch(const TembArgs &a, int B, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k.softmax(dim=-1) statistics (network_components.py:134): row max and sum of exp over N pixels.
+// k.softmax(dim=-1) (network_components.py:134), part 1: row maximum over the N pixels.
+// (The row sum of exponentials is accumulated by the context kernel, which exponentiates anyway.)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kstats_kernel(const float *k, long long k_bs, int C, int N,
-                                                     float *kmax, float *ksum) {
+__global__ void __launch_bounds__(256) kmax_kernel(const float *k, long long k_bs, int C, int N,
+                                                   float *kmax) {
     __shared__ float red[4];
     const int d = blockIdx.x, b = blockIdx.y;
     const float *row = k + (size_t)b * k_bs + (size_t)d * N;
     const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float m = -INFINITY;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) m = fmaxf(m, row[n]);
+    if ((N & 3) == 0) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+        for (int n = threadIdx.x; n < (N >> 2); n += blockDim.x) {
+            const float4 v = r4[n];
+            m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) m = fmaxf(m, row[n]);
+    }
     m = wave_max(m);
     if (lane == 0) red[w] = m;
     __syncthreads();
-    m = red[0];
-    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
-    __syncthreads();
-    float s = 0.f;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) s += expf(row[n] - m);
-    s = wave_sum(s);
-    if (lane == 0) red[w] = s;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < nw; ++i) t += red[i];
+        m = red[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
         kmax[(size_t)b * C + d] = m;
-        ksum[(size_t)b * C + d] = t;
     }
 }
 
-hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, float *ksum,
-                         int B, hipStream_t st) {
-    const int block = N >= 1024 ? 256 : 64;
-    hipLaunchKernelGGL(kstats_kernel, dim3(C, B), dim3(block), 0, st, k, k_bs, C, N, kmax, ksum);
+hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, int B,
+                         hipStream_t st) {
+    const int block = N >= 2048 ? 256 : 64;
+    hipLaunchKernelGGL(kmax_kernel, dim3(C, B), dim3(block), 0, st, k, k_bs, C, N, kmax);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// context = softmax(k) . v^T  (network_components.py:135), unnormalised partial sums:
+// context = softmax(k) . v^T  (network_components.py:135), unnormalised partial sums per pixel split:
 //   S[b][split][d][e] = sum_{n in split} exp(k[d,n] - kmax[d]) * v[e,n]
-// 64(d) x 64(e) output tile per workgroup, MFMA 32x32x2 f32 with A[i=d][k=n], B[k=n][j=e]; the
-// four waves split each 64-pixel chunk (16 pixels = 8 k-steps each) and are summed through LDS.
+//   Zp[b][split][d]   = sum_{n in split} exp(k[d,n] - kmax[d])
+// HBM-bound (C/4 FLOP per byte).  64(d) x 64(e) tile per workgroup on v_mfma_f32_32x32x2_f32 with
+// A[i=d][k=n], B[k=n][j=e]; k / v tiles of 64 pixels stream global -> LDS by 16-byte LDS-DMA into a
+// two-stage ring.  A DMA piece is lane-linear in LDS, so the bank-conflict swizzle is applied on the
+// SOURCE address: LDS slot s of row r holds the pixel quad s ^ (r & 15); reads undo it.  exp() is
+// applied to the A operand on its way from LDS to the MFMA.  The four waves split each chunk's
+// pixels (16 each) and are summed through LDS at the end.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCtxPch = 64;             // pixels per staged chunk
-constexpr int kCtxLd = kCtxPch + 1;     // padded row stride (conflict-free column reads)
+constexpr int kCtxPch = 64;
+
+__device__ __attribute__((aligned(16))) float g_ctx_zeros[64];
+
+__device__ __forceinline__ void ctx_dma16(const float *g, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+}
 
 __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const float *v,
                                                           long long kv_bs, int C, int N,
-                                                          const float *kmax, float *S, int nsplit,
-                                                          int tiles) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *kl = sm;                          // [64][kCtxLd]
-    float *vl = sm + 64 * kCtxLd;            // [64][kCtxLd]
+                                                          const float *kmax, float *S, float *Zp,
+                                                          int nsplit, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 stages x (k 64x64 + v 64x64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dt = blockIdx.x / tiles, et = blockIdx.x % tiles;
@@ -279,7 +290,24 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
     const int n_end = min(N, n_begin + nps);
     const float *kb = k + (size_t)b * kv_bs;
     const float *vb = v + (size_t)b * kv_bs;
-    const float *mb = kmax + (size_t)b * C;
+    const unsigned sm_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) float *)sm);
+
+    // this lane's share of a stage: 8 pieces (4 rows x 64 pixels each); piece p of wave w covers
+    // rows 4*(w*4 + p%4) .. +3 of tensor p/4 (0 = k, 1 = v)
+    const int prow = lane >> 4, pslot = lane & 15;
+    auto issue = [&](int n0, int stage) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int tensor = p >> 2;
+            const int row = 4 * (wave * 4 + (p & 3)) + prow;
+            const int n = n0 + 4 * (pslot ^ (row & 15));
+            const int ch = (tensor ? e0 : d0) + row;
+            const float *src = g_ctx_zeros;
+            if (ch < C && n < n_end) src = (tensor ? vb : kb) + (size_t)ch * N + n;
+            ctx_dma16(src, sm_lds + (unsigned)(stage * 8192 + tensor * 4096 + (wave * 4 + (p & 3)) * 256) * 4u);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -290,29 +318,31 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, jj = lane & 31;
-    for (int n0 = n_begin; n0 < n_end; n0 += kCtxPch) {
+    float mrow[2], zrow[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mrow[i] = (d0 + i * 32 + jj < C) ? kmax[(size_t)b * C + d0 + i * 32 + jj] : 0.f;
+
+    if (n_begin < n_end) issue(n_begin, 0);
+    int stage = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += kCtxPch, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // stage: 64 rows x 64 pixels for k (exponentiated) and v; thread -> (row, 16-pixel strip)
-        for (int e = tid; e < 64 * kCtxPch; e += 256) {
-            const int row = e >> 6, col = e & 63;
-            const int n = n0 + col;
-            float kv = 0.f, vv = 0.f;
-            if (n < n_end) {
-                if (d0 + row < C) kv = expf(kb[(size_t)(d0 + row) * N + n] - mb[d0 + row]);
-                if (e0 + row < C) vv = vb[(size_t)(e0 + row) * N + n];
-            }
-            kl[row * kCtxLd + col] = kv;
-            vl[row * kCtxLd + col] = vv;
-        }
-        __syncthreads();
+        if (n0 + kCtxPch < n_end) issue(n0 + kCtxPch, stage ^ 1);
+        const float *kl = sm + stage * 8192, *vl = kl + 4096;
         const int nb = wave * 16;
 #pragma unroll
         for (int ks = 0; ks < 16; ks += 2) {
+            const int nl = nb + ks + half;                       // pixel inside the chunk
+            const int off = 4 * ((nl >> 2) ^ (jj & 15)) + (nl & 3);   // rows i*32+jj: (row & 15) == jj & 15
+            const bool pv = n0 + nl < n_end;
             float a[2], bb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = kl[(i * 32 + jj) * kCtxLd + nb + ks + half];
+            for (int i = 0; i < 2; ++i) {
+                a[i] = pv ? expf(kl[(i * 32 + jj) * 64 + off] - mrow[i]) : 0.f;
+                zrow[i] += a[i];
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bb[j] = vl[(j * 32 + jj) * kCtxLd + nb + ks + half];
+            for (int j = 0; j < 2; ++j) bb[j] = vl[(j * 32 + jj) * 64 + off];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -320,7 +350,7 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
     }
-    // cross-wave reduction through LDS: red[wave][d 64][e 64]
+    // cross-wave reduction through LDS: red[wave][d 64][e 64] (64 KiB = the whole ring)
     __syncthreads();
     float *red = sm;
 #pragma unroll
@@ -330,24 +360,62 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int e = j * 32 + jj;
-                red[(wave * 64 + d) * 64 + e] = acc[i][j][r];
+                red[(wave * 64 + d) * 64 + j * 32 + jj] = acc[i][j][r];
             }
     __syncthreads();
     float *out = S + (((size_t)b * nsplit + split) * C) * C;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int d = idx >> 6, e = idx & 63;
-        if (d0 + d < C && e0 + e < C) {
-            const float s = red[idx] + red[4096 + idx] + red[8192 + idx] + red[12288 + idx];
-            out[(size_t)(d0 + d) * C + e0 + e] = s;
+        if (d0 + d < C && e0 + e < C)
+            out[(size_t)(d0 + d) * C + e0 + e] = red[idx] + red[4096 + idx] + red[8192 + idx] + red[12288 + idx];
+    }
+    if (et == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float z = zrow[i] + __shfl_xor(zrow[i], 32);
+            if (half == 0) red[wave * 64 + i * 32 + jj] = z;
         }
+        __syncthreads();
+        if (tid < 64 && d0 + tid < C)
+            Zp[((size_t)b * nsplit + split) * C + d0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+    }
+}
+
+// Same quantities for pixel counts that are not a multiple of 4 (tiny odd feature maps only): plain
+// VALU loops, one workgroup per (d, split, image), threads over e.
+__global__ void __launch_bounds__(256) ctx_partial_generic_kernel(const float *k, const float *v,
+                                                                  long long kv_bs, int C, int N,
+                                                                  const float *kmax, float *S,
+                                                                  float *Zp, int nsplit) {
+    const int d = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const int nps = round_up(ceil_div(N, nsplit), kCtxPch);
+    const int n_begin = split * nps, n_end = min(N, n_begin + nps);
+    const float *kr = k + (size_t)b * kv_bs + (size_t)d * N;
+    const float m = kmax[(size_t)b * C + d];
+    for (int e = threadIdx.x; e < C; e += blockDim.x) {
+        const float *vr = v + (size_t)b * kv_bs + (size_t)e * N;
+        float s = 0.f, z = 0.f;
+        for (int n = n_begin; n < n_end; ++n) {
+            const float p = expf(kr[n] - m);
+            s += p * vr[n];
+            z += p;
+        }
+        S[(((size_t)b * nsplit + split) * C + d) * C + e] = s;
+        if (e == 0) Zp[((size_t)b * nsplit + split) * C + d] = z;
     }
 }
 
 hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
-                              const float *kmax, float *S, int nsplit, int B, hipStream_t st) {
+                              const float *kmax, float *S, float *Zp, int nsplit, int B,
+                              hipStream_t st) {
+    if (N & 3) {                                 // 16-byte DMA pieces need N % 4 == 0
+        hipLaunchKernelGGL(ctx_partial_generic_kernel, dim3(C, nsplit, B), dim3(C >= 256 ? 256 : 64), 0, st,
+                           k, v, kv_bs, C, N, kmax, S, Zp, nsplit);
+        return hipGetLastError();
+    }
     const int tiles = ceil_div(C, 64);
-    const size_t lds = sizeof(float) * 4 * 64 * 64;      // reduction buffer (>= staging tiles)
+    const size_t lds = sizeof(float) * 4 * 64 * 64;      // ring == reduction buffer
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)ctx_partial_kernel,
@@ -356,7 +424,7 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
         attr_set = true;
     }
     hipLaunchKernelGGL(ctx_partial_kernel, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
-                       kv_bs, C, N, kmax, S, nsplit, tiles);
+                       kv_bs, C, N, kmax, S, Zp, nsplit, tiles);
     return hipGetLastError();
 }
 
@@ -370,7 +438,8 @@ __global__ void __launch_bounds__(256) ctx_reduce_kernel(const float *S, const f
         for (int e = threadIdx.x; e < COP; e += blockDim.x) row[e] = 0.f;
         return;
     }
-    const float z = ksum[(size_t)b * C + d];
+    float z = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) z += ksum[((size_t)b * nsplit + sp) * C + d];
     for (int e = threadIdx.x; e < COP; e += blockDim.x) {
         float s = 0.f;
         if (e < C) {
@@ -397,43 +466,65 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 //   R1: T1[b][d][c]  = sum_e (sum_split S[b][split][d][e]) / ksum[b][d] * WoT[e][c]
 //   R2: Mt[b][ci][c] = scale * sum_d WqT[ci][d] * T1[b][d][c]     (packed 1x1 weights [Cin_pad][COP])
 // ---------------------------------------------------------------------------------------------
+constexpr int kFoldRows = 8;     // rows per workgroup: each WoT / T1 element is reused 8x from registers
+
 __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *S, const float *ksum, int C,
                                                      int nsplit, const float *WoT, float *T1) {
-    extern __shared__ float row[];          // ctx[d][:] normalised
-    const int d = blockIdx.x, b = blockIdx.y;
-    const float z = ksum[(size_t)b * C + d];
-    for (int e = threadIdx.x; e < C; e += blockDim.x) {
+    extern __shared__ float rows[];         // [kFoldRows][C]: normalised ctx rows d0..d0+7
+    const int d0 = blockIdx.x * kFoldRows, b = blockIdx.y;
+    for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
+        const int r = idx / C, e = idx - r * C, d = d0 + r;
         float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += S[(((size_t)b * nsplit + sp) * C + d) * C + e];
-        row[e] = s / z;
+        if (d < C) {
+            float z = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                z += ksum[((size_t)b * nsplit + sp) * C + d];
+                s += S[(((size_t)b * nsplit + sp) * C + d) * C + e];
+            }
+            s /= z;
+        }
+        rows[idx] = s;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int e = 0; e < C; ++e) s += row[e] * WoT[(size_t)e * C + c];
-        T1[((size_t)b * C + d) * C + c] = s;
+        float acc[kFoldRows];
+#pragma unroll
+        for (int r = 0; r < kFoldRows; ++r) acc[r] = 0.f;
+        for (int e = 0; e < C; ++e) {
+            const float w = WoT[(size_t)e * C + c];
+#pragma unroll
+            for (int r = 0; r < kFoldRows; ++r) acc[r] += rows[r * C + e] * w;
+        }
+#pragma unroll
+        for (int r = 0; r < kFoldRows; ++r)
+            if (d0 + r < C) T1[((size_t)b * C + d0 + r) * C + c] = acc[r];
     }
 }
 
 __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const float *WqT, int C,
                                                      float scale, float *Mt, int Cin_pad, int COP) {
-    extern __shared__ float row[];          // WqT[ci][:]
-    const int ci = blockIdx.x, b = blockIdx.y;
-    float *out = Mt + ((size_t)b * Cin_pad + ci) * COP;
-    if (ci >= C) {
-        for (int c = threadIdx.x; c < COP; c += blockDim.x) out[c] = 0.f;
-        return;
+    extern __shared__ float rows[];         // [kFoldRows][C]: WqT rows ci0..ci0+7
+    const int ci0 = blockIdx.x * kFoldRows, b = blockIdx.y;
+    for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
+        const int r = idx / C, d = idx - r * C;
+        rows[idx] = (ci0 + r < C) ? WqT[(size_t)(ci0 + r) * C + d] : 0.f;
     }
-    for (int d = threadIdx.x; d < C; d += blockDim.x) row[d] = WqT[(size_t)ci * C + d];
     __syncthreads();
     for (int c = threadIdx.x; c < COP; c += blockDim.x) {
-        float s = 0.f;
+        float acc[kFoldRows];
+#pragma unroll
+        for (int r = 0; r < kFoldRows; ++r) acc[r] = 0.f;
         if (c < C) {
             const float *t = T1 + (size_t)b * C * C + c;
-            for (int d = 0; d < C; ++d) s += row[d] * t[(size_t)d * C];
-            s *= scale;
+            for (int d = 0; d < C; ++d) {
+                const float w = t[(size_t)d * C];
+#pragma unroll
+                for (int r = 0; r < kFoldRows; ++r) acc[r] += rows[r * C + d] * w;
+            }
         }
-        out[c] = s;
+#pragma unroll
+        for (int r = 0; r < kFoldRows; ++r)
+            if (ci0 + r < Cin_pad) Mt[((size_t)b * Cin_pad + ci0 + r) * COP + c] = acc[r] * scale;
     }
 }
 
@@ -460,10 +551,10 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
                            int COP, const float *ln_g, const float *ln_b, const float *b_out,
                            float *biasB, int B, hipStream_t st) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(ctx_r1_kernel, dim3(C, B), dim3(blk), sizeof(float) * C, st, S, ksum, C, nsplit,
-                       WoT, T1);
-    hipLaunchKernelGGL(ctx_r2_kernel, dim3(Cin_pad, B), dim3(blk), sizeof(float) * C, st, T1, WqT, C,
-                       scale, Mt, Cin_pad, COP);
+    hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
+                       sizeof(float) * kFoldRows * C, st, S, ksum, C, nsplit, WoT, T1);
+    hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),
+                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, Mt, Cin_pad, COP);
     hipLaunchKernelGGL(ctx_r3_kernel, dim3(B), dim3(blk), 0, st, Mt, ln_g, ln_b, b_out, biasB, C, Cin_pad,
                        COP);
     return hipGetLastError();

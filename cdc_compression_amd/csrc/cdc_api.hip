@@ -490,6 +490,8 @@ struct Builder {
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.C0 = s1 ? C0 : 0;
+        s.Win = W; s.nz = w.nz;
+        for (int z = 0; z < 4; ++z) s.pad_x[z] = w.transposed ? 1 - (z & 1) : pad_x;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
             s.Ho = (H + 2 * pad_y - w.KH) / w.stride + 1;
@@ -573,6 +575,7 @@ struct Builder {
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.Ho = H; s.Wo = W; s.B = B; s.lnmode = 0;
+        s.Win = W; s.pad_x[0] = w.pad;
         ConvPlan pf, pu;
         s.need_all_cout = true;
         if (!conv_make_plan(s, &pf)) return false;
@@ -674,18 +677,19 @@ struct Builder {
     Act attention(const AttnW &at, Act x, float *sm, float *sr) {
         if (rc) return Act();
         const int C = at.C, H = x.H, W = x.W, N = H * W;
-        const bool fold = at.WoT && N >= 4 * C && !getenv("CDC_NO_ATTN_FOLD");
+        const bool fold = at.WoT && N >= 16 * C && !getenv("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
         Act qkv = new_act(kvc, H, W);
         ConvOpts oq;                                   // LN(x) folded into the projection (LNMODE 2)
         oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_mode = 2;
         conv(fold ? at.kv : at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
         const float *kp = qkv.p + (size_t)(fold ? 0 : C) * N, *vp = kp + (size_t)C * N;
-        float *kmax = dalloc((size_t)B * C), *ksum = dalloc((size_t)B * C);
+        float *kmax = dalloc((size_t)B * C);
         const int tiles = ceil_div(C, 64);
         int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
         nsplit = std::min(nsplit, std::max(1, N / 64));
         float *S = dalloc((size_t)B * nsplit * C * C);
+        float *ksum = dalloc((size_t)B * nsplit * C);      // per-split partial sums of exp(k - max)
         const int Cin_pad = round_up(C, 16), COP = round_up(C, 32);
         float *ctxw = dalloc((size_t)B * Cin_pad * COP);
         float *T1 = fold ? dalloc((size_t)B * C * C) : nullptr;
@@ -707,7 +711,7 @@ struct Builder {
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
         cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1; cw.bias = nullptr;
         Act y = new_act(C, H, W);
-        dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * C},
+        dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
         if (fold) {
             // y = M' LN(x) + b_out + x with g folded into M' and (M' b_ln + b_out) as per-image shift
@@ -883,11 +887,11 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
         case Op::LN: HIP_TRY(h, ln_launch(op.ln, B, st)); break;
         case Op::TEMB: HIP_TRY(h, temb_launch(op.temb, B, st)); break;
         case Op::KSTATS:
-            HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, op.at.ksum, B, st));
+            HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, B, st));
             break;
         case Op::CTXP:
             HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
-                                          op.at.S, op.at.nsplit, B, st));
+                                          op.at.S, op.at.ksum, op.at.nsplit, B, st));
             break;
         case Op::CTXR:
             HIP_TRY(h, ctx_reduce_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale,

@@ -20,6 +20,8 @@ conv_kernel_fn conv_lookup_abl(int MB, int NPW, int abl);    // tuning aid (CDC_
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;
     int C0 = 0;          // channels of the first concat source (0: single source); KC must divide it
+    int Win = 0;         // input width and per-phase x padding: 16-byte input pieces need Win % 4 == 0
+    int nz = 1, pad_x[4] = {0, 0, 0, 0};
     int Ho, Wo;          // output extent (per phase for ConvTranspose)
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel
@@ -66,11 +68,12 @@ struct TembArgs {
 hipError_t temb_launch(const TembArgs &a, int B, hipStream_t st);
 
 // k-softmax statistics over the spatial axis (network_components.py:134): per (b, channel) row
-hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, float *ksum,
-                         int B, hipStream_t st);
+hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, int B,
+                         hipStream_t st);
 // S[b][split][d][e] = sum_{n in split} exp(k[d,n]-kmax[d]) * v[e,n]      (:135, unnormalised)
 hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
-                              const float *kmax, float *S, int nsplit, int B, hipStream_t st);
+                              const float *kmax, float *S, float *Zp, int nsplit, int B,
+                              hipStream_t st);
 // ctxw[b][d][e] = scale * sum_split S / ksum[d], written as per-image packed 1x1 weights
 // [Cin_pad][COP] (rows d >= C and cols e >= C zeroed)
 hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,

@@ -40,7 +40,8 @@ struct ConvArgs {
     // tiling
     int lognbw;                     // a 32-pixel N-block is (32>>lognbw) rows x (1<<lognbw) cols
     int tiles_x, tiles_y;
-    int PH, PW;                     // staged input patch: rows, cols
+    int PH, PW;                     // staged input patch: rows, row stride (floats)
+    int xvec, xshift[4];            // 16-byte input pieces: patch starts xshift[z] columns early
     unsigned magic_hw, magic_w;     // fast division by PH*PW and by PW (0 => divisor is 1)
     // epilogue
     const float *bias;              // [Cout] or null
@@ -62,6 +63,7 @@ struct ConvPlan {
     int groups;             // cout groups (gridDim.y)
     int KC, nchunk;
     int lognbw, tiles_x, tiles_y, PH, PW;
+    int xvec, xshift[4];
     size_t lds_bytes;
     int lnmode;
 };

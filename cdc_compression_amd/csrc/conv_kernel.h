@@ -106,12 +106,15 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     const int KC = P.KC;
     const int plane = PH * PW;
 
-    const int n_x = KC * plane;                       // staged input elements per chunk
+    // Input patch pieces: 4-byte (any geometry) or, when rows can be 16-byte aligned in global memory
+    // (W % 4 == 0: the patch is widened to start at a multiple of 4, P.xshift[z] columns early), 16-byte.
+    const int xv = P.xvec ? 4 : 1;
+    const int n_x = KC * plane / xv;                  // staged input pieces per chunk
     const int n_w4 = taps * KC * (COPT / 4);          // staged weight float4 per chunk
     const int xs = (n_x + nthr - 1) / nthr;           // DMA slots per thread
     const int ws = (n_w4 + nthr - 1) / nthr;
     const int w_floats = ws * nthr * 4;
-    const int buf_floats = w_floats + xs * nthr;
+    const int buf_floats = w_floats + xs * nthr * xv;
 
     // ---- chunk-invariant descriptors of this thread's input-patch slots --------------------------
     // xo = (c_local << 27) | (iy*W + ix) for an element inside the image, -1 for zero padding and for
@@ -127,12 +130,12 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
         if constexpr (LNLOAD) { xmean[i] = 0.f; xrstd[i] = 0.f; }
         if (i < xs) {
             if (e < (unsigned)n_x) {
-                const unsigned c = fdiv(e, P.magic_hw);
-                const unsigned rem = e - c * (unsigned)plane;
-                const unsigned r = fdiv(rem, P.magic_w);
-                const unsigned col = rem - r * (unsigned)PW;
-                const int iy = iy0 + (int)r, ix = ix0 + (int)col;
-                if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {
+                const unsigned c = fdiv(e, P.magic_hw);               // / (PH * PW / xv)
+                const unsigned rem = e - c * (unsigned)(plane / xv);
+                const unsigned r = fdiv(rem, P.magic_w);              // / (PW / xv)
+                const unsigned col = (rem - r * (unsigned)(PW / xv)) * xv;
+                const int iy = iy0 + (int)r, ix = ix0 - P.xshift[z] + (int)col;
+                if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {     // a 16-byte piece is all in or all out
                     xo[i] = (int)(c << 27) | (iy * P.W + ix);
                     if constexpr (LNLOAD) {
                         xmean[i] = P.ln_mean[(size_t)b * P.H * P.W + iy * P.W + ix];
@@ -141,8 +144,10 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
                 }
             }
             if (xo[i] < 0) {
-                smem[w_floats + e] = 0.f;
-                smem[buf_floats + w_floats + e] = 0.f;
+                for (int t = 0; t < xv; ++t) {
+                    smem[w_floats + e * xv + t] = 0.f;
+                    smem[buf_floats + w_floats + e * xv + t] = 0.f;
+                }
             }
         }
     }
@@ -177,7 +182,8 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
             if (i < xs && xo[i] >= 0) {
                 const unsigned c = (unsigned)min(xo[i] >> 27, ncm1);
                 const unsigned voff = (c * HW + (unsigned)(xo[i] & 0x7FFFFFF)) * 4u;
-                dma_b32_s(voff, xbase, xb_lds + (unsigned)(i * nthr + wave * 64) * 4u);
+                if (P.xvec) dma_b128_s(voff, xbase, xb_lds + (unsigned)(i * nthr + wave * 64) * 16u);
+                else dma_b32_s(voff, xbase, xb_lds + (unsigned)(i * nthr + wave * 64) * 4u);
             }
         }
     };
@@ -194,7 +200,7 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     const int j = lane & 31;
     const int pr = j >> P.lognbw, pc = j & (NBW - 1);
     const int a_lane = half * COPT + j;
-    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride;
+    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
     const int nb_stride = NBH * P.stride * PW;
 
     float pmean[LNMODE == 2 ? NPW : 1], prstd[LNMODE == 2 ? NPW : 1];

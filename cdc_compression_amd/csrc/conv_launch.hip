@@ -25,9 +25,9 @@ static conv_kernel_fn lookup(int MB, int NPW, int lnmode) {
 // workgroups share a CU's 160 KiB when the register budget allows it.
 static constexpr size_t kLdsSmall = 78 * 1024, kLdsBig = 150 * 1024;
 
-static size_t plan_lds(int taps, int kc, int COPT, int PH, int PW, int nthr) {
-    const int n_x = kc * PH * PW, n_w4 = taps * kc * (COPT / 4);
-    const size_t buf = (size_t)ceil_div(n_w4, nthr) * nthr * 4 + (size_t)ceil_div(n_x, nthr) * nthr;
+static size_t plan_lds(int taps, int kc, int COPT, int PH, int PW, int nthr, int xv) {
+    const int n_x = kc * PH * PW / xv, n_w4 = taps * kc * (COPT / 4);
+    const size_t buf = (size_t)ceil_div(n_w4, nthr) * nthr * 4 + (size_t)ceil_div(n_x, nthr) * nthr * xv;
     return std::max(sizeof(float) * 2 * buf, sizeof(float) * 4 * (size_t)COPT);
 }
 
@@ -42,9 +42,20 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     const int nthr = 64 * WN;
     const int TH = WN * NPW * NBH;
     const int PH = (TH - 1) * s.stride + s.KH;
-    const int PW = (NBW - 1) * s.stride + s.KW;
+    int PW = (NBW - 1) * s.stride + s.KW;
     const int taps = s.KH * s.KW;
     const int COPT = MB * 32;
+    // 16-byte input pieces: tile origins are multiples of 4 columns, so the patch of phase z starts
+    // (-pad_x[z]) mod 4 columns after a 16-byte boundary; widen it to start ON the boundary.
+    const bool xvec = s.Win > 0 && (s.Win & 3) == 0 && s.lnmode != 1 && ((NBW * s.stride) & 3) == 0 &&
+                      !getenv("CDC_NO_XVEC");
+    int xshift[4] = {0, 0, 0, 0};
+    if (xvec) {
+        int mx = 0;
+        for (int z = 0; z < s.nz; ++z) { xshift[z] = ((-s.pad_x[z]) % 4 + 4) % 4; mx = std::max(mx, xshift[z]); }
+        PW = round_up(mx + PW, 4);
+    }
+    const int xv = xvec ? 4 : 1;
     // prefer a footprint that lets two workgroups share a CU (when registers allow it), then the
     // largest K-chunk; fall back to one workgroup per CU
     int KC = 0;
@@ -54,8 +65,8 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
             if (force_kc && kc != force_kc) continue;
             if (s.C0 % kc) continue;                              // a chunk never straddles the concat seam
             if (kc > round_up(s.Cin, 4) && kc > 4) continue;      // do not over-pad tiny Cin
-            const bool x_ok = kc * PH * PW <= kXS * nthr;
-            if (x_ok && plan_lds(taps, kc, COPT, PH, PW, nthr) <= budget) { KC = kc; break; }
+            const bool x_ok = kc * PH * PW / xv <= kXS * nthr;
+            if (x_ok && plan_lds(taps, kc, COPT, PH, PW, nthr, xv) <= budget) { KC = kc; break; }
         }
         if (KC) break;
     }
@@ -68,7 +79,9 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     p->tiles_x = ceil_div(s.Wo, NBW);
     p->tiles_y = ceil_div(s.Ho, TH);
     p->PH = PH; p->PW = PW;
-    p->lds_bytes = plan_lds(taps, KC, COPT, PH, PW, nthr);
+    p->xvec = xvec ? 1 : 0;
+    for (int z = 0; z < 4; ++z) p->xshift[z] = xshift[z];
+    p->lds_bytes = plan_lds(taps, KC, COPT, PH, PW, nthr, xv);
     p->lnmode = s.lnmode;
     return true;
 }
@@ -124,8 +137,11 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.tiles_x = p.tiles_x;
     a.tiles_y = p.tiles_y;
     a.PH = p.PH; a.PW = p.PW;
-    a.magic_hw = magic_of((unsigned)(p.PH * p.PW));
-    a.magic_w = magic_of((unsigned)p.PW);
+    a.xvec = p.xvec;
+    for (int z = 0; z < 4; ++z) a.xshift[z] = p.xshift[z];
+    const int xv = p.xvec ? 4 : 1;
+    a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
+    a.magic_w = magic_of((unsigned)(p.PW / xv));
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
     conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnmode);
     if (ablate && p.lnmode == 0)
