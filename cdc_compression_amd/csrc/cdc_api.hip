@@ -40,6 +40,8 @@ struct ConvW {                    // packed convolution weights (device)
     int Cin_pad = 0, COP = 0, nz = 1;
     float *wp = nullptr, *bias = nullptr;
     long long w_zs = 0, w_bs = 0;
+    unsigned short *wsp = nullptr;   // three-plane bf16 form for conv_split_kernel (k x k, Cin >= 16)
+    long long wsp_zs = 0;
 };
 
 struct Act { float *p = nullptr; int C = 0, H = 0, W = 0;
@@ -297,6 +299,37 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int CoutF, int C
     }
     int rc = upload(h, packed.data(), packed.size(), &cw->wp, pool);
     if (rc) return rc;
+    cw->wsp = nullptr;
+    if (cw->KH * cw->KW > 1 && Cin >= 16 && !getenv("CDC_NO_SPLIT")) {
+        // exact three-way bf16 split (truncation): w = w1 + w2 + w3, laid out in MFMA A-operand order
+        // [z][tap][Cin_pad/16][plane][k-half][COP][8 cin]
+        const int taps = cw->KH * cw->KW, nc16 = cw->Cin_pad / 16;
+        const size_t per_z = (size_t)taps * nc16 * 6 * cw->COP * 8;
+        std::vector<unsigned short> sp(per_z * cw->nz, 0);
+        for (int z = 0; z < cw->nz; ++z)
+            for (int t = 0; t < taps; ++t)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int co = 0; co < Cout; ++co) {
+                        const float v = packed[(size_t)z * (size_t)taps * cw->Cin_pad * cw->COP +
+                                               ((size_t)t * cw->Cin_pad + ci) * cw->COP + co];
+                        uint32_t u; memcpy(&u, &v, 4);
+                        const uint32_t h1 = u & 0xFFFF0000u; float f1; memcpy(&f1, &h1, 4);
+                        const float r = v - f1; uint32_t ur; memcpy(&ur, &r, 4);
+                        const uint32_t h2 = ur & 0xFFFF0000u; float f2; memcpy(&f2, &h2, 4);
+                        const float r2 = r - f2; uint32_t h3; memcpy(&h3, &r2, 4);
+                        const uint32_t parts[3] = {h1, h2, h3};
+                        const int c16 = ci >> 4, kg = (ci >> 3) & 1, q = ci & 7;
+                        for (int pl = 0; pl < 3; ++pl)
+                            sp[(size_t)z * per_z +
+                               ((((size_t)t * nc16 + c16) * 6 + pl * 2 + kg) * cw->COP + co) * 8 + q] =
+                                (unsigned short)(parts[pl] >> 16);
+                    }
+        float *dsp = nullptr;
+        if ((rc = upload(h, reinterpret_cast<const float *>(sp.data()), (sp.size() + 1) / 2, &dsp, pool)))
+            return rc;
+        cw->wsp = reinterpret_cast<unsigned short *>(dsp);
+        cw->wsp_zs = (long long)per_z;
+    }
     cw->bias = nullptr;
     if (bias) rc = upload(h, bias + co0, Cout, &cw->bias, pool);
     return rc;
@@ -425,9 +458,10 @@ struct Builder {
         char buf[160];
         const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy"};
         if (op.kind == Op::CONV)
-            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d%s%s%s", op.conv.KH,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.conv.ep_g ? " LN" : "",
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.split ? " SPLIT" : "",
+                     op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
@@ -491,6 +525,7 @@ struct Builder {
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.C0 = s1 ? C0 : 0;
         s.Win = W; s.nz = w.nz;
+        s.allow_split = w.wsp != nullptr;
         for (int z = 0; z < 4; ++z) s.pad_x[z] = w.transposed ? 1 - (z & 1) : pad_x;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
@@ -521,6 +556,7 @@ struct Builder {
         a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
         a.ln_mean = o.pre_mean; a.ln_rstd = o.pre_rstd; a.ln_g = o.pre_g; a.ln_b = o.pre_b;
         a.wp = w.wp; a.w_bs = o.w_bs; a.w_zs = w.w_zs;
+        a.wsp = w.wsp; a.wsp_zs = w.wsp_zs;
         a.KH = w.KH; a.KW = w.KW; a.stride = w.stride;
         a.Cin_pad = w.Cin_pad; a.COP = w.COP; a.Cout = w.Cout;
         a.out = out; a.out_bs = out_bs;

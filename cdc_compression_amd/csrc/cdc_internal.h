@@ -16,12 +16,14 @@ conv_kernel_fn conv_lookup_a(int MB, int NPW, int lnmode);   // MB 1..3
 conv_kernel_fn conv_lookup_b(int MB, int NPW, int lnmode);   // MB 4..6
 conv_kernel_fn conv_lookup_c(int MB, int NPW, int lnmode);   // MB 7..12
 conv_kernel_fn conv_lookup_abl(int MB, int NPW, int abl);    // tuning aid (CDC_ABLATE)
+conv_kernel_fn conv_lookup_split(int MB, int NPW);           // conv_split_kernel.h
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;
     int C0 = 0;          // channels of the first concat source (0: single source); KC must divide it
     int Win = 0;         // input width and per-phase x padding: 16-byte input pieces need Win % 4 == 0
     int nz = 1, pad_x[4] = {0, 0, 0, 0};
+    bool allow_split = false;   // split-bf16 weights exist for this layer
     int Ho, Wo;          // output extent (per phase for ConvTranspose)
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel

@@ -29,6 +29,9 @@ struct ConvArgs {
     // packed weights [z][taps][Cin_pad][COP] (zero padded); w_bs = per-image stride (0 = shared)
     const float *wp;
     long long w_bs, w_zs;
+    // split-bf16 form (conv_split_kernel.h): [z][tap][Cin_pad/16][plane 3][k-half 2][COP][8] bf16
+    const unsigned short *wsp;
+    long long wsp_zs;
     int KH, KW, stride;
     int pad_y[4], pad_x[4];         // per blockIdx.z (ConvTranspose phases); z = 0 otherwise
     int KC, logKC, nchunk, Cin_pad, COP, Cout;
@@ -66,6 +69,7 @@ struct ConvPlan {
     int xvec, xshift[4];
     size_t lds_bytes;
     int lnmode;
+    int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 
 }  // namespace cdc

@@ -59,6 +59,183 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) {
 
 constexpr int conv_min_waves(int MB, int NPW) { return MB * NPW <= 8 ? 2 : 1; }
 
+struct TileGeom {      // where this workgroup / lane sits (shared by the kernel variants' epilogue)
+    int tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH;
+};
+
+// Fused epilogue on the MFMA accumulators (C/D layout of the 32x32 forms: lane = pixel l&31, register
+// r = channel (r&3) + 8(r>>2) + 4(l>>5)): bias, hoisted partial sums, channel LayerNorm (+ReLU),
+// time-embedding shift, residual add, LN statistics of the result, NCHW store.
+template <int MB, int NPW, int LNMODE, int ABL>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom &g, f32x16 (&acc)[MB][NPW],
+                                              float *smem, const float *prstd) {
+    constexpr int COPT = MB * 32;
+    const int tid = g.tid, nthr = g.nthr, wave = g.wave, half = g.half, pr = g.pr, pc = g.pc;
+    const int b = g.b, z = g.z, cog = g.cog, oy0 = g.oy0, ox0 = g.ox0, NBH = g.NBH;
+    // ---- epilogue -------------------------------------------------------------------------------
+    __syncthreads();
+    float *ep = smem;   // [4][COPT]: bias, ln g, ln b, shift
+    for (int i = tid; i < COPT; i += nthr) {
+        const int co = cog * COPT + i;
+        const bool ok = co < P.Cout;
+        ep[i] = (ok && P.bias) ? P.bias[co] : 0.f;
+        ep[COPT + i] = (ok && P.ep_g) ? P.ep_g[co] : 0.f;
+        ep[2 * COPT + i] = (ok && P.ep_b) ? P.ep_b[co] : 0.f;
+        ep[3 * COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
+    }
+    __syncthreads();
+
+    // Channel masks are only needed in the last, partially filled 32-channel block of a cout
+    // group; the LayerNorm / statistics paths require Cout % 32 == 0 (host-enforced), so they
+    // carry no masks at all.
+    const float inv_c = 1.0f / (float)P.Cout;
+    const int cobase = cog * COPT;
+    const int nvalid = P.Cout - cobase;     // channels of this group that exist
+    const float *epl = ep + 4 * half;       // lane's channel = const + 4*half
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int oy = oy0 + (wave * NPW + n) * NBH + pr;
+        const int ox = ox0 + pc;
+        const bool valid = (oy < P.Ho) && (ox < P.Wo);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (LNMODE == 2) acc[m][n][r] *= prstd[n];
+                acc[m][n][r] += epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+            }
+        const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
+        if (P.pre_add) {
+            // hoisted partial sums (context half of a concatenated input), same addressing as out
+            const float *pp = P.pre_add + (size_t)b * P.out_bs + pix +
+                              (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m * 32 + 32 <= nvalid) {
+                    if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[m][n][r] += pp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs];
+                    }
+                } else if (m * 32 < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (valid && ci + 4 * half < nvalid) acc[m][n][r] += pp[(size_t)ci * P.out_cs];
+                    }
+                }
+            }
+        }
+        if (P.ep_g) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+            s += __shfl_xor(s, 32);
+            const float mean = s * inv_c;
+            float q = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[m][n][r] - mean;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32);
+            const float rinv = 1.0f / sqrtf(q * inv_c + P.eps);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                    acc[m][n][r] = (acc[m][n][r] - mean) * rinv * epl[COPT + ci] + epl[2 * COPT + ci];
+                }
+        }
+        if (P.relu) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], 0.f);
+        }
+        if (P.shift) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
+        }
+        if (P.resid) {
+            const float *rp = P.resid + (size_t)b * P.resid_bs + pix +
+                              (size_t)(cobase + 4 * half) * P.resid_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m * 32 + 32 <= nvalid) {
+                    if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[m][n][r] += rp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.resid_cs];
+                    }
+                } else if (m * 32 < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (valid && ci + 4 * half < nvalid) acc[m][n][r] += rp[(size_t)ci * P.resid_cs];
+                    }
+                }
+            }
+        }
+        if (P.stat_mean) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+            s += __shfl_xor(s, 32);
+            const float mean = s * inv_c;
+            float q = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[m][n][r] - mean;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32);
+            if (valid && half == 0) {     // one plane of the output tensor (phase-aware addressing)
+                P.stat_mean[(size_t)b * P.out_cs + pix] = mean;
+                P.stat_rstd[(size_t)b * P.out_cs + pix] = 1.0f / sqrtf(q * inv_c + P.eps);
+            }
+        }
+        if constexpr ((ABL & 8) != 0) {          // timing aid: one store per lane instead of MB*16
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[m][n][r];
+            if (valid) P.out[(size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs] = t;
+            continue;
+        }
+        float *op = P.out + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m * 32 + 32 <= nvalid) {
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
+                }
+            } else if (m * 32 < nvalid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (valid && ci + 4 * half < nvalid) op[(size_t)ci * P.out_cs] = acc[m][n][r];
+                }
+            }
+        }
+    }
+}
+
 // Workgroup = WN waves (blockDim.x = 64*WN).  Wave w owns NPW N-blocks (32 pixels each) stacked
 // vertically and all MB*32 output channels of the workgroup's cout group.
 //
@@ -280,167 +457,8 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
-    __syncthreads();
-    float *ep = smem;   // [4][COPT]: bias, ln g, ln b, shift
-    for (int i = tid; i < COPT; i += nthr) {
-        const int co = cog * COPT + i;
-        const bool ok = co < P.Cout;
-        ep[i] = (ok && P.bias) ? P.bias[co] : 0.f;
-        ep[COPT + i] = (ok && P.ep_g) ? P.ep_g[co] : 0.f;
-        ep[2 * COPT + i] = (ok && P.ep_b) ? P.ep_b[co] : 0.f;
-        ep[3 * COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
-    }
-    __syncthreads();
-
-    // Channel masks are only needed in the last, partially filled 32-channel block of a cout
-    // group; the LayerNorm / statistics paths require Cout % 32 == 0 (host-enforced), so they
-    // carry no masks at all.
-    const float inv_c = 1.0f / (float)P.Cout;
-    const int cobase = cog * COPT;
-    const int nvalid = P.Cout - cobase;     // channels of this group that exist
-    const float *epl = ep + 4 * half;       // lane's channel = const + 4*half
-#pragma unroll
-    for (int n = 0; n < NPW; ++n) {
-        const int oy = oy0 + (wave * NPW + n) * NBH + pr;
-        const int ox = ox0 + pc;
-        const bool valid = (oy < P.Ho) && (ox < P.Wo);
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (LNMODE == 2) acc[m][n][r] *= prstd[n];
-                acc[m][n][r] += epl[m * 32 + (r & 3) + 8 * (r >> 2)];
-            }
-        const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
-        if (P.pre_add) {
-            // hoisted partial sums (context half of a concatenated input), same addressing as out
-            const float *pp = P.pre_add + (size_t)b * P.out_bs + pix +
-                              (size_t)(cobase + 4 * half) * P.out_cs;
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (m * 32 + 32 <= nvalid) {
-                    if (valid) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[m][n][r] += pp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs];
-                    }
-                } else if (m * 32 < nvalid) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
-                        if (valid && ci + 4 * half < nvalid) acc[m][n][r] += pp[(size_t)ci * P.out_cs];
-                    }
-                }
-            }
-        }
-        if (P.ep_g) {
-            float s = 0.f;
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[m][n][r];
-            s += __shfl_xor(s, 32);
-            const float mean = s * inv_c;
-            float q = 0.f;
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = acc[m][n][r] - mean;
-                    q += d * d;
-                }
-            q += __shfl_xor(q, 32);
-            const float rinv = 1.0f / sqrtf(q * inv_c + P.eps);
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
-                    acc[m][n][r] = (acc[m][n][r] - mean) * rinv * epl[COPT + ci] + epl[2 * COPT + ci];
-                }
-        }
-        if (P.relu) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], 0.f);
-        }
-        if (P.shift) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
-        }
-        if (P.resid) {
-            const float *rp = P.resid + (size_t)b * P.resid_bs + pix +
-                              (size_t)(cobase + 4 * half) * P.resid_cs;
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (m * 32 + 32 <= nvalid) {
-                    if (valid) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[m][n][r] += rp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.resid_cs];
-                    }
-                } else if (m * 32 < nvalid) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
-                        if (valid && ci + 4 * half < nvalid) acc[m][n][r] += rp[(size_t)ci * P.resid_cs];
-                    }
-                }
-            }
-        }
-        if (P.stat_mean) {
-            float s = 0.f;
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[m][n][r];
-            s += __shfl_xor(s, 32);
-            const float mean = s * inv_c;
-            float q = 0.f;
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = acc[m][n][r] - mean;
-                    q += d * d;
-                }
-            q += __shfl_xor(q, 32);
-            if (valid && half == 0) {     // one plane of the output tensor (phase-aware addressing)
-                P.stat_mean[(size_t)b * P.out_cs + pix] = mean;
-                P.stat_rstd[(size_t)b * P.out_cs + pix] = 1.0f / sqrtf(q * inv_c + P.eps);
-            }
-        }
-        if constexpr ((ABL & 8) != 0) {          // timing aid: one store per lane instead of MB*16
-            float t = 0.f;
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[m][n][r];
-            if (valid) P.out[(size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs] = t;
-            continue;
-        }
-        float *op = P.out + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if (m * 32 + 32 <= nvalid) {
-                if (valid) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
-                }
-            } else if (m * 32 < nvalid) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
-                    if (valid && ci + 4 * half < nvalid) op[(size_t)ci * P.out_cs] = acc[m][n][r];
-                }
-            }
-        }
-    }
+    const TileGeom geom{tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH};
+    conv_epilogue<MB, NPW, LNMODE, ABL>(P, geom, acc, smem, prstd);
 }
 
 typedef void (*conv_kernel_fn)(const ConvArgs);

@@ -83,6 +83,43 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     for (int z = 0; z < 4; ++z) p->xshift[z] = xshift[z];
     p->lds_bytes = plan_lds(taps, KC, COPT, PH, PW, nthr, xv);
     p->lnmode = s.lnmode;
+    p->split = 0;
+    return true;
+}
+
+// Split-bf16 kernel: 16-channel chunks, one workgroup per CU; LDS = split patch (96 B/position) +
+// fp32 landing area (64 B/position) + two weight-row stages.
+static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p) {
+    const int nblocks = ceil_div(s.Cout, 32);
+    if (nblocks % MB || !conv_lookup_split(MB, NPW)) return false;
+    const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
+    const int nb_rows = ceil_div(s.Ho, NBH);
+    int WN = std::min(4, ceil_div(nb_rows, NPW));
+    if (WN == 3) WN = 4;
+    const int nthr = 64 * WN;
+    const int TH = WN * NPW * NBH;
+    const int PH = (TH - 1) * s.stride + s.KH;
+    int PW = (NBW - 1) * s.stride + s.KW;
+    int xshift[4] = {0, 0, 0, 0}, mx = 0;
+    for (int z = 0; z < s.nz; ++z) { xshift[z] = ((-s.pad_x[z]) % 4 + 4) % 4; mx = std::max(mx, xshift[z]); }
+    PW = round_up(mx + PW, 4);
+    const int plane = PH * PW, COPT = MB * 32;
+    if (4 * plane > kXS * nthr) return false;
+    const size_t lds = sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);
+    if (lds > 160 * 1024) return false;
+    p->MB = MB; p->NPW = NPW; p->WN = WN;
+    p->groups = nblocks / MB;
+    p->KC = 16;
+    p->nchunk = ceil_div(s.Cin, 16);
+    p->lognbw = lognbw;
+    p->tiles_x = ceil_div(s.Wo, NBW);
+    p->tiles_y = ceil_div(s.Ho, TH);
+    p->PH = PH; p->PW = PW;
+    p->xvec = 1;
+    for (int z = 0; z < 4; ++z) p->xshift[z] = xshift[z];
+    p->lds_bytes = std::max(lds, sizeof(float) * 4 * (size_t)COPT);
+    p->lnmode = 0;
+    p->split = 1;
     return true;
 }
 
@@ -105,6 +142,31 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     // tuning aid: CDC_PLAN="MB,NPW,KC" (0 = free) restricts the candidates
     int f_mb = 0, f_npw = 0, f_kc = 0;
     if (const char *e = getenv("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
+    // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
+    // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
+    const bool split_ok = s.allow_split && s.lnmode == 0 && s.KH * s.KW > 1 && s.Cin >= 16 && (s.C0 % 16) == 0 &&
+                          s.Win > 0 && (s.Win & 3) == 0 && (((1 << lognbw) * s.stride) & 3) == 0 &&
+                          !getenv("CDC_NO_SPLIT");
+    if (split_ok) {
+        for (int MB : mbs) {
+            if (f_mb && !s.need_all_cout && MB != f_mb) continue;
+            for (int NPW : {4, 2, 1}) {
+                if (MB * NPW > 8 || MB > 6) continue;
+                if (NPW > 1 && NPW > nb_rows) continue;
+                if (f_npw && NPW != f_npw) continue;
+                ConvPlan p;
+                p.split = 0;
+                if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
+                const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups * s.nz;
+                const double fill = std::min(1.0, wgs / 256.0);
+                const double reuse = (double)(MB * NPW) / (MB + NPW);
+                const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0));
+                if (score > best_score) { best_score = score; best = p; }
+            }
+            if (s.need_all_cout) break;
+        }
+        if (best_score >= 0) { *plan = best; return true; }
+    }
     for (int MB : mbs) {
         if (f_mb && !s.need_all_cout && MB != f_mb) continue;
         for (int NPW : {4, 2, 1}) {
@@ -112,12 +174,12 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
             if (NPW > 1 && NPW > nb_rows) continue;
             if (f_npw && NPW != f_npw) continue;
             ConvPlan p;
+            p.split = 0;
             if (!try_plan(s, MB, NPW, lognbw, &p, f_kc)) continue;
-            // score: prefer register blocking (fewer LDS reads per MFMA) but keep the chip filled
-            const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups;
-            const double fill = std::min(1.0, wgs * p.WN / (256.0 * 4.0));
             // measured (tools/gpu_conv_tune.py): register blocking matters more than the chunk depth
             // (MB2/NPW4/KC4 99 TF vs MB2/NPW2/KC8 91 TF; MB4/NPW2/KC4 103 TF vs KC8 with one WG/CU 91 TF)
+            const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups;
+            const double fill = std::min(1.0, wgs * p.WN / (256.0 * 4.0));
             const double reuse = (double)(MB * NPW) / (MB + NPW);
             const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0));
             if (score > best_score) { best_score = score; best = p; }
@@ -143,8 +205,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
-    conv_kernel_fn fn = lookup(p.MB, p.NPW, p.lnmode);
-    if (ablate && p.lnmode == 0)
+    conv_kernel_fn fn = p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode);
+    if (ablate && p.lnmode == 0 && !p.split)
         if (conv_kernel_fn f2 = conv_lookup_abl(p.MB, p.NPW, ablate)) fn = f2;
     if (!fn) return hipErrorInvalidValue;
     if (p.lds_bytes > 64 * 1024) {

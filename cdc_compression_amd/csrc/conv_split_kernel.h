@@ -1,0 +1,218 @@
+// conv_split_kernel.h -- k x k convolution with fp32-exact products on the bf16 matrix cores.
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  Every fp32 number is EXACTLY the sum of
+// three bf16 numbers (a = a1 + a2 + a3: top / middle / bottom 8 significant bits, obtained by
+// truncation, so no rounding is involved), and a bf16 x bf16 product is exact in fp32.  Hence
+//      a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1) + O(2^-24 |ab|)
+// is six v_mfma_f32_32x32x16_bf16 per 16-deep K step instead of eight 32x32x2_f32: 2.67x the matrix
+// rate at fp32-class accuracy (measured end to end against a float64 oracle: 1.9e-6 vs 8e-6 for plain
+// fp32; the dropped terms a2b3 + a3b2 + a3b3 are below the fp32 rounding of the running sum).
+//
+// Tensors stay float32 NCHW in HBM.  Per 16-channel chunk the haloed input patch lands in LDS as fp32
+// (16-byte LDS-DMA, same scheme as conv_kernel.h), is split by the workgroup into three bf16 planes in
+// MFMA B-operand order [plane][k-half][row][col][8 channels] (one ds_read_b128 per operand), and the
+// pre-split weights [tap][chunk][plane][k-half][cout][8 cin] stream in one kernel row (KW taps) at a
+// time through a two-stage LDS ring.  Accumulators, tiling, epilogue: as in conv_kernel.h.
+#pragma once
+#include "conv_kernel.h"
+
+namespace cdc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// a -> (hi, mid, lo) as fp32 bit patterns whose low 16 bits are zero; exact: a == hi + mid + lo
+__device__ __forceinline__ void split3(float a, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(a) & 0xFFFF0000u;
+    const float r = a - __uint_as_float(h);
+    m = __float_as_uint(r) & 0xFFFF0000u;
+    l = __float_as_uint(r - __uint_as_float(m));          // <= 8 significant bits: already a bf16
+}
+
+template <int MB, int NPW>
+__global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int COPT = MB * 32;
+    constexpr int KC = 16;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WN = nthr >> 6;
+    const int z = blockIdx.z;
+    const int cog = blockIdx.y;
+
+    int bid = blockIdx.x;
+    const int tx = bid % P.tiles_x;
+    bid /= P.tiles_x;
+    const int ty = bid % P.tiles_y;
+    const int b = bid / P.tiles_y;
+
+    const int NBW = 1 << P.lognbw;
+    const int NBH = 32 >> P.lognbw;
+    const int TH = WN * NPW * NBH;
+    const int oy0 = ty * TH, ox0 = tx * NBW;
+    const int iy0 = oy0 * P.stride - P.pad_y[z];
+    const int ix0 = ox0 * P.stride - P.pad_x[z];
+    const int PH = P.PH, PW = P.PW;                   // PW: 16-byte aligned row stride (floats)
+    const int plane = PH * PW;
+    const int taps = P.KH * P.KW;
+    const int nc16 = P.Cin_pad >> 4;
+
+    // LDS carve (float units): xc = split patch (3 planes x 2 k-halves x plane x 16 B),
+    // xs = fp32 landing area (16 channels x plane), w = 2 stages x KW taps x 6 x COPT x 16 B
+    const int xc_floats = 24 * plane, xs_floats = 16 * plane, wst_floats = P.KW * 24 * COPT;
+    float *xc = smem;
+    float *xs = smem + xc_floats;
+    float *wl = xs + xs_floats;
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned xs_lds = smem_lds + (unsigned)xc_floats * 4u;
+    const unsigned wl_lds = xs_lds + (unsigned)xs_floats * 4u;
+
+    // ---- input patch descriptors: 16-byte pieces (4 columns of one channel row) --------------------
+    const int n_x = 4 * plane;                        // pieces per chunk (16 ch * plane / 4)
+    const int xsl = (n_x + nthr - 1) / nthr;
+    int xo[kXS];
+#pragma unroll
+    for (int i = 0; i < kXS; ++i) {
+        const unsigned e = tid + i * nthr;
+        xo[i] = -1;
+        if (i < xsl) {
+            if (e < (unsigned)n_x) {
+                const unsigned c = fdiv(e, P.magic_hw);               // / (plane / 4)
+                const unsigned rem = e - c * (unsigned)(plane / 4);
+                const unsigned r = fdiv(rem, P.magic_w);              // / (PW / 4)
+                const unsigned col = (rem - r * (unsigned)(PW / 4)) * 4;
+                const int iy = iy0 + (int)r, ix = ix0 - P.xshift[z] + (int)col;
+                if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) xo[i] = (int)(c << 27) | (iy * P.W + ix);
+            }
+            if (xo[i] < 0 && e < (unsigned)n_x)
+                *reinterpret_cast<float4 *>(xs + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const unsigned HW = (unsigned)(P.H * P.W);
+    const float *s0 = P.src0 + (size_t)b * P.src0_bs;
+    const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
+
+    auto issue_x = [&](int chunk) {
+        const int cbase = chunk * KC;
+        const float *xbase = uniform_ptr(cbase < P.C0 ? s0 + (size_t)cbase * HW
+                                                      : s1 + (size_t)(cbase - P.C0) * HW);
+        const int ncm1 = min(KC, P.Cin - cbase) - 1;
+#pragma unroll
+        for (int i = 0; i < kXS; ++i) {
+            if (i < xsl && xo[i] >= 0) {
+                const unsigned c = (unsigned)min(xo[i] >> 27, ncm1);
+                const unsigned voff = (c * HW + (unsigned)(xo[i] & 0x7FFFFFF)) * 4u;
+                dma_b128_s(voff, xbase, xs_lds + (unsigned)(i * nthr + wave * 64) * 16u);
+            }
+        }
+    };
+    // weights of kernel row `ky`, chunk `chunk`: [KW taps][3 planes][2 k-halves][COPT] 16-byte pieces
+    const int n_w = P.KW * 6 * COPT;
+    const int wsl = (n_w + nthr - 1) / nthr;
+    const unsigned short *wsrc = P.wsp + (size_t)z * P.wsp_zs + (size_t)cog * COPT * 8;
+    auto issue_w = [&](int ky, int chunk, int stage) {
+        const unsigned short *base = wsrc + ((size_t)(ky * P.KW) * nc16 + chunk) * 6 * P.COP * 8;
+        const float *wbase = uniform_ptr(reinterpret_cast<const float *>(base));
+        for (int i = 0; i < wsl; ++i) {
+            const int e = tid + i * nthr;
+            if (e < n_w) {
+                const int t = e / (6 * COPT);
+                const int rem = e - t * 6 * COPT;
+                const int pk = rem / COPT, co = rem - pk * COPT;
+                const unsigned voff = (unsigned)(((t * nc16) * 6 + pk) * P.COP + co) * 16u;
+                dma_b128_s(voff, wbase, wl_lds + (unsigned)(stage * wst_floats) * 4u +
+                                            (unsigned)(i * nthr + wave * 64) * 16u);
+            }
+        }
+    };
+
+    f32x16 acc[MB][NPW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int half = lane >> 5;
+    const int j = lane & 31;
+    const int pr = j >> P.lognbw, pc = j & (NBW - 1);
+    // B operand (16 B units): ((plane_p*2 + half) * PH*PW + row*PW + col); A: ((tap*6 + p*2 + half)*COPT + cout)
+    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
+    const int nb_stride = NBH * P.stride * PW;
+    const int a_lane = half * COPT + j;
+
+    issue_x(0);
+    issue_w(0, 0, 0);
+    int wstage = 0;
+    for (int chunk = 0; chunk < nc16; ++chunk) {
+        dma_wait();
+        __syncthreads();                    // fp32 patch of `chunk` (and the first weight row) landed
+        // ---- split the patch into three bf16 planes, 8 channels per 16-byte unit --------------------
+        for (int u = tid; u < 2 * plane; u += nthr) {
+            const int kg = u >= plane ? 1 : 0;
+            const int rc = u - kg * plane;
+            const float *src = xs + (kg * 8) * plane + rc;
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) split3(src[q * plane], hh[q], mm[q], ll[q]);
+            uint4 vh, vm, vl;
+            vh.x = (hh[0] >> 16) | hh[1]; vh.y = (hh[2] >> 16) | hh[3];
+            vh.z = (hh[4] >> 16) | hh[5]; vh.w = (hh[6] >> 16) | hh[7];
+            vm.x = (mm[0] >> 16) | mm[1]; vm.y = (mm[2] >> 16) | mm[3];
+            vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
+            vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
+            vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
+            uint4 *dst = reinterpret_cast<uint4 *>(xc);
+            dst[(0 * 2 + kg) * plane + rc] = vh;
+            dst[(1 * 2 + kg) * plane + rc] = vm;
+            dst[(2 * 2 + kg) * plane + rc] = vl;
+        }
+        __syncthreads();                    // split patch ready; landing area free again
+        if (chunk + 1 < nc16) issue_x(chunk + 1);
+        for (int ky = 0; ky < P.KH; ++ky) {
+            // prefetch the next weight row (next ky, or row 0 of the next chunk) into the other stage
+            if (ky + 1 < P.KH) issue_w(ky + 1, chunk, wstage ^ 1);
+            else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
+            const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats);
+            const uint4 *xb = reinterpret_cast<const uint4 *>(xc);
+            for (int kx = 0; kx < P.KW; ++kx) {
+                bf16x8 A[3][MB], Bv[3][NPW];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const uint4 t = wa[(kx * 6 + p * 2) * COPT + a_lane + m * 32];
+                        A[p][m] = __builtin_bit_cast(bf16x8, t);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) {
+                        const uint4 t = xb[(p * 2) * plane + b_lane + ky * PW + kx + n * nb_stride];
+                        Bv[p][n] = __builtin_bit_cast(bf16x8, t);
+                    }
+                }
+                // six product terms, smallest first
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+                    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[term]][m], Bv[PB[term]][n],
+                                                                                acc[m][n], 0, 0, 0);
+                }
+            }
+            dma_wait();
+            __syncthreads();                // next weight row landed; this stage may be overwritten
+            wstage ^= 1;
+        }
+    }
+
+    const TileGeom geom{tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH};
+    conv_epilogue<MB, NPW, 0, 0>(P, geom, acc, smem, nullptr);
+}
+
+}  // namespace cdc
