@@ -460,7 +460,7 @@ struct Builder {
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.split ? " SPLIT" : "",
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.split == 2 ? " SPLIT2" : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)

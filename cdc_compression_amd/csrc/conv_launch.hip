@@ -104,8 +104,12 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     for (int z = 0; z < s.nz; ++z) { xshift[z] = ((-s.pad_x[z]) % 4 + 4) % 4; mx = std::max(mx, xshift[z]); }
     PW = round_up(mx + PW, 4);
     const int plane = PH * PW, COPT = MB * 32;
-    if (4 * plane > kXS * nthr) return false;
-    const size_t lds = sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);
+    // variant 2 (patch staged through registers, two workgroups per CU) when it fits
+    const size_t lds2 = sizeof(float) * ((size_t)24 * plane + (size_t)2 * s.KW * 24 * COPT);
+    const bool v2 = conv_lookup_split2(MB, NPW) && plane / 2 <= nthr && lds2 <= 80 * 1024 &&
+                    !getenv("CDC_NO_SPLIT2");
+    if (!v2 && 4 * plane > kXS * nthr) return false;
+    const size_t lds = v2 ? lds2 : sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);
     if (lds > 160 * 1024) return false;
     p->MB = MB; p->NPW = NPW; p->WN = WN;
     p->groups = nblocks / MB;
@@ -119,7 +123,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     for (int z = 0; z < 4; ++z) p->xshift[z] = xshift[z];
     p->lds_bytes = std::max(lds, sizeof(float) * 4 * (size_t)COPT);
     p->lnmode = 0;
-    p->split = 1;
+    p->split = v2 ? 2 : 1;
     return true;
 }
 
@@ -158,9 +162,10 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                 p.split = 0;
                 if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
                 const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups * s.nz;
-                const double fill = std::min(1.0, wgs / 256.0);
+                const double fill = std::min(1.0, wgs / (p.split == 2 ? 512.0 : 256.0));
                 const double reuse = (double)(MB * NPW) / (MB + NPW);
-                const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0));
+                // two co-resident workgroups overlap conversion / staging with the other's MFMAs
+                const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0)) * (p.split == 2 ? 1.25 : 1.0);
                 if (score > best_score) { best_score = score; best = p; }
             }
             if (s.need_all_cout) break;
@@ -205,7 +210,10 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
-    conv_kernel_fn fn = p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode);
+    conv_kernel_fn fn = p.split == 2 ? conv_lookup_split2(p.MB, p.NPW)
+                        : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
+    if (ablate && p.split == 1)
+        if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;
     if (ablate && p.lnmode == 0 && !p.split)
         if (conv_kernel_fn f2 = conv_lookup_abl(p.MB, p.NPW, ablate)) fn = f2;
     if (!fn) return hipErrorInvalidValue;

@@ -28,7 +28,9 @@ __device__ __forceinline__ void split3(float a, unsigned &h, unsigned &m, unsign
     l = __float_as_uint(r - __uint_as_float(m));          // <= 8 significant bits: already a bf16
 }
 
-template <int MB, int NPW>
+// ABL (tuning aid, wrong results): 1 convert only chunk 0, 2 no input DMA after chunk 0, 4 no weight DMA after
+// the first row, 8 no per-row barrier, 16 skip the MFMAs
+template <int MB, int NPW, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COPT = MB * 32;
@@ -150,6 +152,7 @@ __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
         dma_wait();
         __syncthreads();                    // fp32 patch of `chunk` (and the first weight row) landed
         // ---- split the patch into three bf16 planes, 8 channels per 16-byte unit --------------------
+        if (!(ABL & 1) || chunk == 0)
         for (int u = tid; u < 2 * plane; u += nthr) {
             const int kg = u >= plane ? 1 : 0;
             const int rc = u - kg * plane;
@@ -170,9 +173,203 @@ __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
             dst[(2 * 2 + kg) * plane + rc] = vl;
         }
         __syncthreads();                    // split patch ready; landing area free again
-        if (chunk + 1 < nc16) issue_x(chunk + 1);
+        if (chunk + 1 < nc16 && !(ABL & 2)) issue_x(chunk + 1);
         for (int ky = 0; ky < P.KH; ++ky) {
             // prefetch the next weight row (next ky, or row 0 of the next chunk) into the other stage
+            if (!(ABL & 4)) {
+                if (ky + 1 < P.KH) issue_w(ky + 1, chunk, wstage ^ 1);
+                else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
+            }
+            const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats);
+            const uint4 *xb = reinterpret_cast<const uint4 *>(xc);
+            for (int kx = 0; kx < P.KW; ++kx) {
+                bf16x8 A[3][MB], Bv[3][NPW];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const uint4 t = wa[(kx * 6 + p * 2) * COPT + a_lane + m * 32];
+                        A[p][m] = __builtin_bit_cast(bf16x8, t);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) {
+                        const uint4 t = xb[(p * 2) * plane + b_lane + ky * PW + kx + n * nb_stride];
+                        Bv[p][n] = __builtin_bit_cast(bf16x8, t);
+                    }
+                }
+                // six product terms, smallest first
+                if constexpr ((ABL & 16) != 0) {
+                    asm volatile("" ::"v"(A[0][0]), "v"(Bv[0][0]), "v"(A[2][MB - 1]), "v"(Bv[2][NPW - 1]));
+                } else
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+                    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[term]][m], Bv[PB[term]][n],
+                                                                                acc[m][n], 0, 0, 0);
+                }
+            }
+            dma_wait();
+            if (!(ABL & 8)) __syncthreads();   // next weight row landed; this stage may be overwritten
+            wstage ^= 1;
+        }
+    }
+
+    const TileGeom geom{tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH};
+    conv_epilogue<MB, NPW, 0, 0>(P, geom, acc, smem, nullptr);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Variant for small channel groups (MB*NPW <= 4): two workgroups per CU.  The ablation of the kernel
+// above (tools/gpu_conv_tune.py, CDC_ABLATE) shows MFMA time 0.56 ms and everything else 0.61 ms with NO
+// overlap at one wave per SIMD, so this variant shrinks the LDS footprint below 80 KiB: the fp32 patch
+// never touches LDS -- it is fetched global -> registers one chunk ahead (16-byte loads of the aligned
+// patch rows), split in registers and written straight into the three bf16 planes.  While one
+// workgroup converts / waits, the other one owns the matrix pipe.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXR = 8;      // float4 registers per thread for the in-flight patch
+
+template <int MB, int NPW>
+__global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int COPT = MB * 32;
+    constexpr int KC = 16;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WN = nthr >> 6;
+    const int z = blockIdx.z;
+    const int cog = blockIdx.y;
+
+    int bid = blockIdx.x;
+    const int tx = bid % P.tiles_x;
+    bid /= P.tiles_x;
+    const int ty = bid % P.tiles_y;
+    const int b = bid / P.tiles_y;
+
+    const int NBW = 1 << P.lognbw;
+    const int NBH = 32 >> P.lognbw;
+    const int TH = WN * NPW * NBH;
+    const int oy0 = ty * TH, ox0 = tx * NBW;
+    const int iy0 = oy0 * P.stride - P.pad_y[z];
+    const int ix0 = ox0 * P.stride - P.pad_x[z];
+    const int PH = P.PH, PW = P.PW;
+    const int plane = PH * PW;
+    const int nc16 = P.Cin_pad >> 4;
+
+    const int xc_floats = 24 * plane, wst_floats = P.KW * 24 * COPT;
+    float *xc = smem;
+    float *wl = smem + xc_floats;
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned wl_lds = smem_lds + (unsigned)xc_floats * 4u;
+
+    // ---- the patch unit owned by this thread: (k-half kg, row r, 4-column group q4) = 8 channels x 4
+    // pixels = 8 float4 registers; after the split it becomes 4 pixels x 3 planes of 16-byte units
+    // (host guarantees 2 * PH * PW/4 <= blockDim.x: one unit per thread)
+    const int units = plane / 2;                      // 2 * plane / 4
+    int xsp = -2, ukg = 0, urc = 0;                   // -2: no unit, -1: zero padding, else iy*W+ix
+    if (tid < units) {
+        ukg = tid >= plane / 4 ? 1 : 0;
+        const unsigned rem = tid - ukg * (plane / 4);
+        const unsigned r = fdiv(rem, P.magic_w);      // / (PW / 4)
+        const unsigned col = (rem - r * (unsigned)(PW / 4)) * 4;
+        urc = (int)(r * PW + col);
+        const int iy = iy0 + (int)r, ix = ix0 - P.xshift[z] + (int)col;
+        xsp = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? iy * P.W + ix : -1;
+    }
+    const unsigned HW = (unsigned)(P.H * P.W);
+    const float *s0 = P.src0 + (size_t)b * P.src0_bs;
+    const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
+
+    float4 xr[kXR];
+    auto load_x = [&](int chunk) {
+        const int cbase = chunk * KC;
+        const float *xbase = cbase < P.C0 ? s0 + (size_t)cbase * HW : s1 + (size_t)(cbase - P.C0) * HW;
+        const int ncm1 = min(KC, P.Cin - cbase) - 1;  // channel tail: re-read the last valid (weights 0)
+#pragma unroll
+        for (int i = 0; i < kXR; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xsp >= 0) {
+                const unsigned c = (unsigned)min(ukg * 8 + i, ncm1);
+                v = *reinterpret_cast<const float4 *>(xbase + (size_t)c * HW + (unsigned)xsp);
+            }
+            xr[i] = v;
+        }
+    };
+    auto store_x = [&]() {
+        if (xsp > -2) {
+            uint4 *dst = reinterpret_cast<uint4 *>(xc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = t == 0 ? xr[q].x : (t == 1 ? xr[q].y : (t == 2 ? xr[q].z : xr[q].w));
+                    split3(v, hh[q], mm[q], ll[q]);
+                }
+                uint4 vh, vm, vl;
+                vh.x = (hh[0] >> 16) | hh[1]; vh.y = (hh[2] >> 16) | hh[3];
+                vh.z = (hh[4] >> 16) | hh[5]; vh.w = (hh[6] >> 16) | hh[7];
+                vm.x = (mm[0] >> 16) | mm[1]; vm.y = (mm[2] >> 16) | mm[3];
+                vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
+                vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
+                vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
+                dst[(0 * 2 + ukg) * plane + urc + t] = vh;
+                dst[(1 * 2 + ukg) * plane + urc + t] = vm;
+                dst[(2 * 2 + ukg) * plane + urc + t] = vl;
+            }
+        }
+    };
+    const int n_w = P.KW * 6 * COPT;
+    const int wsl = (n_w + nthr - 1) / nthr;
+    const unsigned short *wsrc = P.wsp + (size_t)z * P.wsp_zs + (size_t)cog * COPT * 8;
+    auto issue_w = [&](int ky, int chunk, int stage) {
+        const unsigned short *base = wsrc + ((size_t)(ky * P.KW) * nc16 + chunk) * 6 * P.COP * 8;
+        const float *wbase = uniform_ptr(reinterpret_cast<const float *>(base));
+        for (int i = 0; i < wsl; ++i) {
+            const int e = tid + i * nthr;
+            if (e < n_w) {
+                const int t = e / (6 * COPT);
+                const int rem = e - t * 6 * COPT;
+                const int pk = rem / COPT, co = rem - pk * COPT;
+                const unsigned voff = (unsigned)(((t * nc16) * 6 + pk) * P.COP + co) * 16u;
+                dma_b128_s(voff, wbase, wl_lds + (unsigned)(stage * wst_floats) * 4u +
+                                            (unsigned)(i * nthr + wave * 64) * 16u);
+            }
+        }
+    };
+
+    f32x16 acc[MB][NPW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int half = lane >> 5;
+    const int j = lane & 31;
+    const int pr = j >> P.lognbw, pc = j & (NBW - 1);
+    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
+    const int nb_stride = NBH * P.stride * PW;
+    const int a_lane = half * COPT + j;
+
+    load_x(0);
+    issue_w(0, 0, 0);
+    int wstage = 0;
+    for (int chunk = 0; chunk < nc16; ++chunk) {
+        if (chunk) __syncthreads();          // everyone finished reading the previous chunk's planes
+        store_x();
+        if (chunk + 1 < nc16) load_x(chunk + 1);     // in flight during the whole tap loop
+        dma_wait();
+        __syncthreads();                    // planes of `chunk` + first weight row visible
+        for (int ky = 0; ky < P.KH; ++ky) {
             if (ky + 1 < P.KH) issue_w(ky + 1, chunk, wstage ^ 1);
             else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats);
@@ -192,7 +389,6 @@ __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
                         Bv[p][n] = __builtin_bit_cast(bf16x8, t);
                     }
                 }
-                // six product terms, smallest first
 #pragma unroll
                 for (int term = 0; term < 6; ++term) {
                     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
@@ -206,7 +402,7 @@ __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
                 }
             }
             dma_wait();
-            __syncthreads();                // next weight row landed; this stage may be overwritten
+            __syncthreads();
             wstage ^= 1;
         }
     }
