@@ -32,6 +32,7 @@ struct ConvArgs {
     // split-bf16 form (conv_split_kernel.h): [z][tap][Cin_pad/16][plane 3][k-half 2][COP][8] bf16
     const unsigned short *wsp;
     long long wsp_zs;
+    int tg;                         // taps per LDS weight stage (conv_split2_kernel)
     int KH, KW, stride;
     int pad_y[4], pad_x[4];         // per blockIdx.z (ConvTranspose phases); z = 0 otherwise
     int KC, logKC, nchunk, Cin_pad, COP, Cout;
@@ -69,6 +70,7 @@ struct ConvPlan {
     int xvec, xshift[4];
     size_t lds_bytes;
     int lnmode;
+    int tg;                 // taps per weight stage of the split kernels
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 

@@ -24,6 +24,9 @@ conv_kernel_fn conv_lookup_split2(int MB, int NPW) {
     if (MB == 2 && NPW == 2) return conv_split2_kernel<2, 2>;
     if (MB == 3 && NPW == 1) return conv_split2_kernel<3, 1>;
     if (MB == 4 && NPW == 1) return conv_split2_kernel<4, 1>;
+    if (MB == 3 && NPW == 2) return conv_split2_kernel<3, 2>;
+    if (MB == 5 && NPW == 1) return conv_split2_kernel<5, 1>;
+    if (MB == 6 && NPW == 1) return conv_split2_kernel<6, 1>;
     return nullptr;
 }
 }  // namespace cdc

@@ -105,7 +105,10 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     PW = round_up(mx + PW, 4);
     const int plane = PH * PW, COPT = MB * 32;
     // variant 2 (patch staged through registers, two workgroups per CU) when it fits
-    const size_t lds2 = sizeof(float) * ((size_t)24 * plane + (size_t)2 * s.KW * 24 * COPT);
+    // weight stages of one kernel row if that fits next to a second workgroup, else one tap each
+    int tg = s.KW;
+    size_t lds2 = sizeof(float) * ((size_t)24 * plane + (size_t)2 * tg * 24 * COPT);
+    if (lds2 > 80 * 1024) { tg = 1; lds2 = sizeof(float) * ((size_t)24 * plane + (size_t)2 * 24 * COPT); }
     const bool v2 = conv_lookup_split2(MB, NPW) && plane / 2 <= nthr && lds2 <= 80 * 1024 &&
                     !getenv("CDC_NO_SPLIT2");
     if (!v2 && 4 * plane > kXS * nthr) return false;
@@ -124,6 +127,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->lds_bytes = std::max(lds, sizeof(float) * 4 * (size_t)COPT);
     p->lnmode = 0;
     p->split = v2 ? 2 : 1;
+    p->tg = v2 ? tg : s.KW;
     return true;
 }
 
@@ -205,6 +209,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.tiles_y = p.tiles_y;
     a.PH = p.PH; a.PW = p.PW;
     a.xvec = p.xvec;
+    a.tg = p.tg;
     for (int z = 0; z < 4; ++z) a.xshift[z] = p.xshift[z];
     const int xv = p.xvec ? 4 : 1;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));

@@ -263,7 +263,9 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const int plane = PH * PW;
     const int nc16 = P.Cin_pad >> 4;
 
-    const int xc_floats = 24 * plane, wst_floats = P.KW * 24 * COPT;
+    const int TG = P.tg;                              // taps per weight stage (a kernel row, or 1)
+    const int ntg = (P.KH * P.KW) / TG;
+    const int xc_floats = 24 * plane, wst_floats = TG * 24 * COPT;
     float *xc = smem;
     float *wl = smem + xc_floats;
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
@@ -326,11 +328,11 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
             }
         }
     };
-    const int n_w = P.KW * 6 * COPT;
+    const int n_w = TG * 6 * COPT;
     const int wsl = (n_w + nthr - 1) / nthr;
     const unsigned short *wsrc = P.wsp + (size_t)z * P.wsp_zs + (size_t)cog * COPT * 8;
-    auto issue_w = [&](int ky, int chunk, int stage) {
-        const unsigned short *base = wsrc + ((size_t)(ky * P.KW) * nc16 + chunk) * 6 * P.COP * 8;
+    auto issue_w = [&](int grp, int chunk, int stage) {
+        const unsigned short *base = wsrc + ((size_t)(grp * TG) * nc16 + chunk) * 6 * P.COP * 8;
         const float *wbase = uniform_ptr(reinterpret_cast<const float *>(base));
         for (int i = 0; i < wsl; ++i) {
             const int e = tid + i * nthr;
@@ -369,36 +371,40 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
         if (chunk + 1 < nc16) load_x(chunk + 1);     // in flight during the whole tap loop
         dma_wait();
         __syncthreads();                    // planes of `chunk` + first weight row visible
-        for (int ky = 0; ky < P.KH; ++ky) {
-            if (ky + 1 < P.KH) issue_w(ky + 1, chunk, wstage ^ 1);
+        for (int grp = 0; grp < ntg; ++grp) {
+            if (grp + 1 < ntg) issue_w(grp + 1, chunk, wstage ^ 1);
             else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats);
             const uint4 *xb = reinterpret_cast<const uint4 *>(xc);
-            for (int kx = 0; kx < P.KW; ++kx) {
-                bf16x8 A[3][MB], Bv[3][NPW];
+            for (int t = 0; t < TG; ++t) {
+                const int tap = grp * TG + t;
+                const int ky = tap / P.KW, kx = tap - ky * P.KW;
+                // B planes stay live for the tap; the A planes are fetched one at a time, smallest
+                // first: plane 2 feeds one product term, plane 1 two, plane 0 three (six in all)
+                bf16x8 Bv[3][NPW];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const uint4 t = wa[(kx * 6 + p * 2) * COPT + a_lane + m * 32];
-                        A[p][m] = __builtin_bit_cast(bf16x8, t);
-                    }
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
                     for (int n = 0; n < NPW; ++n) {
-                        const uint4 t = xb[(p * 2) * plane + b_lane + ky * PW + kx + n * nb_stride];
-                        Bv[p][n] = __builtin_bit_cast(bf16x8, t);
+                        const uint4 v = xb[(p * 2) * plane + b_lane + ky * PW + kx + n * nb_stride];
+                        Bv[p][n] = __builtin_bit_cast(bf16x8, v);
                     }
-                }
 #pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-                    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+                for (int pa = 2; pa >= 0; --pa) {
+                    bf16x8 A[MB];
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                    for (int m = 0; m < MB; ++m) {
+                        const uint4 v = wa[(t * 6 + pa * 2) * COPT + a_lane + m * 32];
+                        A[m] = __builtin_bit_cast(bf16x8, v);
+                    }
 #pragma unroll
-                        for (int n = 0; n < NPW; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[term]][m], Bv[PB[term]][n],
-                                                                                acc[m][n], 0, 0, 0);
+                    for (int pb = 2 - pa; pb >= 0; --pb)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+#pragma unroll
+                            for (int n = 0; n < NPW; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bv[pb][n], acc[m][n],
+                                                                                    0, 0, 0);
                 }
             }
             dma_wait();
