@@ -468,22 +468,27 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 // ---------------------------------------------------------------------------------------------
 constexpr int kFoldRows = 8;     // rows per workgroup: each WoT / T1 element is reused 8x from registers
 
-__global__ void __launch_bounds__(256) ctx_r1_kernel(const float *S, const float *ksum, int C,
-                                                     int nsplit, const float *WoT, float *T1) {
+// R0: ctxn[b][d][e] = (sum_split S) / (sum_split Zp)   -- one thread per element, coalesced over e
+__global__ void __launch_bounds__(256) ctx_r0_kernel(const float *S, const float *Zp, int C, int nsplit,
+                                                     float *ctxn) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * C) return;
+    const int d = idx / C;
+    float s = 0.f, z = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        s += S[((size_t)b * nsplit + sp) * C * C + idx];
+        z += Zp[((size_t)b * nsplit + sp) * C + d];
+    }
+    ctxn[(size_t)b * C * C + idx] = s / z;
+}
+
+__global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, const float *WoT, float *T1) {
     extern __shared__ float rows[];         // [kFoldRows][C]: normalised ctx rows d0..d0+7
     const int d0 = blockIdx.x * kFoldRows, b = blockIdx.y;
     for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
         const int r = idx / C, e = idx - r * C, d = d0 + r;
-        float s = 0.f;
-        if (d < C) {
-            float z = 0.f;
-            for (int sp = 0; sp < nsplit; ++sp) {
-                z += ksum[((size_t)b * nsplit + sp) * C + d];
-                s += S[(((size_t)b * nsplit + sp) * C + d) * C + e];
-            }
-            s /= z;
-        }
-        rows[idx] = s;
+        rows[idx] = d < C ? ctxn[((size_t)b * C + d) * C + e] : 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -502,7 +507,8 @@ __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *S, const float
 }
 
 __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const float *WqT, int C,
-                                                     float scale, float *Mt, int Cin_pad, int COP) {
+                                                     float scale, const float *ln_g, float *Mt,
+                                                     int Cin_pad, int COP) {
     extern __shared__ float rows[];         // [kFoldRows][C]: WqT rows ci0..ci0+7
     const int ci0 = blockIdx.x * kFoldRows, b = blockIdx.y;
     for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
@@ -524,39 +530,38 @@ __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const floa
         }
 #pragma unroll
         for (int r = 0; r < kFoldRows; ++r)
-            if (ci0 + r < Cin_pad) Mt[((size_t)b * Cin_pad + ci0 + r) * COP + c] = acc[r] * scale;
+            if (ci0 + r < Cin_pad)      // PreNorm gain folded in (LNMODE 2 of the conv kernel)
+                Mt[((size_t)b * Cin_pad + ci0 + r) * COP + c] =
+                    acc[r] * scale * (ci0 + r < C ? ln_g[ci0 + r] : 0.f);
     }
 }
 
-// R3: fold the PreNorm affine into the per-image weights (LNMODE 2 of the conv kernel):
-//   biasB[b][c] = b_out[c] + sum_ci Mt[b][ci][c] * ln_b[ci] ;  Mt[b][ci][c] *= ln_g[ci]
-__global__ void __launch_bounds__(256) ctx_r3_kernel(float *Mt, const float *ln_g, const float *ln_b,
-                                                     const float *b_out, float *biasB, int C,
-                                                     int Cin_pad, int COP) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float *col = Mt + (size_t)b * Cin_pad * COP + c;
-        float acc = 0.f;
-        for (int ci = 0; ci < C; ++ci) {
-            const float v = col[(size_t)ci * COP];
-            acc += v * ln_b[ci];
-            col[(size_t)ci * COP] = v * ln_g[ci];
-        }
-        biasB[(size_t)b * C + c] = b_out[c] + acc;
-    }
+// R3: per-image bias of the folded convolution:  b_out + M' b_ln = b_out + scale * sum_d u[d] T1[b][d][c]
+// with u = Wq b_ln (a per-layer constant computed at weight load)
+__global__ void __launch_bounds__(256) ctx_r3_kernel(const float *T1, const float *u, const float *b_out,
+                                                     float scale, float *biasB, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float *t = T1 + (size_t)b * C * C + c;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < C; ++d) acc += u[d] * t[(size_t)d * C];
+    biasB[(size_t)b * C + c] = b_out[c] + scale * acc;
 }
 
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
-                           int COP, const float *ln_g, const float *ln_b, const float *b_out,
+                           int COP, const float *ln_g, const float *u, const float *b_out,
                            float *biasB, int B, hipStream_t st) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    // Mt doubles as scratch for the normalised context (C*C <= Cin_pad*COP) until R2 overwrites it
+    hipLaunchKernelGGL(ctx_r0_kernel, dim3(ceil_div(C * C, 256), B), dim3(256), 0, st, S, ksum, C, nsplit, Mt);
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
-                       sizeof(float) * kFoldRows * C, st, S, ksum, C, nsplit, WoT, T1);
+                       sizeof(float) * kFoldRows * C, st, Mt, C, WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),
-                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, Mt, Cin_pad, COP);
-    hipLaunchKernelGGL(ctx_r3_kernel, dim3(B), dim3(blk), 0, st, Mt, ln_g, ln_b, b_out, biasB, C, Cin_pad,
-                       COP);
+                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, ln_g, Mt, Cin_pad, COP);
+    hipLaunchKernelGGL(ctx_r3_kernel, dim3(ceil_div(C, 64), B), dim3(64), 0, st, T1, u, b_out, scale, biasB, C);
     return hipGetLastError();
 }
 

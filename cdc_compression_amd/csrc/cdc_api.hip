@@ -54,7 +54,7 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
                    int hoist_cx = 0; ConvW c1x, c1c, cresx, cresc; };
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
-               ConvW kv; float *WoT = nullptr, *WqT = nullptr; };   // folded output (many-pixel levels)
+               ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr; };   // folded output; uq = Wq b_ln
 
 struct Op {
     enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY } kind;
@@ -432,6 +432,14 @@ int pack_attn(cdc_handle *h, const std::string &p, int c) {
             }
         if ((rc = upload(h, woT.data(), woT.size(), &a.WoT, &h->weight_allocs))) return rc;
         if ((rc = upload(h, wqT.data(), wqT.size(), &a.WqT, &h->weight_allocs))) return rc;
+        const auto &bn = hostp(h, p + ".fn.norm.b");
+        std::vector<float> uq(c);
+        for (int d = 0; d < c; ++d) {
+            double acc = 0;
+            for (int ci = 0; ci < c; ++ci) acc += (double)wq[(size_t)d * c + ci] * bn[ci];
+            uq[d] = (float)acc;
+        }
+        if ((rc = upload(h, uq.data(), uq.size(), &a.uq, &h->weight_allocs))) return rc;
     }
     h->attns.push_back(a);
     return CDC_OK;
@@ -608,6 +616,9 @@ struct Builder {
     // leaves most CUs idle, so split channels over workgroups and run the standalone LN instead.
     bool prefer_fused(const ConvW &w, int H, int W) {
         if (w.Cout % 32 || w.Cout > 384) return false;
+        // the split-bf16 kernels hold at most 6 channel blocks per workgroup: wider layers run them over
+        // channel groups (2x the matrix rate) and normalise in a separate pass
+        if (w.wsp && w.Cout > 192 && (W & 3) == 0 && !getenv("CDC_NO_SPLIT")) return false;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.Ho = H; s.Wo = W; s.B = B; s.lnmode = 0;
@@ -733,7 +744,7 @@ struct Builder {
         if (rc) return Act();
         Op k; k.kind = Op::KSTATS; k.prof = PC_SMALL;
         k.at = {kp, vp, qkv.bs(), C, N, kmax, ksum, S, ctxw, nsplit, Cin_pad, COP,
-                1.0f / sqrtf((float)C), at.WoT, at.WqT, T1, at.ng, at.nb, at.out.bias, biasB};
+                1.0f / sqrtf((float)C), at.WoT, at.WqT, T1, at.ng, at.uq, at.out.bias, biasB};
         k.bytes = 8.0 * B * C * N;
         emit(k);
         Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
@@ -1516,6 +1527,13 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
             }
         if ((rc = sc.up(woT.data(), woT.size(), &at.WoT))) return rc;
         if ((rc = sc.up(wqT.data(), wqT.size(), &at.WqT))) return rc;
+        std::vector<float> uq(C);
+        for (int d = 0; d < C; ++d) {
+            double acc = 0;
+            for (int ci = 0; ci < C; ++ci) acc += (double)w_qkv[(size_t)d * C + ci] * norm_b[ci];
+            uq[d] = (float)acc;
+        }
+        if ((rc = sc.up(uq.data(), uq.size(), &at.uq))) return rc;
     }
     Act ax;
     ax.C = C; ax.H = H; ax.W = W;

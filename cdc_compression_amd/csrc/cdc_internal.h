@@ -85,7 +85,7 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
-                           int COP, const float *ln_g, const float *ln_b, const float *b_out,
+                           int COP, const float *ln_g, const float *u, const float *b_out,
                            float *biasB, int B, hipStream_t st);
 hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
                                int pad, int H, int W, int B, hipStream_t st);
