@@ -300,7 +300,7 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int CoutF, int C
     int rc = upload(h, packed.data(), packed.size(), &cw->wp, pool);
     if (rc) return rc;
     cw->wsp = nullptr;
-    if (cw->KH * cw->KW > 1 && Cin >= 16 && !getenv("CDC_NO_SPLIT")) {
+    if (((cw->KH * cw->KW > 1 && Cin >= 16) || Cin >= 32) && !getenv("CDC_NO_SPLIT")) {
         // exact three-way bf16 split (truncation): w = w1 + w2 + w3, laid out in MFMA A-operand order
         // [z][tap][Cin_pad/16][plane][k-half][COP][8 cin]
         const int taps = cw->KH * cw->KW, nc16 = cw->Cin_pad / 16;
@@ -466,9 +466,9 @@ struct Builder {
         char buf[160];
         const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy"};
         if (op.kind == Op::CONV)
-            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d%s%s%s%s", op.conv.KH,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.split == 2 ? " SPLIT2" : (op.plan.split ? " SPLIT" : ""),
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.split == 2 ? " SPLIT2" : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)

@@ -33,6 +33,7 @@ struct ConvArgs {
     const unsigned short *wsp;
     long long wsp_zs;
     int tg;                         // taps per LDS weight stage (conv_split2_kernel)
+    int ipw, B;                     // images per workgroup (small feature maps), batch size
     int KH, KW, stride;
     int pad_y[4], pad_x[4];         // per blockIdx.z (ConvTranspose phases); z = 0 otherwise
     int KC, logKC, nchunk, Cin_pad, COP, Cout;
@@ -71,6 +72,7 @@ struct ConvPlan {
     size_t lds_bytes;
     int lnmode;
     int tg;                 // taps per weight stage of the split kernels
+    int ipw;                // images per workgroup (1: tiles inside one image)
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 

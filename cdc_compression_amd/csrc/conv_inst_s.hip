@@ -17,16 +17,27 @@ conv_kernel_fn conv_lookup_split(int MB, int NPW) {
     if (MB == 6 && NPW == 1) return conv_split_kernel<6, 1>;
     return nullptr;
 }
-conv_kernel_fn conv_lookup_split2(int MB, int NPW) {
-    if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1>;
-    if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2>;
-    if (MB == 2 && NPW == 1) return conv_split2_kernel<2, 1>;
-    if (MB == 2 && NPW == 2) return conv_split2_kernel<2, 2>;
-    if (MB == 3 && NPW == 1) return conv_split2_kernel<3, 1>;
-    if (MB == 4 && NPW == 1) return conv_split2_kernel<4, 1>;
-    if (MB == 3 && NPW == 2) return conv_split2_kernel<3, 2>;
-    if (MB == 5 && NPW == 1) return conv_split2_kernel<5, 1>;
-    if (MB == 6 && NPW == 1) return conv_split2_kernel<6, 1>;
+conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode) {
+    if (lnmode == 0) {
+        if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1>;
+        if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2>;
+        if (MB == 2 && NPW == 1) return conv_split2_kernel<2, 1>;
+        if (MB == 2 && NPW == 2) return conv_split2_kernel<2, 2>;
+        if (MB == 3 && NPW == 1) return conv_split2_kernel<3, 1>;
+        if (MB == 4 && NPW == 1) return conv_split2_kernel<4, 1>;
+        if (MB == 3 && NPW == 2) return conv_split2_kernel<3, 2>;
+        if (MB == 5 && NPW == 1) return conv_split2_kernel<5, 1>;
+        if (MB == 6 && NPW == 1) return conv_split2_kernel<6, 1>;
+    } else if (lnmode == 2) {
+        if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1, 2>;
+        if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2, 2>;
+        if (MB == 2 && NPW == 1) return conv_split2_kernel<2, 1, 2>;
+        if (MB == 2 && NPW == 2) return conv_split2_kernel<2, 2, 2>;
+        if (MB == 3 && NPW == 1) return conv_split2_kernel<3, 1, 2>;
+        if (MB == 4 && NPW == 1) return conv_split2_kernel<4, 1, 2>;
+        if (MB == 3 && NPW == 2) return conv_split2_kernel<3, 2, 2>;
+        if (MB == 6 && NPW == 1) return conv_split2_kernel<6, 1, 2>;
+    }
     return nullptr;
 }
 }  // namespace cdc

@@ -61,6 +61,8 @@ constexpr int conv_min_waves(int MB, int NPW) { return MB * NPW <= 8 ? 2 : 1; }
 
 struct TileGeom {      // where this workgroup / lane sits (shared by the kernel variants' epilogue)
     int tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH;
+    // small feature maps: a workgroup covers ipw images, wpi waves each (b = first image; default 1 image)
+    int ipw = 1, wpi = 4, nimg = 1 << 30;
 };
 
 // Fused epilogue on the MFMA accumulators (C/D layout of the 32x32 forms: lane = pixel l&31, register
@@ -70,18 +72,24 @@ template <int MB, int NPW, int LNMODE, int ABL>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom &g, f32x16 (&acc)[MB][NPW],
                                               float *smem, const float *prstd) {
     constexpr int COPT = MB * 32;
-    const int tid = g.tid, nthr = g.nthr, wave = g.wave, half = g.half, pr = g.pr, pc = g.pc;
-    const int b = g.b, z = g.z, cog = g.cog, oy0 = g.oy0, ox0 = g.ox0, NBH = g.NBH;
+    const int tid = g.tid, nthr = g.nthr, half = g.half, pr = g.pr, pc = g.pc;
+    const int z = g.z, cog = g.cog, oy0 = g.oy0, ox0 = g.ox0, NBH = g.NBH;
+    const int img_l = g.ipw > 1 ? g.wave / g.wpi : 0;          // image of this wave inside the workgroup
+    const int wave = g.ipw > 1 ? g.wave % g.wpi : g.wave;      // row-block index inside its image
+    const int b = g.b + img_l;
+    const bool img_ok = b < g.nimg;
     // ---- epilogue -------------------------------------------------------------------------------
     __syncthreads();
-    float *ep = smem;   // [4][COPT]: bias, ln g, ln b, shift
+    float *ep = smem;   // [3 + ipw][COPT]: bias, ln g, ln b, shift (one row per image of the workgroup)
     for (int i = tid; i < COPT; i += nthr) {
         const int co = cog * COPT + i;
         const bool ok = co < P.Cout;
         ep[i] = (ok && P.bias) ? P.bias[co] : 0.f;
         ep[COPT + i] = (ok && P.ep_g) ? P.ep_g[co] : 0.f;
         ep[2 * COPT + i] = (ok && P.ep_b) ? P.ep_b[co] : 0.f;
-        ep[3 * COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
+        for (int q = 0; q < g.ipw; ++q)
+            ep[(3 + q) * COPT + i] =
+                (ok && P.shift && g.b + q < g.nimg) ? P.shift[(size_t)(g.b + q) * P.shift_bs + co] : 0.f;
     }
     __syncthreads();
 
@@ -96,7 +104,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
     for (int n = 0; n < NPW; ++n) {
         const int oy = oy0 + (wave * NPW + n) * NBH + pr;
         const int ox = ox0 + pc;
-        const bool valid = (oy < P.Ho) && (ox < P.Wo);
+        const bool valid = (oy < P.Ho) && (ox < P.Wo) && img_ok;
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -163,7 +171,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
+                    acc[m][n][r] += epl[(3 + img_l) * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
         }
         if (P.resid) {
             const float *rp = P.resid + (size_t)b * P.resid_bs + pix +

@@ -84,20 +84,27 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     p->lds_bytes = plan_lds(taps, KC, COPT, PH, PW, nthr, xv);
     p->lnmode = s.lnmode;
     p->split = 0;
+    p->ipw = 1;
+    p->tg = 0;
     return true;
 }
 
 // Split-bf16 kernel: 16-channel chunks, one workgroup per CU; LDS = split patch (96 B/position) +
 // fp32 landing area (64 B/position) + two weight-row stages.
-static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p) {
+static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p, bool allow_ipw = true) {
     const int nblocks = ceil_div(s.Cout, 32);
-    if (nblocks % MB || !conv_lookup_split(MB, NPW)) return false;
+    if (nblocks % MB) return false;
     const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
     const int nb_rows = ceil_div(s.Ho, NBH);
     int WN = std::min(4, ceil_div(nb_rows, NPW));
     if (WN == 3) WN = 4;
+    // small feature maps (one or two 32-pixel row blocks per wave cover the image): pack several images
+    // into the workgroup so the weight stages are still shared by four waves
+    int ipw = 1;
+    if (allow_ipw && s.Wo <= NBW && WN <= 2 && s.B >= 2 && !getenv("CDC_NO_IPW")) { ipw = 4 / WN; WN = 4; }
+    const int wpi = WN / ipw;
     const int nthr = 64 * WN;
-    const int TH = WN * NPW * NBH;
+    const int TH = wpi * NPW * NBH;
     const int PH = (TH - 1) * s.stride + s.KH;
     int PW = (NBW - 1) * s.stride + s.KW;
     int xshift[4] = {0, 0, 0, 0}, mx = 0;
@@ -107,11 +114,12 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // variant 2 (patch staged through registers, two workgroups per CU) when it fits
     // weight stages of one kernel row if that fits next to a second workgroup, else one tap each
     int tg = s.KW;
-    size_t lds2 = sizeof(float) * ((size_t)24 * plane + (size_t)2 * tg * 24 * COPT);
-    if (lds2 > 80 * 1024) { tg = 1; lds2 = sizeof(float) * ((size_t)24 * plane + (size_t)2 * 24 * COPT); }
-    const bool v2 = conv_lookup_split2(MB, NPW) && plane / 2 <= nthr && lds2 <= 80 * 1024 &&
+    size_t lds2 = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * tg * 24 * COPT);
+    if (lds2 > 80 * 1024) { tg = 1; lds2 = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * 24 * COPT); }
+    const bool v2 = conv_lookup_split2(MB, NPW, s.lnmode) && plane / 2 <= wpi * 64 && lds2 <= 80 * 1024 &&
                     !getenv("CDC_NO_SPLIT2");
-    if (!v2 && 4 * plane > kXS * nthr) return false;
+    if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
+    if (!v2 && (s.lnmode != 0 || !conv_lookup_split(MB, NPW) || 4 * plane > kXS * nthr)) return false;
     const size_t lds = v2 ? lds2 : sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);
     if (lds > 160 * 1024) return false;
     p->MB = MB; p->NPW = NPW; p->WN = WN;
@@ -124,10 +132,11 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->PH = PH; p->PW = PW;
     p->xvec = 1;
     for (int z = 0; z < 4; ++z) p->xshift[z] = xshift[z];
-    p->lds_bytes = std::max(lds, sizeof(float) * 4 * (size_t)COPT);
-    p->lnmode = 0;
+    p->lds_bytes = std::max(lds, sizeof(float) * (3 + ipw) * (size_t)COPT);
+    p->lnmode = s.lnmode;
     p->split = v2 ? 2 : 1;
     p->tg = v2 ? tg : s.KW;
+    p->ipw = ipw;
     return true;
 }
 
@@ -152,7 +161,8 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     if (const char *e = getenv("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
     // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
     // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
-    const bool split_ok = s.allow_split && s.lnmode == 0 && s.KH * s.KW > 1 && s.Cin >= 16 && (s.C0 % 16) == 0 &&
+    const bool split_ok = s.allow_split && (s.lnmode == 0 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
+                          s.Cin >= (s.KH * s.KW > 1 ? 16 : 32) && (s.C0 % 16) == 0 &&
                           s.Win > 0 && (s.Win & 3) == 0 && (((1 << lognbw) * s.stride) & 3) == 0 &&
                           !getenv("CDC_NO_SPLIT");
     if (split_ok) {
@@ -165,11 +175,14 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                 ConvPlan p;
                 p.split = 0;
                 if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
-                const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups * s.nz;
-                const double fill = std::min(1.0, wgs / (p.split == 2 ? 512.0 : 256.0));
+                const double wgs = (p.ipw > 1 ? (double)ceil_div(s.B, p.ipw) : (double)p.tiles_x * p.tiles_y * s.B) *
+                                   p.groups * s.nz;
+                const double fill = std::min(1.0, wgs * p.WN / (p.split == 2 ? 2048.0 : 1024.0));
                 const double reuse = (double)(MB * NPW) / (MB + NPW);
                 // two co-resident workgroups overlap conversion / staging with the other's MFMAs
-                const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0)) * (p.split == 2 ? 1.25 : 1.0);
+                // 1x1 layers are bandwidth-bound: every extra channel group re-reads the input
+                const double grp_pen = s.KH * s.KW == 1 ? 1.0 / (1.0 + 0.2 * (p.groups - 1)) : 1.0;
+                const double score = fill * (0.5 + 0.15 * std::min(reuse, 3.0)) * (p.split == 2 ? 1.25 : 1.0) * grp_pen;
                 if (score > best_score) { best_score = score; best = p; }
             }
             if (s.need_all_cout) break;
@@ -210,12 +223,14 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.PH = p.PH; a.PW = p.PW;
     a.xvec = p.xvec;
     a.tg = p.tg;
+    a.ipw = p.ipw;
+    a.B = B;
     for (int z = 0; z < 4; ++z) a.xshift[z] = p.xshift[z];
     const int xv = p.xvec ? 4 : 1;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
-    conv_kernel_fn fn = p.split == 2 ? conv_lookup_split2(p.MB, p.NPW)
+    conv_kernel_fn fn = p.split == 2 ? conv_lookup_split2(p.MB, p.NPW, p.lnmode)
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
     if (ablate && p.split == 1)
         if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;
@@ -228,7 +243,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
                                            (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
+    dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
+              (unsigned)nz);
     dim3 block(64 * p.WN);
     hipLaunchKernelGGL(fn, grid, block, p.lds_bytes, st, a);
     return hipGetLastError();

@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kXR = 8;      // float4 registers per thread for the in-flight patch
 
-template <int MB, int NPW>
+// LNMODE 2 (1x1 only): PreNorm LayerNorm folded as in conv_kernel.h -- the pixel mean is subtracted before
+// the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
+template <int MB, int NPW, int LNMODE = 0>
 __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COPT = MB * 32;
@@ -247,15 +249,25 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const int z = blockIdx.z;
     const int cog = blockIdx.y;
 
-    int bid = blockIdx.x;
-    const int tx = bid % P.tiles_x;
-    bid /= P.tiles_x;
-    const int ty = bid % P.tiles_y;
-    const int b = bid / P.tiles_y;
-
     const int NBW = 1 << P.lognbw;
     const int NBH = 32 >> P.lognbw;
-    const int TH = WN * NPW * NBH;
+    // Small feature maps: the workgroup covers ipw whole images, wpi waves each, so that the weight
+    // stages are shared by four waves even when an image has only one or two 32-pixel blocks.
+    const int ipw = P.ipw, wpi = WN / ipw;
+    int bid = blockIdx.x, tx = 0, ty = 0, b;
+    if (ipw > 1) {
+        b = bid * ipw + wave / wpi;
+    } else {
+        tx = bid % P.tiles_x;
+        bid /= P.tiles_x;
+        ty = bid % P.tiles_y;
+        b = bid / P.tiles_y;
+    }
+    const bool img_ok = b < P.B;
+    if (!img_ok) b = P.B - 1;                       // keep addresses valid; results are masked out
+    const int rb = ipw > 1 ? wave % wpi : wave;     // this wave's row-block inside its image / tile
+    const int team = wpi * 64, uid = (ipw > 1 ? (wave % wpi) * 64 : wave * 64) + lane;
+    const int TH = wpi * NPW * NBH;
     const int oy0 = ty * TH, ox0 = tx * NBW;
     const int iy0 = oy0 * P.stride - P.pad_y[z];
     const int ix0 = ox0 * P.stride - P.pad_x[z];
@@ -266,19 +278,19 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const int TG = P.tg;                              // taps per weight stage (a kernel row, or 1)
     const int ntg = (P.KH * P.KW) / TG;
     const int xc_floats = 24 * plane, wst_floats = TG * 24 * COPT;
-    float *xc = smem;
-    float *wl = smem + xc_floats;
+    float *xc = smem + (ipw > 1 ? (wave / wpi) * xc_floats : 0);     // one split patch per image
+    float *wl = smem + ipw * xc_floats;
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const unsigned wl_lds = smem_lds + (unsigned)xc_floats * 4u;
+    const unsigned wl_lds = smem_lds + (unsigned)(ipw * xc_floats) * 4u;
 
     // ---- the patch unit owned by this thread: (k-half kg, row r, 4-column group q4) = 8 channels x 4
     // pixels = 8 float4 registers; after the split it becomes 4 pixels x 3 planes of 16-byte units
     // (host guarantees 2 * PH * PW/4 <= blockDim.x: one unit per thread)
     const int units = plane / 2;                      // 2 * plane / 4
     int xsp = -2, ukg = 0, urc = 0;                   // -2: no unit, -1: zero padding, else iy*W+ix
-    if (tid < units) {
-        ukg = tid >= plane / 4 ? 1 : 0;
-        const unsigned rem = tid - ukg * (plane / 4);
+    if (uid < units) {
+        ukg = uid >= plane / 4 ? 1 : 0;
+        const unsigned rem = uid - ukg * (plane / 4);
         const unsigned r = fdiv(rem, P.magic_w);      // / (PW / 4)
         const unsigned col = (rem - r * (unsigned)(PW / 4)) * 4;
         urc = (int)(r * PW + col);
@@ -289,6 +301,13 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const float *s0 = P.src0 + (size_t)b * P.src0_bs;
     const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
 
+    float umean[4] = {0.f, 0.f, 0.f, 0.f};          // LNMODE 2: means of the unit's 4 pixels
+    if constexpr (LNMODE == 2) {
+        if (xsp >= 0) {
+            const float4 m4 = *reinterpret_cast<const float4 *>(P.ln_mean + (size_t)b * HW + (unsigned)xsp);
+            umean[0] = m4.x; umean[1] = m4.y; umean[2] = m4.z; umean[3] = m4.w;
+        }
+    }
     float4 xr[kXR];
     auto load_x = [&](int chunk) {
         const int cbase = chunk * KC;
@@ -312,7 +331,8 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
                 unsigned hh[8], mm[8], ll[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const float v = t == 0 ? xr[q].x : (t == 1 ? xr[q].y : (t == 2 ? xr[q].z : xr[q].w));
+                    float v = t == 0 ? xr[q].x : (t == 1 ? xr[q].y : (t == 2 ? xr[q].z : xr[q].w));
+                    if constexpr (LNMODE == 2) v -= umean[t];
                     split3(v, hh[q], mm[q], ll[q]);
                 }
                 uint4 vh, vm, vl;
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const int half = lane >> 5;
     const int j = lane & 31;
     const int pr = j >> P.lognbw, pc = j & (NBW - 1);
-    const int b_lane = half * plane + (wave * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
+    const int b_lane = half * plane + (rb * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
     const int nb_stride = NBH * P.stride * PW;
     const int a_lane = half * COPT + j;
 
@@ -413,8 +433,17 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
         }
     }
 
-    const TileGeom geom{tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH};
-    conv_epilogue<MB, NPW, 0, 0>(P, geom, acc, smem, nullptr);
+    float prstd[LNMODE == 2 ? NPW : 1];
+    if constexpr (LNMODE == 2) {
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int oy = oy0 + (rb * NPW + n) * NBH + pr, ox = ox0 + pc;
+            prstd[n] = (oy < P.Ho && ox < P.Wo) ? P.ln_rstd[(size_t)b * HW + oy * P.W + ox] : 0.f;
+        }
+    }
+    TileGeom geom{tid, nthr, wave, half, pr, pc, ipw > 1 ? (int)blockIdx.x * ipw : b, z, cog, oy0, ox0, NBH};
+    geom.ipw = ipw; geom.wpi = wpi; geom.nimg = P.B;
+    conv_epilogue<MB, NPW, LNMODE, 0>(P, geom, acc, smem, prstd);
 }
 
 }  // namespace cdc
