@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcdc_hip.so")
+# CDC_HIP_LIB selects another build of the same HIP library (A/B kernel experiments, tools/build_variant.sh)
+LIB_PATH = os.environ.get("CDC_HIP_LIB") or os.path.join(_HERE, "libcdc_hip.so")
 
 CDC_MEM_HOST, CDC_MEM_DEVICE = 0, 1
 CDC_PRED_X, CDC_PRED_NOISE = 0, 1

@@ -28,6 +28,11 @@ conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode) {
         if (MB == 3 && NPW == 2) return conv_split2_kernel<3, 2>;
         if (MB == 5 && NPW == 1) return conv_split2_kernel<5, 1>;
         if (MB == 6 && NPW == 1) return conv_split2_kernel<6, 1>;
+    } else if (lnmode == 1) {
+        if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1, 1>;
+        if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2, 1>;
+        if (MB == 2 && NPW == 1) return conv_split2_kernel<2, 1, 1>;
+        if (MB == 2 && NPW == 2) return conv_split2_kernel<2, 2, 1>;
     } else if (lnmode == 2) {
         if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1, 2>;
         if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2, 2>;

@@ -161,7 +161,7 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     if (const char *e = getenv("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
     // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
     // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
-    const bool split_ok = s.allow_split && (s.lnmode == 0 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
+    const bool split_ok = s.allow_split && (s.lnmode == 0 || s.lnmode == 1 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
                           s.Cin >= (s.KH * s.KW > 1 ? 16 : 32) && (s.C0 % 16) == 0 &&
                           s.Win > 0 && (s.Win & 3) == 0 && (((1 << lognbw) * s.stride) & 3) == 0 &&
                           !getenv("CDC_NO_SPLIT");

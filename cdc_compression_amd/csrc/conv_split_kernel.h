@@ -301,11 +301,16 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const float *s0 = P.src0 + (size_t)b * P.src0_bs;
     const float *s1 = P.src1 ? P.src1 + (size_t)b * P.src1_bs : nullptr;
 
-    float umean[4] = {0.f, 0.f, 0.f, 0.f};          // LNMODE 2: means of the unit's 4 pixels
-    if constexpr (LNMODE == 2) {
+    float umean[4] = {0.f, 0.f, 0.f, 0.f};          // LNMODE 1/2: statistics of the unit's 4 pixels
+    float urstd[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNMODE != 0) {
         if (xsp >= 0) {
             const float4 m4 = *reinterpret_cast<const float4 *>(P.ln_mean + (size_t)b * HW + (unsigned)xsp);
             umean[0] = m4.x; umean[1] = m4.y; umean[2] = m4.z; umean[3] = m4.w;
+            if constexpr (LNMODE == 1) {
+                const float4 r4 = *reinterpret_cast<const float4 *>(P.ln_rstd + (size_t)b * HW + (unsigned)xsp);
+                urstd[0] = r4.x; urstd[1] = r4.y; urstd[2] = r4.z; urstd[3] = r4.w;
+            }
         }
     }
     float4 xr[kXR];
@@ -323,9 +328,17 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
             xr[i] = v;
         }
     };
-    auto store_x = [&]() {
+    auto store_x = [&](int chunk) {
         if (xsp > -2) {
             uint4 *dst = reinterpret_cast<uint4 *>(xc);
+            float lg[8], lb[8];
+            if constexpr (LNMODE == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = min(chunk * KC + ukg * 8 + q, P.Cin - 1);
+                    lg[q] = P.ln_g[c]; lb[q] = P.ln_b[c];
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned hh[8], mm[8], ll[8];
@@ -333,6 +346,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
                 for (int q = 0; q < 8; ++q) {
                     float v = t == 0 ? xr[q].x : (t == 1 ? xr[q].y : (t == 2 ? xr[q].z : xr[q].w));
                     if constexpr (LNMODE == 2) v -= umean[t];
+                    if constexpr (LNMODE == 1) v = xsp >= 0 ? (v - umean[t]) * urstd[t] * lg[q] + lb[q] : 0.f;
                     split3(v, hh[q], mm[q], ll[q]);
                 }
                 uint4 vh, vm, vl;
@@ -387,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     int wstage = 0;
     for (int chunk = 0; chunk < nc16; ++chunk) {
         if (chunk) __syncthreads();          // everyone finished reading the previous chunk's planes
-        store_x();
+        store_x(chunk);
         if (chunk + 1 < nc16) load_x(chunk + 1);     // in flight during the whole tap loop
         dma_wait();
         __syncthreads();                    // planes of `chunk` + first weight row visible

@@ -20,7 +20,7 @@ for f in files:
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 for k, v in acc.items():
-    if "conv_mfma" in k:
+    if "conv_" in k:
         print(k, {c: round(x / max(cnt[(k, c)], 1)) for c, x in v.items()})
 PY
 }
