@@ -60,6 +60,9 @@ struct ConvArgs {
     long long resid_bs, resid_cs;
     float *stat_mean, *stat_rstd;   // [B][Ho*Wo]: LN statistics of the final values (for the next
                                     // PreNorm); needs gridDim.y == 1
+#ifdef CDC_TIMELINE
+    unsigned long long *tl;         // tools/build_variant.sh timeline -DCDC_TIMELINE: 64 cycle stamps per workgroup
+#endif
 };
 
 // Host-side launch plan for one convolution.

@@ -25,26 +25,26 @@ __device__ __forceinline__ void dma_b128(const float *g, unsigned lds_byte) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte)) : "memory");
 }
 __device__ __forceinline__ void dma_b32(const float *g, unsigned lds_byte) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte)) : "memory");
 }
 // same, source address = scalar base (SGPR pair) + per-lane unsigned 32-bit byte offset
 __device__ __forceinline__ void dma_b128_s(unsigned voff, const float *sbase, unsigned lds_byte) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_byte)) : "memory");
 }
 __device__ __forceinline__ void dma_b32_s(unsigned voff, const float *sbase, unsigned lds_byte) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_byte)) : "memory");
 }
 __device__ __forceinline__ const float *uniform_ptr(const float *p) {
     const unsigned long long v = (unsigned long long)p;

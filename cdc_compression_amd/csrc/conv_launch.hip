@@ -1,4 +1,7 @@
 // conv_launch.hip -- launch-plan chooser and launcher of the implicit-GEMM convolution kernel.
+#include <map>
+#include <vector>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -89,6 +92,17 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     return true;
 }
 
+// Architected VGPRs of a kernel (cached): decides how many waves fit a SIMD (512 registers / lane).
+static int kernel_vgprs(conv_kernel_fn f) {
+    static std::map<const void *, int> cache;
+    auto it = cache.find((const void *)f);
+    if (it != cache.end()) return it->second;
+    hipFuncAttributes at{};
+    const int n = hipFuncGetAttributes(&at, (const void *)f) == hipSuccess ? at.numRegs : 512;
+    cache[(const void *)f] = n;
+    return n;
+}
+
 // Split-bf16 kernel: 16-channel chunks, one workgroup per CU; LDS = split patch (96 B/position) +
 // fp32 landing area (64 B/position) + two weight-row stages.
 static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p, bool allow_ipw = true) {
@@ -114,8 +128,14 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // variant 2 (patch staged through registers, two workgroups per CU) when it fits
     // weight stages of one kernel row if that fits next to a second workgroup, else one tap each
     int tg = s.KW;
+    const size_t lds_tap = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * 24 * COPT);
     size_t lds2 = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * tg * 24 * COPT);
-    if (lds2 > 80 * 1024) { tg = 1; lds2 = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * 24 * COPT); }
+    if (lds2 > 80 * 1024) { tg = 1; lds2 = lds_tap; }
+    // a third workgroup per CU (+12 % measured on 64->64 @256^2) when single-tap stages bring the LDS
+    // footprint under 160/3 KiB and the kernel's registers allow three waves per SIMD
+    if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !getenv("CDC_NO_TG1"))
+        if (conv_kernel_fn f = conv_lookup_split2(MB, NPW, s.lnmode))
+            if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
     const bool v2 = conv_lookup_split2(MB, NPW, s.lnmode) && plane / 2 <= wpi * 64 && lds2 <= 80 * 1024 &&
                     !getenv("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
@@ -246,7 +266,36 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
               (unsigned)nz);
     dim3 block(64 * p.WN);
+#ifdef CDC_TIMELINE
+    // Development build only: per-workgroup cycle stamps of the split2 kernel, summarised on stderr.
+    static unsigned long long *tl_dev = nullptr;
+    const size_t tl_wgs = (size_t)grid.x * grid.y;
+    a.tl = nullptr;
+    if (p.split == 2 && tl_wgs <= (1u << 16)) {
+        if (!tl_dev) hipMalloc(&tl_dev, sizeof(unsigned long long) * 64 * (1u << 16));
+        hipMemsetAsync(tl_dev, 0, sizeof(unsigned long long) * 64 * tl_wgs, st);
+        a.tl = tl_dev;
+    }
+#endif
     hipLaunchKernelGGL(fn, grid, block, p.lds_bytes, st, a);
+#ifdef CDC_TIMELINE
+    if (a.tl) {
+        hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(64 * tl_wgs);
+        hipMemcpy(h.data(), tl_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double dsum[64] = {0}; size_t dn[64] = {0};
+        for (size_t w = 0; w < tl_wgs; ++w) {
+            const unsigned long long *r = &h[w * 64];
+            if (!r[0]) continue;
+            t0 = std::min(t0, r[0]);
+            for (int k = 1; k < 64 && r[k]; ++k) { dsum[k] += (double)(r[k] - r[k - 1]); dn[k]++; t1 = std::max(t1, r[k]); }
+        }
+        fprintf(stderr, "[timeline] wgs %zu  span %llu cycles; mean delta per stamp:", tl_wgs, t1 - t0);
+        for (int k = 1; k < 64 && dn[k]; ++k) fprintf(stderr, " %d:%.0f", k, dsum[k] / dn[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -239,6 +239,13 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 template <int MB, int NPW, int LNMODE = 0>
 __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef CDC_TIMELINE
+    int tl_n = 0;
+#define TL() do { if (P.tl && threadIdx.x == 0 && tl_n < 64) P.tl[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TL() do { } while (0)
+#endif
+    TL();
     constexpr int COPT = MB * 32;
     constexpr int KC = 16;
     const int tid = threadIdx.x;
@@ -399,15 +406,28 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     load_x(0);
     issue_w(0, 0, 0);
     int wstage = 0;
+    TL();
     for (int chunk = 0; chunk < nc16; ++chunk) {
         if (chunk) __syncthreads();          // everyone finished reading the previous chunk's planes
+        TL();
+#ifndef CDC_AB_NOSTOREX
         store_x(chunk);
-        if (chunk + 1 < nc16) load_x(chunk + 1);     // in flight during the whole tap loop
-        dma_wait();
+#else
+        if (chunk == 0) store_x(chunk);
+#endif
+        TL();
+        dma_wait();                         // first weight stage landed (nothing else is in flight)
         __syncthreads();                    // planes of `chunk` + first weight row visible
+        TL();
+#ifndef CDC_AB_NOLOADX
+        if (chunk + 1 < nc16) load_x(chunk + 1);     // in flight during the tap loop; the group-end
+                                                     // waits cover it (issued >= one group earlier)
+#endif
         for (int grp = 0; grp < ntg; ++grp) {
+#ifndef CDC_AB_NOW
             if (grp + 1 < ntg) issue_w(grp + 1, chunk, wstage ^ 1);
             else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
+#endif
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats);
             const uint4 *xb = reinterpret_cast<const uint4 *>(xc);
             for (int t = 0; t < TG; ++t) {
@@ -437,15 +457,23 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
                         for (int m = 0; m < MB; ++m)
 #pragma unroll
                             for (int n = 0; n < NPW; ++n)
+#ifndef CDC_AB_NOMFMA
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bv[pb][n], acc[m][n],
                                                                                     0, 0, 0);
+#else
+                                acc[m][n][0] += __builtin_bit_cast(float4, A[m]).x * __builtin_bit_cast(float4, Bv[pb][n]).y;
+#endif
                 }
             }
+            TL();
             dma_wait();
+            TL();
             __syncthreads();
+            TL();
             wstage ^= 1;
         }
     }
+    TL();
 
     float prstd[LNMODE == 2 ? NPW : 1];
     if constexpr (LNMODE == 2) {
@@ -457,7 +485,15 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     }
     TileGeom geom{tid, nthr, wave, half, pr, pc, ipw > 1 ? (int)blockIdx.x * ipw : b, z, cog, oy0, ox0, NBH};
     geom.ipw = ipw; geom.wpi = wpi; geom.nimg = P.B;
+#ifdef CDC_AB_NOEPI
+    { float sacc = 0.f;
+      for (int m = 0; m < MB; ++m) for (int n = 0; n < NPW; ++n) for (int r = 0; r < 16; ++r) sacc += acc[m][n][r];
+      if (sacc == 12345.678f) P.out[tid] = sacc; }
+#else
     conv_epilogue<MB, NPW, LNMODE, 0>(P, geom, acc, smem, prstd);
+#endif
+    TL();
+#undef TL
 }
 
 }  // namespace cdc
