@@ -372,9 +372,30 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const int n_w = TG * 6 * COPT;
     const int wsl = (n_w + nthr - 1) / nthr;
     const unsigned short *wsrc = P.wsp + (size_t)z * P.wsp_zs + (size_t)cog * COPT * 8;
+    // Per-thread byte offsets of its units inside one (group, chunk) weight stage: they do not depend on
+    // the group or the chunk (those move the scalar base), so the in-loop DMA issue is address-free.
+    // A stage has TG*6*COPT units = a whole number of waves, so the tail test is wave-uniform.
+    constexpr int kWS = 5;
+    unsigned wvo[kWS];
+#pragma unroll
+    for (int i = 0; i < kWS; ++i) {
+        const int e = min(tid + i * nthr, n_w - 1);
+        const int t = e / (6 * COPT);
+        const int rem = e - t * 6 * COPT;
+        const int pk = rem / COPT, co = rem - pk * COPT;
+        wvo[i] = (unsigned)(((t * nc16) * 6 + pk) * P.COP + co) * 16u;
+    }
+    const bool w_fast = wsl <= kWS;
     auto issue_w = [&](int grp, int chunk, int stage) {
         const unsigned short *base = wsrc + ((size_t)(grp * TG) * nc16 + chunk) * 6 * P.COP * 8;
         const float *wbase = uniform_ptr(reinterpret_cast<const float *>(base));
+        const unsigned dst = wl_lds + (unsigned)(stage * wst_floats) * 4u + (unsigned)(wave * 64) * 16u;
+        if (w_fast) {
+#pragma unroll
+            for (int i = 0; i < kWS; ++i)
+                if (i * nthr + wave * 64 < n_w) dma_b128_s(wvo[i], wbase, dst + (unsigned)(i * nthr) * 16u);
+            return;
+        }
         for (int i = 0; i < wsl; ++i) {
             const int e = tid + i * nthr;
             if (e < n_w) {
@@ -382,8 +403,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
                 const int rem = e - t * 6 * COPT;
                 const int pk = rem / COPT, co = rem - pk * COPT;
                 const unsigned voff = (unsigned)(((t * nc16) * 6 + pk) * P.COP + co) * 16u;
-                dma_b128_s(voff, wbase, wl_lds + (unsigned)(stage * wst_floats) * 4u +
-                                            (unsigned)(i * nthr + wave * 64) * 16u);
+                dma_b128_s(voff, wbase, dst + (unsigned)(i * nthr) * 16u);
             }
         }
     };
@@ -402,6 +422,14 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     const int b_lane = half * plane + (rb * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
     const int nb_stride = NBH * P.stride * PW;
     const int a_lane = half * COPT + j;
+    int bidx[3][NPW];                                 // B-operand unit index of tap (0,0), per plane / block
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            bidx[p][n] = (p * 2) * plane + b_lane + n * nb_stride;
+            asm volatile("" : "+v"(bidx[p][n]));      // keep it a plain per-lane index (+ scalar tap offset)
+        }
 
     load_x(0);
     issue_w(0, 0, 0);
@@ -428,29 +456,24 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
             if (grp + 1 < ntg) issue_w(grp + 1, chunk, wstage ^ 1);
             else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
 #endif
-            const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats);
-            const uint4 *xb = reinterpret_cast<const uint4 *>(xc);
+            const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats) + a_lane;
+            int ky = (grp * TG) / P.KW, kx = grp * TG - ky * P.KW;      // uniform tap walk (SALU)
             for (int t = 0; t < TG; ++t) {
-                const int tap = grp * TG + t;
-                const int ky = tap / P.KW, kx = tap - ky * P.KW;
+                const uint4 *xb = reinterpret_cast<const uint4 *>(xc) + (ky * PW + kx);
+                if (++kx == P.KW) { kx = 0; ++ky; }
                 // B planes stay live for the tap; the A planes are fetched one at a time, smallest
                 // first: plane 2 feeds one product term, plane 1 two, plane 0 three (six in all)
                 bf16x8 Bv[3][NPW];
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
 #pragma unroll
-                    for (int n = 0; n < NPW; ++n) {
-                        const uint4 v = xb[(p * 2) * plane + b_lane + ky * PW + kx + n * nb_stride];
-                        Bv[p][n] = __builtin_bit_cast(bf16x8, v);
-                    }
+                    for (int n = 0; n < NPW; ++n) Bv[p][n] = __builtin_bit_cast(bf16x8, xb[bidx[p][n]]);
 #pragma unroll
                 for (int pa = 2; pa >= 0; --pa) {
                     bf16x8 A[MB];
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const uint4 v = wa[(t * 6 + pa * 2) * COPT + a_lane + m * 32];
-                        A[m] = __builtin_bit_cast(bf16x8, v);
-                    }
+                    for (int m = 0; m < MB; ++m)
+                        A[m] = __builtin_bit_cast(bf16x8, wa[(t * 6 + pa * 2) * COPT + m * 32]);
 #pragma unroll
                     for (int pb = 2 - pa; pb >= 0; --pb)
 #pragma unroll
