@@ -646,6 +646,33 @@ __global__ void __launch_bounds__(256) copy_kernel(const float *src, long long s
         d[i] = s[i];
 }
 
+// Column unfold for few-channel k x k convolutions (the first 7x7 layer, unet.py:31 / nc.py:104):
+// dst[kx*C + c][y][x] = src[c][y][x + kx - pad] (zero outside), so the layer becomes a KH x 1
+// convolution over KW*C channels and runs on the split-bf16 kernel instead of the fp32 MFMA path.
+__global__ void __launch_bounds__(256) unfold_x_kernel(const float *src, long long src_bs, float *dst,
+                                                       long long dst_bs, int C, int KW, int pad, int H, int W) {
+    const int b = blockIdx.z, cc = blockIdx.y;          // cc = kx * C + c
+    const int kx = cc / C, c = cc - kx * C;
+    const float *s = src + (size_t)b * src_bs + (size_t)c * H * W;
+    float *d = dst + (size_t)b * dst_bs + (size_t)cc * H * W;
+    const int W4 = W >> 2, n4 = H * W4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const int y = i / W4, x0 = (i - y * W4) * 4 + kx - pad;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (x0 + t >= 0 && x0 + t < W) ? s[y * W + x0 + t] : 0.f;
+        *reinterpret_cast<float4 *>(d + (size_t)y * W + (i - y * W4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+hipError_t unfold_x_launch(const float *src, long long src_bs, float *dst, long long dst_bs, int C, int KW,
+                           int pad, int H, int W, int B, hipStream_t st) {
+    const int gx = std::min((H * (W >> 2) + 255) / 256, 256);
+    hipLaunchKernelGGL(unfold_x_kernel, dim3(gx, C * KW, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, C, KW,
+                       pad, H, W);
+    return hipGetLastError();
+}
+
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
                                 long long n, int B, hipStream_t st) {
     const int gx = (int)std::min<long long>((n + 255) / 256, 2048);

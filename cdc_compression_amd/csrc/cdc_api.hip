@@ -51,13 +51,14 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
                    ConvW c1, c2, cres; float *g1, *b1, *g2, *b2, *mlp_w, *mlp_b;
                    // context hoisting: input = cat(x [hoist_cx ch], ctx); the ctx halves of block1 and
                    // res_conv are step-invariant, so they are split off and evaluated once per decode
-                   int hoist_cx = 0; ConvW c1x, c1c, cresx, cresc; };
+                   int hoist_cx = 0; ConvW c1x, c1c, cresx, cresc;
+                  ConvW c1u; bool has_unfold = false; };   // c1x as a KH x 1 conv over KW*cx unfolded channels
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
                ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr; };   // folded output; uq = Wq b_ln
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD } kind;
     int prof = PC_SMALL;
     int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
     char label[96] = {0};
@@ -71,6 +72,7 @@ struct Op {
     struct { const float *P, *bias; float *out; int Cout, KH, pad, H, W; } cb;
     DdimArgs ddim;
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
+    struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
 };
 
 }  // namespace
@@ -367,6 +369,22 @@ int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k,
     if (hoist_cx > 0) {
         const std::string w1 = p + ".block1.block.0.weight", b1 = p + ".block1.block.0.bias";
         if ((rc = pack_named_conv(h, w1, "", 1, k / 2, false, &rb.c1x, 0, hoist_cx))) return rc;
+        if (k > 3 && hoist_cx * k <= 32 && !getenv("CDC_NO_UNFOLD")) {
+            // column-unfolded form of the few-channel k x k layer: w'[co][kx*cx + c][ky][0] = w[co][c][ky][kx]
+            const Param &pw = h->params[h->pindex.at(w1)];
+            const int co_n = (int)pw.shape[0], ci_n = (int)pw.shape[1], cu = hoist_cx * k;
+            std::vector<float> wu((size_t)co_n * cu * k);
+            for (int co = 0; co < co_n; ++co)
+                for (int c = 0; c < hoist_cx; ++c)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            wu[((size_t)co * cu + kx * hoist_cx + c) * k + ky] =
+                                pw.host[(((size_t)co * ci_n + c) * k + ky) * k + kx];
+            if ((rc = pack_conv(h, wu.data(), nullptr, co_n, cu, k, 1, 1, 0, false, &rb.c1u, &h->weight_allocs)))
+                return rc;
+            rb.c1u.pad_y = k / 2; rb.c1u.pad_x = 0;
+            rb.has_unfold = rb.c1u.wsp != nullptr;
+        }
         if ((rc = pack_named_conv(h, w1, b1, 1, k / 2, false, &rb.c1c, hoist_cx, cin - hoist_cx)))
             return rc;
         if (rb.has_res) {
@@ -464,7 +482,7 @@ struct Builder {
         op.id = (int)h->op_ms.size();
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
-        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy"};
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold"};
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
@@ -680,6 +698,15 @@ struct Builder {
                 copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
             }
             cur = saved;
+            if (rb.has_unfold && (W & 3) == 0) {
+                Act u = new_act(a0.C * rb.k, H, W);
+                Op uo; uo.kind = Op::UNFOLD; uo.prof = prof1;
+                uo.uf = {a0.p, a0.bs(), u.p, u.bs(), a0.C, rb.k, rb.k / 2, H, W};
+                uo.bytes = 4.0 * B * (a0.C + u.C) * HW;
+                emit(uo);
+                block(rb.c1u, u.p, u.C, u.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
+                      nullptr, nullptr, prof1);
+            } else
             block(rb.c1x, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
                   nullptr, nullptr, prof1);
             if (rb.has_res) {
@@ -954,6 +981,10 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
                                            op.cb.H, op.cb.W, B, st));
             break;
         case Op::DDIM: HIP_TRY(h, ddim_launch(op.ddim, st)); break;
+        case Op::UNFOLD:
+            HIP_TRY(h, unfold_x_launch(op.uf.src, op.uf.src_bs, op.uf.dst, op.uf.dst_bs, op.uf.C, op.uf.KW,
+                                       op.uf.pad, op.uf.H, op.uf.W, B, st));
+            break;
         case Op::COPY:
             HIP_TRY(h, copy_channels_launch(op.cp.src, op.cp.src_bs, op.cp.dst, op.cp.dst_bs, op.cp.n,
                                             B, st));

@@ -236,8 +236,13 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 
 // LNMODE 2 (1x1 only): PreNorm LayerNorm folded as in conv_kernel.h -- the pixel mean is subtracted before
 // the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
+// three workgroups per CU wherever the accumulators leave room (<= 168 VGPRs)
+constexpr int split2_min_wgs(int MB, int NPW, int LNMODE) {
+    return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (MB * NPW == 3 && LNMODE == 2))) ? 3 : 2;
+}
+
 template <int MB, int NPW, int LNMODE = 0>
-__global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
+__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_split2_kernel(const ConvArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef CDC_TIMELINE
     int tl_n = 0;
@@ -321,9 +326,22 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
         }
     }
     float4 xr[kXR];
+    // byte offset of the unit's first channel row inside a 16-channel chunk: the chunk / channel part of
+    // the address is wave-uniform and goes into the scalar base (global_load ... v, s[base])
+    const unsigned xvo = xsp >= 0 ? ((unsigned)(ukg * 8) * HW + (unsigned)xsp) * 4u : 0u;
     auto load_x = [&](int chunk) {
         const int cbase = chunk * KC;
         const float *xbase = cbase < P.C0 ? s0 + (size_t)cbase * HW : s1 + (size_t)(cbase - P.C0) * HW;
+        if (cbase + KC <= P.Cin) {
+#pragma unroll
+            for (int i = 0; i < kXR; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const char *rowb = reinterpret_cast<const char *>(xbase + (size_t)i * HW);
+                if (xsp >= 0) v = *reinterpret_cast<const float4 *>(rowb + xvo);
+                xr[i] = v;
+            }
+            return;
+        }
         const int ncm1 = min(KC, P.Cin - cbase) - 1;  // channel tail: re-read the last valid (weights 0)
 #pragma unroll
         for (int i = 0; i < kXR; ++i) {
@@ -376,14 +394,28 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
     // the group or the chunk (those move the scalar base), so the in-loop DMA issue is address-free.
     // A stage has TG*6*COPT units = a whole number of waves, so the tail test is wave-uniform.
     constexpr int kWS = 5;
-    unsigned wvo[kWS];
+    constexpr bool kWaveRows = MB % 2 == 0;           // a wave's 64 units never straddle a (tap, plane) row
+    unsigned wvo[kWaveRows ? 1 : kWS];                // per-lane part
+    unsigned wso[kWS];                                // wave-uniform part (SGPRs)
+    if constexpr (kWaveRows) {
+        wvo[0] = (unsigned)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < kWS; ++i) {
-        const int e = min(tid + i * nthr, n_w - 1);
-        const int t = e / (6 * COPT);
-        const int rem = e - t * 6 * COPT;
-        const int pk = rem / COPT, co = rem - pk * COPT;
-        wvo[i] = (unsigned)(((t * nc16) * 6 + pk) * P.COP + co) * 16u;
+        for (int i = 0; i < kWS; ++i) {
+            const int u = min(wave + i * WN, n_w / 64 - 1);
+            const int row = u / (COPT / 64), seg = u - row * (COPT / 64);
+            const int t = row / 6, pk = row - t * 6;
+            wso[i] = (unsigned)(((t * nc16) * 6 + pk) * P.COP + seg * 64) * 16u;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kWS; ++i) {
+            const int e = min(tid + i * nthr, n_w - 1);
+            const int t = e / (6 * COPT);
+            const int rem = e - t * 6 * COPT;
+            const int pk = rem / COPT, co = rem - pk * COPT;
+            wvo[i] = (unsigned)(((t * nc16) * 6 + pk) * P.COP + co) * 16u;
+            wso[i] = 0;
+        }
     }
     const bool w_fast = wsl <= kWS;
     auto issue_w = [&](int grp, int chunk, int stage) {
@@ -393,7 +425,9 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvArgs P) {
         if (w_fast) {
 #pragma unroll
             for (int i = 0; i < kWS; ++i)
-                if (i * nthr + wave * 64 < n_w) dma_b128_s(wvo[i], wbase, dst + (unsigned)(i * nthr) * 16u);
+                if (i * nthr + wave * 64 < n_w)
+                    dma_b128_s(wvo[kWaveRows ? 0 : i], reinterpret_cast<const float *>(
+                                   reinterpret_cast<const char *>(wbase) + wso[i]), dst + (unsigned)(i * nthr) * 16u);
             return;
         }
         for (int i = 0; i < wsl; ++i) {

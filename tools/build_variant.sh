@@ -5,10 +5,10 @@
 set -eu
 NAME="$1"; EXTRA="${2:-}"
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-SRC="$ROOT/cdc_compression_amd/csrc"; OBJ="/tmp/cdc_variant_$NAME"; mkdir -p "$OBJ"
+SRC="${SRC_DIR:-$ROOT/cdc_compression_amd/csrc}"; OBJ="/tmp/cdc_variant_$NAME"; mkdir -p "$OBJ"
 pids=()
 for f in "$SRC"/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$SRC" -Wno-unused-result $EXTRA -c "$f" -o "$OBJ/$(basename "$f" .hip).o" &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$SRC" -I"$SRC/../../include" -Wno-unused-result $EXTRA -c "$f" -o "$OBJ/$(basename "$f" .hip).o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
