@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
     for (int i = 0; i < kLnCache; ++i) {
         const int c = cs + 8 * i;
         v[i] = (pv && c < a.C) ? x[(size_t)c * a.HW] : 0.f;
+        for (int k = 1; k < a.nparts; ++k)            // split-K slices of the producing convolution
+            v[i] += (pv && c < a.C) ? x[(size_t)k * a.part_stride + (size_t)c * a.HW] : 0.f;
         s += v[i];
     }
     red[cs][pl] = s;
@@ -166,6 +168,7 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
 }
 
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
+    if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache) {
         hipLaunchKernelGGL(ln_kernel_sliced, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
                            st, a);

@@ -484,9 +484,9 @@ struct Builder {
         char buf[160];
         const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold"};
         if (op.kind == Op::CONV)
-            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d%s%s%s%s", op.conv.KH,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.split == 2 ? " SPLIT2" : (op.plan.split ? " SPLIT" : ""),
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? " SPLIT2" : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)
@@ -530,7 +530,9 @@ struct Builder {
         int shift_bs = -1;                             // row stride of `shift` (-1: the U-Net's table)
         long long w_bs = 0;
         bool no_bias = false;
+        int max_ksplit = 1;                            // > 1: `out` has room for that many partial-sum planes
     };
+    int last_ksplit = 1;                               // slices the last conv() call really used
 
     // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
@@ -566,6 +568,15 @@ struct Builder {
             rc = fail(h, CDC_ERR_UNSUPPORTED, "no launch plan for conv Cin=%d Cout=%d k=%dx%d out=%dx%d",
                       w.Cin, w.Cout, w.KH, w.KW, s.Ho, s.Wo);
             return true;
+        }
+        last_ksplit = 1;
+        if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !getenv("CDC_NO_KSPLIT")) {
+            // few workgroups and a long K loop (low-resolution levels): slice K so that the chip holds
+            // >= 4 workgroups per CU; the LayerNorm kernel that follows adds the slices
+            const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
+                                  plan.groups * w.nz;
+            int ks = (int)std::min<long long>(ceil_div(1024, wgs), std::min(o.max_ksplit, plan.nchunk / 4));
+            if (ks > 1) { plan.ksplit = ks; last_ksplit = ks; }
         }
         if (getenv("CDC_DEBUG_PLAN"))
             fprintf(stderr, "[plan] %-10s Cin=%4d Cout=%4d k=%dx%d s=%d in=%3dx%-3d out=%3dx%-3d %s%s%s| MB=%2d NPW=%d "
@@ -604,6 +615,7 @@ struct Builder {
         a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
+        a.out_ks = (long long)B * out_bs;
         const double px = (double)B * s.Ho * s.Wo * w.nz;
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
@@ -612,11 +624,12 @@ struct Builder {
     }
 
     void ln(const float *in, float *out, int C, int HW, const float *g, const float *b, int relu,
-            const float *shift, const float *resid, float *sm, float *sr) {
+            const float *shift, const float *resid, float *sm, float *sr, int nparts = 1) {
         if (rc) return;
         Op op;
         op.kind = Op::LN; op.prof = PC_LN;
         LnArgs &a = op.ln;
+        a.nparts = nparts; a.part_stride = (long long)B * C * HW;
         a.in = in; a.out = out; a.C = C; a.HW = HW; a.g = g; a.b = b; a.eps = 1e-5f; a.relu = relu;
         a.shift = shift; a.shift_bs = h->shift_bs; a.resid = resid; a.stat_mean = sm; a.stat_rstd = sr;
         op.bytes = 4.0 * B * C * HW * (out ? 2 : 1);
@@ -667,6 +680,16 @@ struct Builder {
             return;
         ConvOpts u;
         u.pre_add = pre_add; u.no_bias = o.no_bias;
+        const size_t plane_f = (size_t)B * w.Cout * H * W;
+        if (!pre_add && w.wsp && w.Cout <= 8 * 48 && plane_f * 4 * 4 <= (160u << 20)) {
+            // low-resolution levels: split-K partial sums into scratch, summed by the LayerNorm kernel
+            const int kmax = 4;
+            float *part = dalloc(plane_f * kmax);
+            u.max_ksplit = kmax;
+            conv(w, s0, C0, bs0, s1, bs1, H, W, part, out.bs(), u, false, prof);
+            ln(part, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr, last_ksplit);
+            return;
+        }
         conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), u, false, prof);
         ln(out.p, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr);
     }

@@ -51,6 +51,8 @@ struct LnArgs {
     int shift_bs;
     const float *resid;       // same layout as in, or null
     float *stat_mean, *stat_rstd;   // [B][HW] statistics of the FINAL values, or null
+    int nparts;               // > 1: `in` holds split-K partial sums, slice k at in + k*part_stride
+    long long part_stride;
 };
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st);
 

@@ -60,6 +60,11 @@ struct ConvArgs {
     long long resid_bs, resid_cs;
     float *stat_mean, *stat_rstd;   // [B][Ho*Wo]: LN statistics of the final values (for the next
                                     // PreNorm); needs gridDim.y == 1
+    // split-K (conv_split2_kernel, plain bias-only epilogue): gridDim.z = nzz * ksplit; slice ks handles chunks
+    // [ks*nchunk/ksplit, (ks+1)*nchunk/ksplit) and stores its partial sums at out + ks*out_ks (bias in
+    // slice 0); the consumer (ln_kernel_sliced) adds the slices.
+    int ksplit, nzz;
+    long long out_ks;
 #ifdef CDC_TIMELINE
     unsigned long long *tl;         // tools/build_variant.sh timeline -DCDC_TIMELINE: 64 cycle stamps per workgroup
 #endif
@@ -76,6 +81,7 @@ struct ConvPlan {
     int lnmode;
     int tg;                 // taps per weight stage of the split kernels
     int ipw;                // images per workgroup (1: tiles inside one image)
+    int ksplit = 1;         // K slices (split2 only)
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 

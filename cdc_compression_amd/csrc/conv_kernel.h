@@ -63,6 +63,8 @@ struct TileGeom {      // where this workgroup / lane sits (shared by the kernel
     int tid, nthr, wave, half, pr, pc, b, z, cog, oy0, ox0, NBH;
     // small feature maps: a workgroup covers ipw images, wpi waves each (b = first image; default 1 image)
     int ipw = 1, wpi = 4, nimg = 1 << 30;
+    long long out_off = 0;      // split-K: this slice's partial-sum plane
+    bool no_bias = false;       // split-K: slices > 0
 };
 
 // Fused epilogue on the MFMA accumulators (C/D layout of the 32x32 forms: lane = pixel l&31, register
@@ -84,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
     for (int i = tid; i < COPT; i += nthr) {
         const int co = cog * COPT + i;
         const bool ok = co < P.Cout;
-        ep[i] = (ok && P.bias) ? P.bias[co] : 0.f;
+        ep[i] = (ok && P.bias && !g.no_bias) ? P.bias[co] : 0.f;
         ep[COPT + i] = (ok && P.ep_g) ? P.ep_g[co] : 0.f;
         ep[2 * COPT + i] = (ok && P.ep_b) ? P.ep_b[co] : 0.f;
         for (int q = 0; q < g.ipw; ++q)
@@ -224,7 +226,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
             if (valid) P.out[(size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs] = t;
             continue;
         }
-        float *op = P.out + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
+        float *op = P.out + g.out_off + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m * 32 + 32 <= nvalid) {

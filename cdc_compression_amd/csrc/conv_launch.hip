@@ -136,7 +136,19 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !getenv("CDC_NO_TG1"))
         if (conv_kernel_fn f = conv_lookup_split2(MB, NPW, s.lnmode))
             if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
-    const bool v2 = conv_lookup_split2(MB, NPW, s.lnmode) && plane / 2 <= wpi * 64 && lds2 <= 80 * 1024 &&
+    // Few workgroups (low-resolution levels): the chip cannot hide the weight-stage latency by occupancy,
+    // so stage ALL taps of a chunk at once -- one barrier and one DMA wait per 16 channels, and the DMA of
+    // the next chunk has a whole chunk of matrix work to land.
+    {
+        const int taps = s.KH * s.KW;
+        const long long wgs = (long long)(ipw > 1 ? ceil_div(s.B, ipw) : ceil_div(s.Wo, NBW) * ceil_div(s.Ho, TH) * s.B) *
+                              (nblocks / MB) * s.nz;
+        const size_t lds_all = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * taps * 24 * COPT);
+        static const char *force = getenv("CDC_TGALL");
+        const bool few = wgs <= 3 * 256 && lds_all <= 72 * 1024;
+        if (taps > tg && ((force && atoi(force) && lds_all <= 150 * 1024) || (!force && few))) { tg = taps; lds2 = lds_all; }
+    }
+    const bool v2 = conv_lookup_split2(MB, NPW, s.lnmode) && plane / 2 <= wpi * 64 && lds2 <= 150 * 1024 &&
                     !getenv("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
     if (!v2 && (s.lnmode != 0 || !conv_lookup_split(MB, NPW) || 4 * plane > kXS * nthr)) return false;
@@ -244,6 +256,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.xvec = p.xvec;
     a.tg = p.tg;
     a.ipw = p.ipw;
+    a.ksplit = p.split == 2 ? std::max(1, p.ksplit) : 1;
+    a.nzz = nz;
     a.B = B;
     for (int z = 0; z < 4; ++z) a.xshift[z] = p.xshift[z];
     const int xv = p.xvec ? 4 : 1;
@@ -264,7 +278,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
         if (e != hipSuccess) return e;
     }
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
-              (unsigned)nz);
+              (unsigned)(nz * a.ksplit));
     dim3 block(64 * p.WN);
 #ifdef CDC_TIMELINE
     // Development build only: per-workgroup cycle stamps of the split2 kernel, summarised on stderr.

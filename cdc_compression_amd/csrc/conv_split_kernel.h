@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int WN = nthr >> 6;
-    const int z = blockIdx.z;
+    int z = blockIdx.z, ks = 0;
+    if (P.ksplit > 1) { ks = z / P.nzz; z -= ks * P.nzz; }
     const int cog = blockIdx.y;
 
     const int NBW = 1 << P.lognbw;
@@ -393,7 +394,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
     // Per-thread byte offsets of its units inside one (group, chunk) weight stage: they do not depend on
     // the group or the chunk (those move the scalar base), so the in-loop DMA issue is address-free.
     // A stage has TG*6*COPT units = a whole number of waves, so the tail test is wave-uniform.
-    constexpr int kWS = 5;
+    constexpr int kWS = 7;
     constexpr bool kWaveRows = MB % 2 == 0;           // a wave's 64 units never straddle a (tap, plane) row
     unsigned wvo[kWaveRows ? 1 : kWS];                // per-lane part
     unsigned wso[kWS];                                // wave-uniform part (SGPRs)
@@ -465,30 +466,32 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
             asm volatile("" : "+v"(bidx[p][n]));      // keep it a plain per-lane index (+ scalar tap offset)
         }
 
-    load_x(0);
-    issue_w(0, 0, 0);
+    const int c_lo = P.ksplit > 1 ? ks * nc16 / P.ksplit : 0;
+    const int c_hi = P.ksplit > 1 ? (ks + 1) * nc16 / P.ksplit : nc16;
+    load_x(c_lo);
+    issue_w(0, c_lo, 0);
     int wstage = 0;
     TL();
-    for (int chunk = 0; chunk < nc16; ++chunk) {
-        if (chunk) __syncthreads();          // everyone finished reading the previous chunk's planes
+    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+        if (chunk > c_lo) __syncthreads();          // everyone finished reading the previous chunk's planes
         TL();
 #ifndef CDC_AB_NOSTOREX
         store_x(chunk);
 #else
-        if (chunk == 0) store_x(chunk);
+        if (chunk == c_lo) store_x(chunk);
 #endif
         TL();
         dma_wait();                         // first weight stage landed (nothing else is in flight)
         __syncthreads();                    // planes of `chunk` + first weight row visible
         TL();
 #ifndef CDC_AB_NOLOADX
-        if (chunk + 1 < nc16) load_x(chunk + 1);     // in flight during the tap loop; the group-end
+        if (chunk + 1 < c_hi) load_x(chunk + 1);     // in flight during the tap loop; the group-end
                                                      // waits cover it (issued >= one group earlier)
 #endif
         for (int grp = 0; grp < ntg; ++grp) {
 #ifndef CDC_AB_NOW
             if (grp + 1 < ntg) issue_w(grp + 1, chunk, wstage ^ 1);
-            else if (chunk + 1 < nc16) issue_w(0, chunk + 1, wstage ^ 1);
+            else if (chunk + 1 < c_hi) issue_w(0, chunk + 1, wstage ^ 1);
 #endif
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats) + a_lane;
             int ky = (grp * TG) / P.KW, kx = grp * TG - ky * P.KW;      // uniform tap walk (SALU)
@@ -542,6 +545,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
     }
     TileGeom geom{tid, nthr, wave, half, pr, pc, ipw > 1 ? (int)blockIdx.x * ipw : b, z, cog, oy0, ox0, NBH};
     geom.ipw = ipw; geom.wpi = wpi; geom.nimg = P.B;
+    geom.out_off = (long long)ks * P.out_ks; geom.no_bias = ks > 0;
 #ifdef CDC_AB_NOEPI
     { float sacc = 0.f;
       for (int m = 0; m < MB; ++m) for (int n = 0; n < NPW; ++n) for (int r = 0; r < 16; ++r) sacc += acc[m][n][r];
