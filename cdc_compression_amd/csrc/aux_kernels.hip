@@ -498,6 +498,9 @@ __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, c
         float acc[kFoldRows];
 #pragma unroll
         for (int r = 0; r < kFoldRows; ++r) acc[r] = 0.f;
+        // C % 8 == 0 on the folded levels; batches of 8 independent loads hide the L2 latency of this
+        // otherwise serial (load -> 8 FMAs) chain
+#pragma unroll 8
         for (int e = 0; e < C; ++e) {
             const float w = WoT[(size_t)e * C + c];
 #pragma unroll
@@ -525,6 +528,7 @@ __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const floa
         for (int r = 0; r < kFoldRows; ++r) acc[r] = 0.f;
         if (c < C) {
             const float *t = T1 + (size_t)b * C * C + c;
+#pragma unroll 8
             for (int d = 0; d < C; ++d) {
                 const float w = t[(size_t)d * C];
 #pragma unroll

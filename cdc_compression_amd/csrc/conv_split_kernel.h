@@ -238,7 +238,7 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 // the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
 // three workgroups per CU wherever the accumulators leave room (<= 168 VGPRs)
 constexpr int split2_min_wgs(int MB, int NPW, int LNMODE) {
-    return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (MB * NPW == 3 && LNMODE == 2))) ? 3 : 2;
+    return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (LNMODE == 2 && (MB * NPW == 3 || (MB == 4 && NPW == 1))))) ? 3 : 2;
 }
 
 template <int MB, int NPW, int LNMODE = 0>
