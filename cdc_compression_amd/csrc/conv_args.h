@@ -82,6 +82,7 @@ struct ConvPlan {
     int tg;                 // taps per weight stage of the split kernels
     int ipw;                // images per workgroup (1: tiles inside one image)
     int ksplit = 1;         // K slices (split2 only)
+    int xu = 1;             // patch units per thread (split2 only)
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 

@@ -17,7 +17,14 @@ conv_kernel_fn conv_lookup_split(int MB, int NPW) {
     if (MB == 6 && NPW == 1) return conv_split_kernel<6, 1>;
     return nullptr;
 }
-conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode) {
+conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu) {
+    if (xu == 2) {
+        if (lnmode != 0) return nullptr;
+        if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1, 0, 2>;
+        if (MB == 2 && NPW == 1) return conv_split2_kernel<2, 1, 0, 2>;
+        if (MB == 3 && NPW == 1) return conv_split2_kernel<3, 1, 0, 2>;
+        return nullptr;
+    }
     if (lnmode == 0) {
         if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1>;
         if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2>;

@@ -134,7 +134,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // a third workgroup per CU (+12 % measured on 64->64 @256^2) when single-tap stages bring the LDS
     // footprint under 160/3 KiB and the kernel's registers allow three waves per SIMD
     if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !getenv("CDC_NO_TG1"))
-        if (conv_kernel_fn f = conv_lookup_split2(MB, NPW, s.lnmode))
+        if (conv_kernel_fn f = conv_lookup_split2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
             if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
     // Few workgroups (low-resolution levels): the chip cannot hide the weight-stage latency by occupancy,
     // so stage ALL taps of a chunk at once -- one barrier and one DMA wait per 16 channels, and the DMA of
@@ -148,8 +148,10 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
         const bool few = wgs <= 3 * 256 && lds_all <= 72 * 1024;
         if (taps > tg && ((force && atoi(force) && lds_all <= 150 * 1024) || (!force && few))) { tg = taps; lds2 = lds_all; }
     }
-    const bool v2 = conv_lookup_split2(MB, NPW, s.lnmode) && plane / 2 <= wpi * 64 && lds2 <= 150 * 1024 &&
-                    !getenv("CDC_NO_SPLIT2");
+    // patch units per thread: stride 2 always runs the two-unit / parity-plane variant
+    const int xu = s.stride == 2 ? 2 : 1;
+    const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && conv_lookup_split2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
+                    (xu == 1 || (s.Ho * s.Wo >= 256 && !getenv("CDC_NO_XU2"))) && !getenv("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
     if (!v2 && (s.lnmode != 0 || !conv_lookup_split(MB, NPW) || 4 * plane > kXS * nthr)) return false;
     const size_t lds = v2 ? lds2 : sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);
@@ -169,6 +171,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->split = v2 ? 2 : 1;
     p->tg = v2 ? tg : s.KW;
     p->ipw = ipw;
+    p->xu = v2 ? xu : 1;
     return true;
 }
 
@@ -264,7 +267,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
-    conv_kernel_fn fn = p.split == 2 ? conv_lookup_split2(p.MB, p.NPW, p.lnmode)
+    conv_kernel_fn fn = p.split == 2 ? conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu)
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
     if (ablate && p.split == 1)
         if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;

@@ -237,12 +237,17 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 // LNMODE 2 (1x1 only): PreNorm LayerNorm folded as in conv_kernel.h -- the pixel mean is subtracted before
 // the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
 // three workgroups per CU wherever the accumulators leave room (<= 168 VGPRs)
-constexpr int split2_min_wgs(int MB, int NPW, int LNMODE) {
+constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1) {
+    if (XU > 1) return 2;
     return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (LNMODE == 2 && (MB * NPW == 3 || (MB == 4 && NPW == 1))))) ? 3 : 2;
 }
 
-template <int MB, int NPW, int LNMODE = 0>
-__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_split2_kernel(const ConvArgs P) {
+// XU = patch units per thread (2 for the large stride-2 patches).  Stride 2 keeps the even and the odd
+// patch columns in separate half-rows of the LDS planes, so that the B-operand reads of a tap (every
+// other column) are contiguous 16-byte units instead of a 2-way bank conflict.
+template <int MB, int NPW, int LNMODE = 0, int XU = 1>
+__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU)) conv_split2_kernel(const ConvArgs P) {
+    static_assert(XU == 1 || LNMODE == 0, "two-unit variant carries no LayerNorm-on-load");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef CDC_TIMELINE
     int tl_n = 0;
@@ -300,15 +305,22 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
     // pixels = 8 float4 registers; after the split it becomes 4 pixels x 3 planes of 16-byte units
     // (host guarantees 2 * PH * PW/4 <= blockDim.x: one unit per thread)
     const int units = plane / 2;                      // 2 * plane / 4
-    int xsp = -2, ukg = 0, urc = 0;                   // -2: no unit, -1: zero padding, else iy*W+ix
-    if (uid < units) {
-        ukg = uid >= plane / 4 ? 1 : 0;
-        const unsigned rem = uid - ukg * (plane / 4);
-        const unsigned r = fdiv(rem, P.magic_w);      // / (PW / 4)
-        const unsigned col = (rem - r * (unsigned)(PW / 4)) * 4;
-        urc = (int)(r * PW + col);
-        const int iy = iy0 + (int)r, ix = ix0 - P.xshift[z] + (int)col;
-        xsp = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? iy * P.W + ix : -1;
+    constexpr bool s2 = XU == 2;                      // the two-unit variant IS the stride-2 variant (host-enforced)
+    const int ustep1 = s2 ? PW / 2 : 1, ustep2 = s2 ? 1 : 2;   // LDS position of unit pixel t: base + (t&1)*ustep1 + (t>>1)*ustep2
+    int xsp[XU], ukg[XU], urc[XU];                    // xsp -2: no unit, -1: zero padding, else iy*W+ix
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        xsp[u] = -2; ukg[u] = 0; urc[u] = 0;
+        const int id = uid + u * team;
+        if (id < units) {
+            ukg[u] = id >= plane / 4 ? 1 : 0;
+            const unsigned rem = id - ukg[u] * (plane / 4);
+            const unsigned r = fdiv(rem, P.magic_w);      // / (PW / 4)
+            const unsigned col = (rem - r * (unsigned)(PW / 4)) * 4;
+            urc[u] = (int)(r * PW + (s2 ? col >> 1 : col));
+            const int iy = iy0 + (int)r, ix = ix0 - P.xshift[z] + (int)col;
+            xsp[u] = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? iy * P.W + ix : -1;
+        }
     }
     const unsigned HW = (unsigned)(P.H * P.W);
     const float *s0 = P.src0 + (size_t)b * P.src0_bs;
@@ -317,74 +329,84 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
     float umean[4] = {0.f, 0.f, 0.f, 0.f};          // LNMODE 1/2: statistics of the unit's 4 pixels
     float urstd[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (LNMODE != 0) {
-        if (xsp >= 0) {
-            const float4 m4 = *reinterpret_cast<const float4 *>(P.ln_mean + (size_t)b * HW + (unsigned)xsp);
+        if (xsp[0] >= 0) {
+            const float4 m4 = *reinterpret_cast<const float4 *>(P.ln_mean + (size_t)b * HW + (unsigned)xsp[0]);
             umean[0] = m4.x; umean[1] = m4.y; umean[2] = m4.z; umean[3] = m4.w;
             if constexpr (LNMODE == 1) {
-                const float4 r4 = *reinterpret_cast<const float4 *>(P.ln_rstd + (size_t)b * HW + (unsigned)xsp);
+                const float4 r4 = *reinterpret_cast<const float4 *>(P.ln_rstd + (size_t)b * HW + (unsigned)xsp[0]);
                 urstd[0] = r4.x; urstd[1] = r4.y; urstd[2] = r4.z; urstd[3] = r4.w;
             }
         }
     }
-    float4 xr[kXR];
+    float4 xr[XU][kXR];
     // byte offset of the unit's first channel row inside a 16-channel chunk: the chunk / channel part of
     // the address is wave-uniform and goes into the scalar base (global_load ... v, s[base])
-    const unsigned xvo = xsp >= 0 ? ((unsigned)(ukg * 8) * HW + (unsigned)xsp) * 4u : 0u;
+    unsigned xvo[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) xvo[u] = xsp[u] >= 0 ? ((unsigned)(ukg[u] * 8) * HW + (unsigned)xsp[u]) * 4u : 0u;
     auto load_x = [&](int chunk) {
         const int cbase = chunk * KC;
         const float *xbase = cbase < P.C0 ? s0 + (size_t)cbase * HW : s1 + (size_t)(cbase - P.C0) * HW;
         if (cbase + KC <= P.Cin) {
 #pragma unroll
-            for (int i = 0; i < kXR; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const char *rowb = reinterpret_cast<const char *>(xbase + (size_t)i * HW);
-                if (xsp >= 0) v = *reinterpret_cast<const float4 *>(rowb + xvo);
-                xr[i] = v;
-            }
+            for (int u = 0; u < XU; ++u)
+#pragma unroll
+                for (int i = 0; i < kXR; ++i) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const char *rowb = reinterpret_cast<const char *>(xbase + (size_t)i * HW);
+                    if (xsp[u] >= 0) v = *reinterpret_cast<const float4 *>(rowb + xvo[u]);
+                    xr[u][i] = v;
+                }
             return;
         }
         const int ncm1 = min(KC, P.Cin - cbase) - 1;  // channel tail: re-read the last valid (weights 0)
 #pragma unroll
-        for (int i = 0; i < kXR; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xsp >= 0) {
-                const unsigned c = (unsigned)min(ukg * 8 + i, ncm1);
-                v = *reinterpret_cast<const float4 *>(xbase + (size_t)c * HW + (unsigned)xsp);
+        for (int u = 0; u < XU; ++u)
+#pragma unroll
+            for (int i = 0; i < kXR; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xsp[u] >= 0) {
+                    const unsigned c = (unsigned)min(ukg[u] * 8 + i, ncm1);
+                    v = *reinterpret_cast<const float4 *>(xbase + (size_t)c * HW + (unsigned)xsp[u]);
+                }
+                xr[u][i] = v;
             }
-            xr[i] = v;
-        }
     };
     auto store_x = [&](int chunk) {
-        if (xsp > -2) {
-            uint4 *dst = reinterpret_cast<uint4 *>(xc);
-            float lg[8], lb[8];
-            if constexpr (LNMODE == 1) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int c = min(chunk * KC + ukg * 8 + q, P.Cin - 1);
-                    lg[q] = P.ln_g[c]; lb[q] = P.ln_b[c];
+        for (int u = 0; u < XU; ++u) {
+            if (xsp[u] > -2) {
+                uint4 *dst = reinterpret_cast<uint4 *>(xc);
+                float lg[8], lb[8];
+                if constexpr (LNMODE == 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = min(chunk * KC + ukg[u] * 8 + q, P.Cin - 1);
+                        lg[q] = P.ln_g[c]; lb[q] = P.ln_b[c];
+                    }
                 }
-            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                unsigned hh[8], mm[8], ll[8];
+                for (int t = 0; t < 4; ++t) {
+                    unsigned hh[8], mm[8], ll[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float v = t == 0 ? xr[q].x : (t == 1 ? xr[q].y : (t == 2 ? xr[q].z : xr[q].w));
-                    if constexpr (LNMODE == 2) v -= umean[t];
-                    if constexpr (LNMODE == 1) v = xsp >= 0 ? (v - umean[t]) * urstd[t] * lg[q] + lb[q] : 0.f;
-                    split3(v, hh[q], mm[q], ll[q]);
+                    for (int q = 0; q < 8; ++q) {
+                        float v = t == 0 ? xr[u][q].x : (t == 1 ? xr[u][q].y : (t == 2 ? xr[u][q].z : xr[u][q].w));
+                        if constexpr (LNMODE == 2) v -= umean[t];
+                        if constexpr (LNMODE == 1) v = xsp[u] >= 0 ? (v - umean[t]) * urstd[t] * lg[q] + lb[q] : 0.f;
+                        split3(v, hh[q], mm[q], ll[q]);
+                    }
+                    uint4 vh, vm, vl;
+                    vh.x = (hh[0] >> 16) | hh[1]; vh.y = (hh[2] >> 16) | hh[3];
+                    vh.z = (hh[4] >> 16) | hh[5]; vh.w = (hh[6] >> 16) | hh[7];
+                    vm.x = (mm[0] >> 16) | mm[1]; vm.y = (mm[2] >> 16) | mm[3];
+                    vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
+                    vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
+                    vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
+                    const int pos = urc[u] + (t & 1) * ustep1 + (t >> 1) * ustep2;
+                    dst[(0 * 2 + ukg[u]) * plane + pos] = vh;
+                    dst[(1 * 2 + ukg[u]) * plane + pos] = vm;
+                    dst[(2 * 2 + ukg[u]) * plane + pos] = vl;
                 }
-                uint4 vh, vm, vl;
-                vh.x = (hh[0] >> 16) | hh[1]; vh.y = (hh[2] >> 16) | hh[3];
-                vh.z = (hh[4] >> 16) | hh[5]; vh.w = (hh[6] >> 16) | hh[7];
-                vm.x = (mm[0] >> 16) | mm[1]; vm.y = (mm[2] >> 16) | mm[3];
-                vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
-                vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
-                vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
-                dst[(0 * 2 + ukg) * plane + urc + t] = vh;
-                dst[(1 * 2 + ukg) * plane + urc + t] = vm;
-                dst[(2 * 2 + ukg) * plane + urc + t] = vl;
             }
         }
     };
@@ -454,7 +476,8 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
     const int half = lane >> 5;
     const int j = lane & 31;
     const int pr = j >> P.lognbw, pc = j & (NBW - 1);
-    const int b_lane = half * plane + (rb * NPW * NBH + pr) * P.stride * PW + pc * P.stride + P.xshift[z];
+    const int xs = P.xshift[z];
+    const int b_lane = half * plane + (rb * NPW * NBH + pr) * P.stride * PW + (s2 ? pc : pc + xs);
     const int nb_stride = NBH * P.stride * PW;
     const int a_lane = half * COPT + j;
     int bidx[3][NPW];                                 // B-operand unit index of tap (0,0), per plane / block
@@ -496,7 +519,8 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE)) conv_spl
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats) + a_lane;
             int ky = (grp * TG) / P.KW, kx = grp * TG - ky * P.KW;      // uniform tap walk (SALU)
             for (int t = 0; t < TG; ++t) {
-                const uint4 *xb = reinterpret_cast<const uint4 *>(xc) + (ky * PW + kx);
+                const uint4 *xb = reinterpret_cast<const uint4 *>(xc) +
+                                  (ky * PW + (s2 ? ((kx + xs) & 1) * (PW / 2) + ((kx + xs) >> 1) : kx));
                 if (++kx == P.KW) { kx = 0; ++ky; }
                 // B planes stay live for the tap; the A planes are fetched one at a time, smallest
                 // first: plane 2 feeds one product term, plane 1 two, plane 0 three (six in all)
