@@ -530,9 +530,11 @@ struct Builder {
         int shift_bs = -1;                             // row stride of `shift` (-1: the U-Net's table)
         long long w_bs = 0;
         bool no_bias = false;
+        const float *res3_w = nullptr, *res3_x = nullptr; long long res3_bs = 0;   // 3-channel res_conv in the epilogue
         int max_ksplit = 1;                            // > 1: `out` has room for that many partial-sum planes
     };
     int last_ksplit = 1;                               // slices the last conv() call really used
+    const float *next_res3_w = nullptr, *next_res3_x = nullptr; long long next_res3_bs = 0;   // for the next block()
 
     // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
@@ -616,6 +618,7 @@ struct Builder {
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.out_ks = (long long)B * out_bs;
+        a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
         const double px = (double)B * s.Ho * s.Wo * w.nz;
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
@@ -676,8 +679,12 @@ struct Builder {
         o.no_bias = pre_add != nullptr;          // the hoisted partial already carries the bias
         o.resid = resid; o.resid_bs = resid_bs; o.resid_cs = (long long)H * W;
         o.stat_mean = sm; o.stat_rstd = sr;
+        o.res3_w = next_res3_w; o.res3_x = next_res3_x; o.res3_bs = next_res3_bs;
+        const bool want_res3 = next_res3_w != nullptr;
+        next_res3_w = next_res3_x = nullptr;
         if (prefer_fused(w, H, W) && conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), o, true, prof))
             return;
+        if (want_res3) { rc = fail(h, CDC_ERR_UNSUPPORTED, "epilogue res_conv needs the fused LayerNorm plan"); return; }
         ConvOpts u;
         u.pre_add = pre_add; u.no_bias = o.no_bias;
         const size_t plane_f = (size_t)B * w.Cout * H * W;
@@ -732,7 +739,13 @@ struct Builder {
             } else
             block(rb.c1x, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
                   nullptr, nullptr, prof1);
-            if (rb.has_res) {
+            if (rb.has_res && a0.C == 3 && rb.cresx.COP == round_up(rb.cout, 32) && prefer_fused(rb.c2, H, W) &&
+                !getenv("CDC_NO_RES3")) {
+                // res_conv over the 3 image channels rides in block2's epilogue; its context half (with
+                // the bias) is the hoisted tensor
+                res = pr.p; res_bs = pr.bs();
+                next_res3_w = rb.cresx.wp; next_res3_x = a0.p; next_res3_bs = a0.bs();
+            } else if (rb.has_res) {
                 Act r = new_act(rb.cout, H, W);
                 ConvOpts orr; orr.pre_add = pr.p; orr.no_bias = true;
                 conv(rb.cresx, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, r.p, r.bs(), orr, false, PC_CONV1);

@@ -58,6 +58,10 @@ struct ConvArgs {
     int shift_bs;
     const float *resid;             // same addressing as out, added last (ResnetBlock / Residual)
     long long resid_bs, resid_cs;
+    // residual branch of the first ResnetBlock: res_conv over the 3 image channels, evaluated in the
+    // epilogue (3 FMAs per value) instead of a separate 1x1 launch: += sum_c res3_w[c][co] * res3_x[b][c][pix]
+    const float *res3_w, *res3_x;   // packed 1x1 weights [>=3][COP] / stride-1 input of the same H x W
+    long long res3_bs;
     float *stat_mean, *stat_rstd;   // [B][Ho*Wo]: LN statistics of the final values (for the next
                                     // PreNorm); needs gridDim.y == 1
     // split-K (conv_split2_kernel, plain bias-only epilogue): gridDim.z = nzz * ksplit; slice ks handles chunks

@@ -82,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
     const bool img_ok = b < g.nimg;
     // ---- epilogue -------------------------------------------------------------------------------
     __syncthreads();
-    float *ep = smem;   // [3 + ipw][COPT]: bias, ln g, ln b, shift (one row per image of the workgroup)
+    float *ep = smem;   // [3 + ipw (+3)][COPT]: bias, ln g, ln b, shift (one row per image), res3 weights
     for (int i = tid; i < COPT; i += nthr) {
         const int co = cog * COPT + i;
         const bool ok = co < P.Cout;
@@ -92,6 +92,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
         for (int q = 0; q < g.ipw; ++q)
             ep[(3 + q) * COPT + i] =
                 (ok && P.shift && g.b + q < g.nimg) ? P.shift[(size_t)(g.b + q) * P.shift_bs + co] : 0.f;
+        if (P.res3_w)
+            for (int c = 0; c < 3; ++c) ep[(3 + g.ipw + c) * COPT + i] = ok ? P.res3_w[(size_t)c * P.COP + co] : 0.f;
     }
     __syncthreads();
 
@@ -194,6 +196,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
                     }
                 }
             }
+        }
+        if (P.res3_w) {
+            const size_t hw = (size_t)P.Ho * P.Wo;
+            const float *xp = P.res3_x + (size_t)b * P.res3_bs + (size_t)oy * P.Wo + ox;
+            const float x0 = valid ? xp[0] : 0.f, x1 = valid ? xp[hw] : 0.f, x2 = valid ? xp[2 * hw] : 0.f;
+            const float *w3 = epl + (3 + g.ipw) * COPT;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                    acc[m][n][r] += w3[ci] * x0 + w3[COPT + ci] * x1 + w3[2 * COPT + ci] * x2;
+                }
         }
         if (P.stat_mean) {
             float s = 0.f;

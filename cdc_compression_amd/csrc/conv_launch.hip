@@ -31,7 +31,7 @@ static constexpr size_t kLdsSmall = 78 * 1024, kLdsBig = 150 * 1024;
 static size_t plan_lds(int taps, int kc, int COPT, int PH, int PW, int nthr, int xv) {
     const int n_x = kc * PH * PW / xv, n_w4 = taps * kc * (COPT / 4);
     const size_t buf = (size_t)ceil_div(n_w4, nthr) * nthr * 4 + (size_t)ceil_div(n_x, nthr) * nthr * xv;
-    return std::max(sizeof(float) * 2 * buf, sizeof(float) * 4 * (size_t)COPT);
+    return std::max(sizeof(float) * 2 * buf, sizeof(float) * 7 * (size_t)COPT);
 }
 
 static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p, int force_kc = 0) {
@@ -166,7 +166,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->PH = PH; p->PW = PW;
     p->xvec = 1;
     for (int z = 0; z < 4; ++z) p->xshift[z] = xshift[z];
-    p->lds_bytes = std::max(lds, sizeof(float) * (3 + ipw) * (size_t)COPT);
+    p->lds_bytes = std::max(lds, sizeof(float) * (6 + ipw) * (size_t)COPT);
     p->lnmode = s.lnmode;
     p->split = v2 ? 2 : 1;
     p->tg = v2 ? tg : s.KW;
