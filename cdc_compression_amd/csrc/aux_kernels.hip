@@ -76,19 +76,23 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs a) {
 // single threads walk 384 channels three times.
 constexpr int kLnCache = 48;
 
+// PL pixels x CS = 256/PL channel slices per workgroup: PL = 32 normally, 8 for the few-pixel levels (more
+// workgroups; a thread then walks C/32 channels x nparts split-K slices).
+template <int PL>
 __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
-    __shared__ float red[8][33];
+    constexpr int CS = 256 / PL, NV = 8 * kLnCache / CS;
+    __shared__ float red[CS][PL + 1];
     const int b = blockIdx.y;
-    const int pl = threadIdx.x & 31, cs = threadIdx.x >> 5;
-    const int p = blockIdx.x * 32 + pl;
+    const int pl = threadIdx.x % PL, cs = threadIdx.x / PL;
+    const int p = blockIdx.x * PL + pl;
     const bool pv = p < a.HW;
     const size_t base = (size_t)b * a.C * a.HW + (pv ? p : 0);
     const float *x = a.in + base;
-    float v[kLnCache];
+    float v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnCache; ++i) {
-        const int c = cs + 8 * i;
+    for (int i = 0; i < NV; ++i) {
+        const int c = cs + CS * i;
         v[i] = (pv && c < a.C) ? x[(size_t)c * a.HW] : 0.f;
         for (int k = 1; k < a.nparts; ++k)            // split-K slices of the producing convolution
             v[i] += (pv && c < a.C) ? x[(size_t)k * a.part_stride + (size_t)c * a.HW] : 0.f;
@@ -98,20 +102,20 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[k][pl];
+    for (int k = 0; k < CS; ++k) tot += red[k][pl];
     const float mean = tot / (float)a.C;
     __syncthreads();
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnCache; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const float d = v[i] - mean;
-        q += (cs + 8 * i < a.C) ? d * d : 0.f;
+        q += (cs + CS * i < a.C) ? d * d : 0.f;
     }
     red[cs][pl] = q;
     __syncthreads();
     tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += red[k][pl];
+    for (int k = 0; k < CS; ++k) tot += red[k][pl];
     const float var = tot / (float)a.C;
     if (!a.out) {
         if (pv && cs == 0) {
@@ -126,8 +130,8 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
     const float *sh = a.shift ? a.shift + (size_t)b * a.shift_bs : nullptr;
     float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnCache; ++i) {
-        const int c = cs + 8 * i;
+    for (int i = 0; i < NV; ++i) {
+        const int c = cs + CS * i;
         if (c < a.C) {
             float w = (v[i] - mean) / den * a.g[c] + a.b[c];
             if (a.relu) w = fmaxf(w, 0.f);
@@ -146,20 +150,20 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
         __syncthreads();
         tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot += red[k][pl];
+        for (int k = 0; k < CS; ++k) tot += red[k][pl];
         const float m2 = tot / (float)a.C;
         __syncthreads();
         float q2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < kLnCache; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const float d = v[i] - m2;
-            q2 += (cs + 8 * i < a.C) ? d * d : 0.f;
+            q2 += (cs + CS * i < a.C) ? d * d : 0.f;
         }
         red[cs][pl] = q2;
         __syncthreads();
         tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot += red[k][pl];
+        for (int k = 0; k < CS; ++k) tot += red[k][pl];
         if (pv && cs == 0) {
             a.stat_mean[(size_t)b * a.HW + p] = m2;
             a.stat_rstd[(size_t)b * a.HW + p] = 1.0f / sqrtf(tot / (float)a.C + a.eps);
@@ -170,8 +174,11 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache) {
-        hipLaunchKernelGGL(ln_kernel_sliced, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
-                           st, a);
+        if (a.HW <= 256)
+            hipLaunchKernelGGL(ln_kernel_sliced<8>, dim3((unsigned)ceil_div(a.HW, 8), (unsigned)B), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(ln_kernel_sliced<32>, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
+                               st, a);
         return hipGetLastError();
     }
     const int block = a.HW >= 256 ? 256 : 64;
@@ -469,6 +476,7 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 //   R1: T1[b][d][c]  = sum_e (sum_split S[b][split][d][e]) / ksum[b][d] * WoT[e][c]
 //   R2: Mt[b][ci][c] = scale * sum_d WqT[ci][d] * T1[b][d][c]     (packed 1x1 weights [Cin_pad][COP])
 // ---------------------------------------------------------------------------------------------
+static_assert(true, "");
 constexpr int kFoldRows = 8;     // rows per workgroup: each WoT / T1 element is reused 8x from registers
 
 // R0: ctxn[b][d][e] = (sum_split S) / (sum_split Zp)   -- one thread per element, coalesced over e
@@ -487,11 +495,11 @@ __global__ void __launch_bounds__(256) ctx_r0_kernel(const float *S, const float
 }
 
 __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, const float *WoT, float *T1) {
-    extern __shared__ float rows[];         // [kFoldRows][C]: normalised ctx rows d0..d0+7
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [C][kFoldRows]: normalised ctx rows d0..d0+7, e-major
     const int d0 = blockIdx.x * kFoldRows, b = blockIdx.y;
     for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
         const int r = idx / C, e = idx - r * C, d = d0 + r;
-        rows[idx] = d < C ? ctxn[((size_t)b * C + d) * C + e] : 0.f;
+        rows[e * kFoldRows + r] = d < C ? ctxn[((size_t)b * C + d) * C + e] : 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -503,8 +511,10 @@ __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, c
 #pragma unroll 8
         for (int e = 0; e < C; ++e) {
             const float w = WoT[(size_t)e * C + c];
-#pragma unroll
-            for (int r = 0; r < kFoldRows; ++r) acc[r] += rows[r * C + e] * w;
+            const float4 ra = *reinterpret_cast<const float4 *>(rows + e * kFoldRows);
+            const float4 rb = *reinterpret_cast<const float4 *>(rows + e * kFoldRows + 4);
+            acc[0] += ra.x * w; acc[1] += ra.y * w; acc[2] += ra.z * w; acc[3] += ra.w * w;
+            acc[4] += rb.x * w; acc[5] += rb.y * w; acc[6] += rb.z * w; acc[7] += rb.w * w;
         }
 #pragma unroll
         for (int r = 0; r < kFoldRows; ++r)
@@ -515,11 +525,11 @@ __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, c
 __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const float *WqT, int C,
                                                      float scale, const float *ln_g, float *Mt,
                                                      int Cin_pad, int COP) {
-    extern __shared__ float rows[];         // [kFoldRows][C]: WqT rows ci0..ci0+7
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [C][kFoldRows]: WqT rows ci0..ci0+7, d-major
     const int ci0 = blockIdx.x * kFoldRows, b = blockIdx.y;
     for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
         const int r = idx / C, d = idx - r * C;
-        rows[idx] = (ci0 + r < C) ? WqT[(size_t)(ci0 + r) * C + d] : 0.f;
+        rows[d * kFoldRows + r] = (ci0 + r < C) ? WqT[(size_t)(ci0 + r) * C + d] : 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < COP; c += blockDim.x) {
@@ -531,8 +541,10 @@ __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const floa
 #pragma unroll 8
             for (int d = 0; d < C; ++d) {
                 const float w = t[(size_t)d * C];
-#pragma unroll
-                for (int r = 0; r < kFoldRows; ++r) acc[r] += rows[r * C + d] * w;
+                const float4 ra = *reinterpret_cast<const float4 *>(rows + d * kFoldRows);
+                const float4 rb = *reinterpret_cast<const float4 *>(rows + d * kFoldRows + 4);
+                acc[0] += ra.x * w; acc[1] += ra.y * w; acc[2] += ra.z * w; acc[3] += ra.w * w;
+                acc[4] += rb.x * w; acc[5] += rb.y * w; acc[6] += rb.z * w; acc[7] += rb.w * w;
             }
         }
 #pragma unroll
