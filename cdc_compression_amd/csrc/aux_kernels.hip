@@ -655,14 +655,25 @@ hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// dst[b][i] = sum_k src[k*part_stride + b*src_bs + i]   (parts = 1: plain channel copy; > 1: split-K slices)
 __global__ void __launch_bounds__(256) copy_kernel(const float *src, long long src_bs, float *dst,
-                                                   long long dst_bs, long long n) {
+                                                   long long dst_bs, long long n, int parts, long long part_stride) {
     const int b = blockIdx.y;
     const float *s = src + (size_t)b * src_bs;
     float *d = dst + (size_t)b * dst_bs;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x)
-        d[i] = s[i];
+         i += (long long)gridDim.x * blockDim.x) {
+        float v = s[i];
+        for (int k = 1; k < parts; ++k) v += s[(size_t)k * part_stride + i];
+        d[i] = v;
+    }
+}
+
+hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
+                                long long n, int B, hipStream_t st, int parts, long long part_stride) {
+    const int gx = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(copy_kernel, dim3(gx, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, n, parts, part_stride);
+    return hipGetLastError();
 }
 
 // Column unfold for few-channel k x k convolutions (the first 7x7 layer, unet.py:31 / nc.py:104):
@@ -689,13 +700,6 @@ hipError_t unfold_x_launch(const float *src, long long src_bs, float *dst, long 
     const int gx = std::min((H * (W >> 2) + 255) / 256, 256);
     hipLaunchKernelGGL(unfold_x_kernel, dim3(gx, C * KW, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, C, KW,
                        pad, H, W);
-    return hipGetLastError();
-}
-
-hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
-                                long long n, int B, hipStream_t st) {
-    const int gx = (int)std::min<long long>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(copy_kernel, dim3(gx, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, n);
     return hipGetLastError();
 }
 

@@ -72,6 +72,7 @@ struct Op {
     struct { const float *P, *bias; float *out; int Cout, KH, pad, H, W; } cb;
     DdimArgs ddim;
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
+    int cp_parts = 1; long long cp_part_stride = 0;   // COPY: dst = sum of cp_parts planes of src
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
 };
 
@@ -580,6 +581,20 @@ struct Builder {
             int ks = (int)std::min<long long>(ceil_div(1024, wgs), std::min(o.max_ksplit, plan.nchunk / 4));
             if (ks > 1) { plan.ksplit = ks; last_ksplit = ks; }
         }
+        // Plain (linear) epilogues at the few-workgroup levels -- the attention projections and res_convs
+        // at 8x8 / 16x16: slice K as well, slice 0 carries bias + residual, a sum pass follows.
+        float *ks_scratch = nullptr;
+        const long long dense_bs = (long long)w.Cout * s.Ho * s.Wo;
+        if (o.max_ksplit <= 1 && plan.split == 2 && !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean &&
+            !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed && !getenv("CDC_NO_KSPLIT")) {
+            const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
+                                  plan.groups;
+            const int ks = (int)std::min<long long>(ceil_div(1024, wgs), std::min(4, plan.nchunk / 4));
+            if (ks > 1 && (size_t)B * dense_bs * 4 * ks <= (64u << 20)) {
+                plan.ksplit = ks;
+                ks_scratch = dalloc((size_t)ks * B * dense_bs);
+            }
+        }
         if (getenv("CDC_DEBUG_PLAN"))
             fprintf(stderr, "[plan] %-10s Cin=%4d Cout=%4d k=%dx%d s=%d in=%3dx%-3d out=%3dx%-3d %s%s%s| MB=%2d NPW=%d "
                     "WN=%d groups=%2d KC=%2d nchunk=%3d tiles=%dx%d wgs=%6d lds=%6zu\n", kProfNames[prof], w.Cin,
@@ -622,7 +637,17 @@ struct Builder {
         const double px = (double)B * s.Ho * s.Wo * w.nz;
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
+        if (ks_scratch) {
+            a.out = ks_scratch; a.out_bs = dense_bs; a.out_ks = (long long)B * dense_bs;
+        }
         emit(op);
+        if (ks_scratch) {
+            Op c; c.kind = Op::COPY; c.prof = prof;
+            c.cp = {ks_scratch, dense_bs, out, out_bs, dense_bs};
+            c.cp_parts = plan.ksplit; c.cp_part_stride = (long long)B * dense_bs;
+            c.bytes = 4.0 * B * dense_bs * (plan.ksplit + 1);
+            emit(c);
+        }
         return true;
     }
 
@@ -1023,7 +1048,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             break;
         case Op::COPY:
             HIP_TRY(h, copy_channels_launch(op.cp.src, op.cp.src_bs, op.cp.dst, op.cp.dst_bs, op.cp.n,
-                                            B, st));
+                                            B, st, op.cp_parts, op.cp_part_stride));
             break;
     }
     if (prof) {

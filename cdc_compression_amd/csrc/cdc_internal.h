@@ -104,7 +104,7 @@ struct DdimArgs {
 };
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
-                                long long n_per_image, int B, hipStream_t st);
+                                long long n, int B, hipStream_t st, int parts = 1, long long part_stride = 0);
 hipError_t unfold_x_launch(const float *src, long long src_bs, float *dst, long long dst_bs, int C, int KW,
                            int pad, int H, int W, int B, hipStream_t st);
 

@@ -177,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
                 for (int r = 0; r < 16; ++r)
                     acc[m][n][r] += epl[(3 + img_l) * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
         }
-        if (P.resid) {
+        if (P.resid && !g.no_bias) {       // (split-K: the residual enters through slice 0 only)
             const float *rp = P.resid + (size_t)b * P.resid_bs + pix +
                               (size_t)(cobase + 4 * half) * P.resid_cs;
 #pragma unroll

@@ -5,7 +5,7 @@
 // truncation, so no rounding is involved), and a bf16 x bf16 product is exact in fp32.  Hence
 //      a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1) + O(2^-24 |ab|)
 // is six v_mfma_f32_32x32x16_bf16 per 16-deep K step instead of eight 32x32x2_f32: 2.67x the matrix
-// rate at fp32-class accuracy (measured end to end against a float64 oracle: 1.9e-6 vs 8e-6 for plain
+// rate at fp32-class accuracy (measured end to end against a float64 convolution: 1.9e-6 vs 8e-6 for plain
 // fp32; the dropped terms a2b3 + a3b2 + a3b3 are below the fp32 rounding of the running sum).
 //
 // Tensors stay float32 NCHW in HBM.  Per 16-channel chunk the haloed input patch lands in LDS as fp32
