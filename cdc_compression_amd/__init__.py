@@ -3,3 +3,4 @@ compression): the N-step DDIM loop over the denoising U-Net, as hand-written HIP
 C-ABI (include/cdc_hip.h), with host-side mirrors of the reference's Unet / GaussianDiffusion API."""
 from .unet import Unet  # noqa: F401
 from .diffusion import GaussianDiffusionEps, GaussianDiffusionX  # noqa: F401
+from .compressor import BigCompressor, ResnetCompressor  # noqa: F401

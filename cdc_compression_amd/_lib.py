@@ -25,6 +25,12 @@ class UnetConfig(ctypes.Structure):
                 ("context_dim_mults", ctypes.c_int32 * CDC_MAX_LEVELS)]
 
 
+class CtxdecConfig(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int32), ("n_rev_mults", ctypes.c_int32),
+                ("rev_mults", ctypes.c_int32 * CDC_MAX_LEVELS), ("out_channels", ctypes.c_int32),
+                ("up_index", ctypes.c_int32)]
+
+
 class CdcError(RuntimeError):
     pass
 
@@ -67,6 +73,8 @@ def lib():
     L.cdc_load_tensor.argtypes = [H, ctypes.c_char_p, _vp, ctypes.POINTER(ctypes.c_int64), _i]
     L.cdc_finalize_weights.argtypes = [H]
     L.cdc_unet_forward.argtypes = [H, _vp, _vp, pp, _i, _vp, _i, _i, _i, _i, _vp]
+    L.cdc_ctxdec_create.argtypes = [ctypes.POINTER(CtxdecConfig), _i, ctypes.POINTER(H)]
+    L.cdc_ctxdec_decode.argtypes = [H, _vp, pp, _i, _i, _i, _i, _i, _vp]
     L.cdc_set_schedule.argtypes = [H, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     L.cdc_ddim_step.argtypes = [H, _vp, _i, pp, _i, _vp, ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                 _i, _vp]
@@ -91,7 +99,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_set_schedule", "cdc_ddim_step", "cdc_decode", "cdc_prof_enable",
            "cdc_prof_num_classes", "cdc_prof_name", "cdc_prof_get", "cdc_prof_reset",
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
-           "cdc_op_linear_attention"]
+           "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode"]
 
 
 def check(handle, rc):

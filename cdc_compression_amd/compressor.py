@@ -1,0 +1,165 @@
+"""Host-side mirror of the DECODER half of the reference context model, backed by libcdc_hip.so.
+
+`ResnetCompressor` (xparam/modules/compress_modules.py:110-177) and `BigCompressor`
+(epsilonparam/modules/compress_modules.py:112-185) keep the reference constructors' argument names;
+only `decode(q_latent)` (compress_modules.py:68-74) -- the synthesis transform that turns the
+transmitted latents into the context pyramid of the denoising U-Net -- is implemented (SURVEY
+section 8f row 1).  `load_state_dict` accepts the reference compressor's full state_dict and takes its
+`dec.*` entries; `encode` / `bpp` / `forward` (analysis transform, hyperprior, rate estimate) raise
+NotImplementedError: the reference module stays in charge of those.
+"""
+import ctypes
+
+from . import _lib
+from .unet import _Arg, _as_host_f32, _current_stream, _result_like
+
+
+class _ContextDecoder:
+    _up_index = 1
+
+    def __init__(self, dim, rev_mults, out_channels, device=0):
+        self.dim = dim
+        self.rev_mults = tuple(rev_mults)
+        self.out_channels = out_channels
+        self.reversed_dims = [dim * m for m in self.rev_mults] + [out_channels]
+        self.training = False
+        self.device_index = int(device) if not hasattr(device, "index") else (device.index or 0)
+        self._h = None
+        self._sd = {}
+        self._finalized = False
+
+    # ---- handle management ----------------------------------------------------------------
+    def _handle(self):
+        if self._h is None:
+            L = _lib.lib()
+            cfg = _lib.CtxdecConfig()
+            cfg.dim, cfg.out_channels, cfg.up_index = self.dim, self.out_channels, self._up_index
+            cfg.n_rev_mults = len(self.rev_mults)
+            for i, m in enumerate(self.rev_mults):
+                cfg.rev_mults[i] = m
+            h = ctypes.c_void_p()
+            rc = L.cdc_ctxdec_create(ctypes.byref(cfg), self.device_index, ctypes.byref(h))
+            if rc != 0:
+                raise _lib.CdcError(f"cdc_ctxdec_create failed ({rc}): {L.cdc_last_error(None).decode()}")
+            self._h = h
+            for k, v in self._sd.items():
+                self._load_one(k, v)
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.lib().cdc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def to(self, device):
+        idx = device if isinstance(device, int) else getattr(device, "index", None)
+        if isinstance(device, str):
+            idx = int(device.split(":")[1]) if ":" in device else 0
+        idx = 0 if idx is None else int(idx)
+        if idx != self.device_index and self._h is not None:
+            _lib.lib().cdc_destroy(self._h)
+            self._h = None
+            self._finalized = False
+        self.device_index = idx
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    # ---- parameters -----------------------------------------------------------------------
+    def manifest(self):
+        """[(name, shape)] of the `dec.*` entries, in the reference's registration order."""
+        L, h = _lib.lib(), self._handle()
+        out = []
+        for i in range(L.cdc_num_tensors(h)):
+            name = ctypes.c_char_p()
+            shape = (ctypes.c_int64 * 4)()
+            nd = ctypes.c_int()
+            _lib.check(h, L.cdc_tensor_info(h, i, ctypes.byref(name), shape, ctypes.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value))))
+        return out
+
+    def _load_one(self, name, value):
+        L, h = _lib.lib(), self._h
+        a = _as_host_f32(value)
+        shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+        _lib.check(h, L.cdc_load_tensor(h, name.encode(), a.ctypes.data, shape, a.ndim))
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Takes the `dec.*` entries; the encoder / hyperprior entries of a full reference state_dict are
+        not this module's.  strict: every `dec.*` key must match the manifest."""
+        h = self._handle()
+        names = [n for n, _ in self.manifest()]
+        missing = [n for n in names if n not in state_dict]
+        unexpected = [k for k in state_dict if k.startswith("dec.") and k not in names]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing "
+                               f"{missing[:3]}{'...' if len(missing) > 3 else ''}, unexpected {unexpected[:3]}")
+        for n in names:
+            if n in state_dict:
+                self._sd[n] = _as_host_f32(state_dict[n])
+                self._load_one(n, self._sd[n])
+        _lib.check(h, _lib.lib().cdc_finalize_weights(h))
+        self._finalized = True
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    # ---- Compressor.decode ------------------------------------------------------------------
+    def decode(self, input, cond=None):
+        """q_latent [B, reversed_dims[0], h, w] -> [ctx@16h, ctx@8h, ctx@4h, ctx@2h] (finest first)."""
+        if cond is not None:
+            raise NotImplementedError("vbr conditioning (VBRCondition) is not on the decode path (vbr=False)")
+        L, h = _lib.lib(), self._handle()
+        if not self._finalized:
+            raise _lib.CdcError("load_state_dict() has not been called")
+        aq = _Arg(input, self.device_index)
+        B, C, hl, wl = aq.shape
+        if C != self.reversed_dims[0]:
+            raise _lib.CdcError(f"q_latent has {C} channels, the decoder expects {self.reversed_dims[0]}")
+        n = len(self.rev_mults)
+        outs, ptrs = [], []
+        for i in range(n):                     # outs[0] = finest
+            lvl = n - 1 - i
+            o, p, _ = _result_like(input, (B, self.reversed_dims[lvl + 1], hl << (lvl + 1), wl << (lvl + 1)),
+                                   self.device_index)
+            outs.append(o)
+            ptrs.append(p)
+        arr = (ctypes.c_void_p * n)(*ptrs)
+        _lib.check(h, L.cdc_ctxdec_decode(h, aq.ptr, arr, n, B, hl, wl, aq.mem, _current_stream(aq.mem)))
+        return outs
+
+    def encode(self, *a, **k):
+        raise NotImplementedError("the analysis transform / hyperprior run in the reference module "
+                                  "(SURVEY section 8f rows 2-3)")
+
+    bpp = forward = __call__ = encode
+
+
+class ResnetCompressor(_ContextDecoder):
+    """xparam/modules/compress_modules.py:110-177 (decoder half)."""
+    _up_index = 1
+
+    def __init__(self, dim=64, dim_mults=(1, 2, 3, 4), reverse_dim_mults=(4, 3, 2, 1),
+                 hyper_dims_mults=(4, 4, 4), channels=3, out_channels=3, device=0):
+        if dim * dim_mults[-1] != dim * reverse_dim_mults[0]:
+            raise AssertionError("dims[-1] == reversed_dims[0]")       # compress_modules.py:23
+        super().__init__(dim, reverse_dim_mults, out_channels, device)
+        self.dim_mults, self.hyper_dims_mults, self.channels = tuple(dim_mults), tuple(hyper_dims_mults), channels
+
+
+class BigCompressor(_ContextDecoder):
+    """epsilonparam/modules/compress_modules.py:112-185 (decoder half, vbr=False)."""
+    _up_index = 2
+
+    def __init__(self, dim=64, dim_mults=(1, 2, 3, 3), hyper_dims_mults=(3, 3, 3), channels=3,
+                 out_channels=3, vbr=False, device=0):
+        if vbr:
+            raise NotImplementedError("vbr=True (VBRCondition scalers) is not on the decode path")
+        super().__init__(dim, tuple(reversed(dim_mults)), out_channels, device)
+        self.dim_mults, self.hyper_dims_mults, self.channels = tuple(dim_mults), tuple(hyper_dims_mults), channels

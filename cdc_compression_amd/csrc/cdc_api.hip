@@ -48,11 +48,11 @@ struct Act { float *p = nullptr; int C = 0, H = 0, W = 0;
              long long bs() const { return (long long)C * H * W; } };
 
 struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift_off;
-                   ConvW c1, c2, cres; float *g1, *b1, *g2, *b2, *mlp_w, *mlp_b;
+                   ConvW c1, c2, cres; float *g1, *b1, *g2, *b2, *mlp_w = nullptr, *mlp_b = nullptr;
                    // context hoisting: input = cat(x [hoist_cx ch], ctx); the ctx halves of block1 and
                    // res_conv are step-invariant, so they are split off and evaluated once per decode
                    int hoist_cx = 0; ConvW c1x, c1c, cresx, cresc;
-                  ConvW c1u; bool has_unfold = false; };   // c1x as a KH x 1 conv over KW*cx unfolded channels
+                  ConvW c1u; bool has_unfold = false; bool has_mlp = true; };   // c1x as a KH x 1 conv over KW*cx unfolded channels
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
                ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr; };   // folded output; uq = Wq b_ln
@@ -80,6 +80,10 @@ struct Op {
 
 struct cdc_handle {
     cdc_unet_config cfg;
+    int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode)
+    std::vector<int> rev_dims;    // kind 1: [dim*m for m in rev_mults] + [out_channels]
+    int up_index = 1;
+    std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
     int device = 0;
     std::string err;
     hipStream_t own_stream = nullptr;
@@ -168,10 +172,12 @@ void add_param(cdc_handle *h, const std::string &name, std::vector<int64_t> shap
     h->params.push_back(std::move(p));
 }
 
-void add_resblock_params(cdc_handle *h, const std::string &p, int cin, int cout, int k) {
+void add_resblock_params(cdc_handle *h, const std::string &p, int cin, int cout, int k, bool with_mlp = true) {
     const int d = h->cfg.dim;
-    add_param(h, p + ".mlp.1.weight", {cout, d});
-    add_param(h, p + ".mlp.1.bias", {cout});
+    if (with_mlp) {
+        add_param(h, p + ".mlp.1.weight", {cout, d});
+        add_param(h, p + ".mlp.1.bias", {cout});
+    }
     add_param(h, p + ".block1.block.0.weight", {cout, cin, k, k});
     add_param(h, p + ".block1.block.0.bias", {cout});
     add_param(h, p + ".block1.block.1.g", {1, cout, 1, 1});
@@ -353,8 +359,9 @@ int pack_named_conv(cdc_handle *h, const std::string &wname, const std::string &
 }
 
 int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k, int *shift_off,
-                  int hoist_cx = 0) {
+                  int hoist_cx = 0, bool with_mlp = true) {
     ResBlockW rb;
+    rb.has_mlp = with_mlp;
     rb.prefix = p; rb.cin = cin; rb.cout = cout; rb.k = k; rb.has_res = cin != cout;
     rb.hoist_cx = hoist_cx;
     rb.shift_off = *shift_off;
@@ -399,8 +406,10 @@ int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k,
     if ((rc = upload_param(h, p + ".block1.block.1.b", &rb.b1))) return rc;
     if ((rc = upload_param(h, p + ".block2.block.1.g", &rb.g2))) return rc;
     if ((rc = upload_param(h, p + ".block2.block.1.b", &rb.b2))) return rc;
-    if ((rc = upload_param(h, p + ".mlp.1.weight", &rb.mlp_w))) return rc;
-    if ((rc = upload_param(h, p + ".mlp.1.bias", &rb.mlp_b))) return rc;
+    if (with_mlp) {
+        if ((rc = upload_param(h, p + ".mlp.1.weight", &rb.mlp_w))) return rc;
+        if ((rc = upload_param(h, p + ".mlp.1.bias", &rb.mlp_b))) return rc;
+    }
     h->rbs.push_back(rb);
     return CDC_OK;
 }
@@ -733,7 +742,7 @@ struct Builder {
         if (rc) return Act();
         const int H = a0.H, W = a0.W, HW = H * W;
         const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
-        const float *shift = h->shift + rb.shift_off;
+        const float *shift = rb.has_mlp ? h->shift + rb.shift_off : nullptr;   // Compressor blocks: no time embedding
         Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W);
         if (a1 && a1_is_context && rb.hoist_cx == a0.C) {
             std::vector<Op> *saved = cur;
@@ -875,6 +884,7 @@ void free_program(cdc_handle *h) {
     h->pre_ops.clear();
     h->op_ms.clear(); h->op_n.clear(); h->op_label.clear(); h->op_flops.clear();
     h->in_ctx.clear();
+    h->dec_outs.clear();
     h->act_bytes = 0;
     h->pB = h->pH = h->pW = 0;
     h->d_time_steps = nullptr;
@@ -983,6 +993,29 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     bd.emit(cb);
     if (bd.rc) return bd.rc;
     h->pB = B; h->pH = H; h->pW = W;
+    return CDC_OK;
+}
+
+// Launch program of Compressor.decode (compress_modules.py:68-74) for q_latent [B][rev[0]][hl][wl].
+int build_ctxdec_program(cdc_handle *h, int B, int hl, int wl) {
+    if (h->pB == B && h->pH == hl && h->pW == wl) return CDC_OK;
+    free_program(h);
+    h->dec_outs.clear();
+    Builder bd{h, B, &h->act_allocs};
+    h->in_x = bd.dalloc((size_t)B * h->rev_dims[0] * hl * wl);
+    if (bd.rc) return bd.rc;
+    Act x; x.p = h->in_x; x.C = h->rev_dims[0]; x.H = hl; x.W = wl;
+    const int n = (int)h->rev_dims.size() - 1;
+    for (int i = 0; i < n; ++i) {
+        x = bd.resblock(h->rbs[i], x, nullptr, false, nullptr, nullptr);
+        const ConvW &uw = h->ups[i];
+        Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2);
+        bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false, PC_UP);
+        x = y;
+        h->dec_outs.push_back(y);
+        if (bd.rc) return bd.rc;
+    }
+    h->pB = B; h->pH = hl; h->pW = wl;
     return CDC_OK;
 }
 
@@ -1242,6 +1275,23 @@ int cdc_finalize_weights(cdc_handle *h) {
     free_program(h);
     free_pool(&h->weight_allocs);
     h->rbs.clear(); h->attns.clear(); h->downs.clear(); h->ups.clear();
+    if (h->kind == 1) {
+        // Compressor.dec: ResnetBlock(rev[i] -> rev[i+1] | rev[i] on the last level) + Upsample(-> rev[i+1])
+        const int n = (int)h->rev_dims.size() - 1;
+        int shift_off = 0;
+        for (int i = 0; i < n; ++i) {
+            const std::string p = "dec." + std::to_string(i);
+            const int din = h->rev_dims[i], dout = h->rev_dims[i + 1], dmid = i == n - 1 ? din : dout;
+            if ((rc = pack_resblock(h, p + ".0", din, dmid, 3, &shift_off, 0, false))) return rc;
+            ConvW uw;
+            const std::string u = p + "." + std::to_string(h->up_index);
+            if ((rc = pack_named_conv(h, u + ".conv.weight", u + ".conv.bias", 2, 1, true, &uw))) return rc;
+            h->ups.push_back(uw);
+        }
+        h->shift_bs = 0;
+        h->finalized = true;
+        return CDC_OK;
+    }
     if ((rc = upload_param(h, "time_mlp.0.weight", &h->tm_w0))) return rc;
     if ((rc = upload_param(h, "time_mlp.0.bias", &h->tm_b0))) return rc;
     if ((rc = upload_param(h, "time_mlp.2.weight", &h->tm_w2))) return rc;
@@ -1311,10 +1361,64 @@ int cdc_finalize_weights(cdc_handle *h) {
     return CDC_OK;
 }
 
+int cdc_ctxdec_create(const cdc_ctxdec_config *cfg, int device, cdc_handle **out) {
+    if (!cfg || !out) return fail(nullptr, CDC_ERR_INVALID, "null argument");
+    if (cfg->dim <= 0 || cfg->n_rev_mults < 1 || cfg->n_rev_mults > CDC_MAX_LEVELS || cfg->out_channels < 1 ||
+        cfg->up_index < 1 || cfg->up_index > 2)
+        return fail(nullptr, CDC_ERR_INVALID, "bad cdc_ctxdec_config");
+    if (device < 0) return fail(nullptr, CDC_ERR_INVALID, "device %d out of range", device);
+    std::unique_ptr<cdc_handle> h(new cdc_handle);
+    memset(&h->cfg, 0, sizeof h->cfg);
+    h->cfg.dim = cfg->dim;
+    h->kind = 1;
+    h->device = device;
+    h->up_index = cfg->up_index;
+    for (int i = 0; i < cfg->n_rev_mults; ++i) {
+        if (cfg->rev_mults[i] < 1) return fail(nullptr, CDC_ERR_INVALID, "bad cdc_ctxdec_config");
+        h->rev_dims.push_back(cfg->dim * cfg->rev_mults[i]);
+    }
+    h->rev_dims.push_back(cfg->out_channels);
+    const int n = cfg->n_rev_mults;
+    for (int i = 0; i < n; ++i) {       // registration order of Compressor.dec (compress_modules.py:147-156)
+        const std::string p = "dec." + std::to_string(i);
+        const int din = h->rev_dims[i], dout = h->rev_dims[i + 1], dmid = i == n - 1 ? din : dout;
+        add_resblock_params(h.get(), p + ".0", din, dmid, 3, false);
+        const std::string u = p + "." + std::to_string(cfg->up_index);
+        add_param(h.get(), u + ".conv.weight", {dmid, dout, 4, 4});     // ConvTranspose2d: [Cin][Cout][4][4]
+        add_param(h.get(), u + ".conv.bias", {dout});
+    }
+    *out = h.release();
+    return CDC_OK;
+}
+
+int cdc_ctxdec_decode(cdc_handle *h, const float *q_latent, float *const *outs, int n_outs, int B,
+                      int hl, int wl, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->kind != 1) return fail(h, CDC_ERR_STATE, "handle is not a context decoder");
+    const int n = (int)h->rev_dims.size() - 1;
+    if (!q_latent || !outs || n_outs != n || B < 1 || hl < 1 || wl < 1)
+        return fail(h, CDC_ERR_INVALID, "null/invalid argument (the decoder has %d outputs)", n);
+    for (int i = 0; i < n; ++i)
+        if (!outs[i]) return fail(h, CDC_ERR_INVALID, "null output %d", i);
+    if ((rc = build_ctxdec_program(h, B, hl, wl))) return rc;
+    hipStream_t st = pick_stream(h, stream, mem);
+    if ((rc = copy_in(h, h->in_x, q_latent, (size_t)B * h->rev_dims[0] * hl * wl, mem, st))) return rc;
+    h->prof_now = true;
+    for (const Op &op : h->ops)
+        if ((rc = run_op(h, op, h->pB, st))) return rc;
+    for (int i = 0; i < n; ++i) {       // outs[0] = finest = the last level's output (output[::-1])
+        const Act &a = h->dec_outs[n - 1 - i];
+        if ((rc = copy_out(h, outs[i], a.p, (size_t)B * a.C * a.H * a.W, mem, st))) return rc;
+    }
+    return CDC_OK;
+}
+
 int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const float *const *ctx,
                      int n_ctx, float *out, int B, int H, int W, int mem, void *stream) {
     int rc = check_ready(h);
     if (rc) return rc;
+    if (h->kind != 0) return fail(h, CDC_ERR_STATE, "handle is not a U-Net");
     if (!x || !time || !out || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
     if ((rc = build_program(h, B, H, W))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
@@ -1330,6 +1434,7 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
 int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float *sqrt_recip,
                      const float *sqrt_recipm1, const float *sqrt_ac_prev,
                      const float *one_minus_ac_prev, const float *sigma) {
+    if (h && h->kind != 0) return fail(h, CDC_ERR_STATE, "handle is not a U-Net");
     if (!h || steps < 1 || !time_in || !sqrt_recip || !sqrt_recipm1 || !sqrt_ac_prev ||
         !one_minus_ac_prev || !sigma)
         return fail(h, CDC_ERR_INVALID, "null/invalid argument");
@@ -1390,6 +1495,7 @@ static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *
 int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *ctx, int n_ctx,
                   const float *noise, float eta, float *x_out, int B, int H, int W, int pred_mode,
                   int clip, int mem, void *stream) {
+    if (h && h->kind != 0) return fail(h, CDC_ERR_STATE, "handle is not a U-Net");
     int rc = check_ready(h);
     if (rc) return rc;
     if (!h->steps) return fail(h, CDC_ERR_STATE, "cdc_set_schedule has not been called");
@@ -1415,6 +1521,7 @@ int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *c
 
 int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_ctx, float *out, int B,
                int H, int W, int pred_mode, int clip, int mem, void *stream) {
+    if (h && h->kind != 0) return fail(h, CDC_ERR_STATE, "handle is not a U-Net");
     int rc = check_ready(h);
     if (rc) return rc;
     if (!h->steps) return fail(h, CDC_ERR_STATE, "cdc_set_schedule has not been called");

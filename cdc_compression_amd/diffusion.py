@@ -128,7 +128,13 @@ class _GaussianDiffusionBase:
         return img
 
     def decompress(self, context, shape, sample_steps=None, init=None, eta=0, clip_denoised=None):
-        """Decode half of compress(): context pyramid (= context_fn(...)["output"]) -> image."""
+        """Decode half of compress(): context pyramid (= context_fn(...)["output"]) -> image.  `context`
+        may also be the transmitted q_latent tensor [B, C, H/16, W/16]: it then goes through
+        `context_fn.decode` first (compress_modules.py:68-74; cdc_compression_amd.compressor on the GPU)."""
+        if not isinstance(context, (list, tuple)):
+            if self.context_fn is None or not hasattr(self.context_fn, "decode"):
+                raise RuntimeError("decompress(q_latent, ...) needs a context_fn with decode()")
+            context = self.context_fn.decode(context)
         self.set_sample_schedule(self.num_timesteps if sample_steps is None else sample_steps)
         if clip_denoised is None:
             clip_denoised = True if self._param == "x" else getattr(self, "clip_noise", "none")

@@ -10,3 +10,4 @@ class Unet(_Unet):
                  channels=3, context_channels=3, with_time_emb=True, device=0):
         super().__init__(dim, out_dim, dim_mults, context_dim_mults, channels, context_channels,
                          with_time_emb, "01", device)
+from ..compressor import BigCompressor  # noqa: F401

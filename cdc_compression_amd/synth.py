@@ -61,7 +61,7 @@ def unet_state_dict(manifest, seed=0, final_gain=1.0):
         elif name.endswith(".bias"):
             t = normal(name, shape, seed, 0.1)
         else:
-            if name.endswith("3.conv.weight") and len(shape) == 4 and shape[-1] == 4:
+            if name.endswith(".conv.weight") and len(shape) == 4 and shape[-1] == 4:
                 fan_in = shape[0] * 4          # ConvTranspose2d [Cin][Cout][4][4], 2x2 taps/output
             else:
                 fan_in = int(np.prod(shape[1:]))

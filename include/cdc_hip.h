@@ -112,6 +112,32 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
 
 /* ---- measurement --------------------------------------------------------------------------- */
 
+/* ---- context decoder: Compressor.decode ---------------------------- */
+
+/* The synthesis transform of the context model: `for resnet, up in dec: x = up(resnet(x))`, outputs
+ * returned finest first (xparam/modules/compress_modules.py:68-74, epsilonparam/...:74-82).  Level i =
+ * ResnetBlock(rev[i] -> rev[i+1], no time embedding; the last level keeps rev[i]) + ConvTranspose2d(4,2,1)
+ * to rev[i+1]; rev = [dim*m for m in rev_mults] + [out_channels] (compress_modules.py:21-22,147-156).
+ * up_index = position of the Upsample in each ModuleList: 1 for xparam's ResnetCompressor
+ * ("dec.0.1.conv.weight"), 2 for epsilonparam's BigCompressor (an nn.Identity sits at index 1). */
+typedef struct {
+    int32_t dim;
+    int32_t n_rev_mults;
+    int32_t rev_mults[CDC_MAX_LEVELS];    /* xparam: reverse_dim_mults (4,3,2,1); eps: reversed(dim_mults) */
+    int32_t out_channels;                 /* = the U-Net's context_channels */
+    int32_t up_index;
+} cdc_ctxdec_config;
+
+/* Same handle type and the same parameter entry points (cdc_num_tensors / cdc_tensor_info /
+ * cdc_load_tensor with the reference's "dec.*" keys / cdc_finalize_weights / cdc_destroy). */
+int cdc_ctxdec_create(const cdc_ctxdec_config *cfg, int device, cdc_handle **out);
+
+/* q_latent [B][rev[0]][h][w] -> n_outs = n_rev_mults tensors, outs[0] = finest
+ * ([B][out_channels][h*2^n][w*2^n]) ... outs[n-1] = [B][rev[1]][2h][2w]: exactly the `context` list
+ * cdc_unet_forward / cdc_decode take.  mem_kind / stream as for cdc_unet_forward. */
+int cdc_ctxdec_decode(cdc_handle *h, const float *q_latent, float *const *outs, int n_outs, int B,
+                      int h_latent, int w_latent, int mem_kind, void *stream);
+
 /* Kernel-class timing: hipEvent pairs recorded (without host synchronisation) on the launch stream
  * around every kernel of a forward / DDIM iteration and resolved at cdc_prof_get.
  * on = 0: off (default); on = 1: every launch; on = n > 1: inside cdc_decode only the DDIM

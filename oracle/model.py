@@ -314,3 +314,58 @@ def p_sample_loop(ops, cfg, sd, sched, shape, context, clip, init=None, eta=0.0,
         nz = None if noises is None else noises[count]
         img = ddim_step(ops, cfg, sd, sched, img, i, context, None, clip, eta, nz)
     return img
+
+
+# --------------------------------------------------------------------------------------------
+# context decoder: Compressor.decode
+# --------------------------------------------------------------------------------------------
+
+
+class CompressorConfig:
+    """Decoder half of the reference context model.
+
+    xparam ResnetCompressor (xparam/modules/compress_modules.py:6-33,147-156): reversed_dims =
+    [dim*m for m in reverse_dim_mults] + [out_channels]; each level is ModuleList([ResnetBlock,
+    Upsample]) -> up_index 1.  epsilonparam BigCompressor (epsilonparam/modules/compress_modules.py:
+    21,144-156): reversed_dims = reversed([out_channels] + [dim*m for m in dim_mults]); each level is
+    ModuleList([ResnetBlock, Identity | VBRCondition, Upsample]) -> up_index 2 (vbr=False only)."""
+
+    def __init__(self, dim=64, rev_mults=(4, 3, 2, 1), out_channels=3, up_index=1):
+        self.dim = dim
+        self.rev_mults = tuple(rev_mults)
+        self.out_channels = out_channels
+        self.up_index = up_index
+        self.reversed_dims = [dim * m for m in rev_mults] + [out_channels]
+        self.reversed_in_out = list(zip(self.reversed_dims[:-1], self.reversed_dims[1:]))
+
+
+def compressor_dec_manifest(cfg):
+    """(name, shape) of the `dec.*` entries of the reference Compressor.state_dict(), in
+    registration order (pinned by tests/golden/manifest_ctxdec_*.json)."""
+    out = []
+    n = len(cfg.reversed_in_out)
+    for ind, (dim_in, dim_out) in enumerate(cfg.reversed_in_out):
+        is_last = ind >= n - 1
+        mid = dim_in if is_last else dim_out        # ResnetBlock(dim_in, dim_out if not is_last else dim_in)
+        p = f"dec.{ind}.0"
+        out += [(p + ".block1.block.0.weight", (mid, dim_in, 3, 3)), (p + ".block1.block.0.bias", (mid,)),
+                (p + ".block1.block.1.g", (1, mid, 1, 1)), (p + ".block1.block.1.b", (1, mid, 1, 1)),
+                (p + ".block2.block.0.weight", (mid, mid, 3, 3)), (p + ".block2.block.0.bias", (mid,)),
+                (p + ".block2.block.1.g", (1, mid, 1, 1)), (p + ".block2.block.1.b", (1, mid, 1, 1))]
+        if dim_in != mid:
+            out += [(p + ".res_conv.weight", (mid, dim_in, 1, 1)), (p + ".res_conv.bias", (mid,))]
+        u = f"dec.{ind}.{cfg.up_index}"
+        out += [(u + ".conv.weight", (mid, dim_out, 4, 4)), (u + ".conv.bias", (dim_out,))]
+    return out
+
+
+def compressor_decode(ops, cfg, sd, q_latent):
+    """Compressor.decode compress_modules.py:68-74: `for resnet, up in dec: x = up(resnet(x))`,
+    collected outputs returned finest first (`output[::-1]`)."""
+    x = np.asarray(q_latent, np.float32)
+    outs = []
+    for ind in range(len(cfg.reversed_in_out)):
+        x = resnet_block(ops, sd, f"dec.{ind}.0", x)
+        x = upsample(ops, sd, f"dec.{ind}.{cfg.up_index}", x)
+        outs.append(x)
+    return outs[::-1]

@@ -247,6 +247,52 @@ def gen_full_res():
     print("full res ok", d["sum"])
 
 
+CTXDEC = {
+    # name: (tree, class name, ctor kwargs, up_index, latent h, w, B)
+    "ctxdec_small_x": ("xparam", "ResnetCompressor",
+                       dict(dim=8, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                            hyper_dims_mults=[4, 4, 4], channels=3, out_channels=8), 1, 3, 5, 2),
+    "ctxdec_small_eps": ("epsilonparam", "BigCompressor",
+                         dict(dim=8, dim_mults=(1, 2, 3, 4), hyper_dims_mults=(4, 4, 4), channels=3,
+                              out_channels=3, vbr=False), 2, 4, 4, 2),
+    "ctxdec_full_x": ("xparam", "ResnetCompressor",
+                      dict(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                           hyper_dims_mults=[4, 4, 4], channels=3, out_channels=64), 1, 4, 4, 1),
+    "ctxdec_full_eps": ("epsilonparam", "BigCompressor",
+                        dict(dim=64, dim_mults=(1, 2, 3, 4), hyper_dims_mults=(4, 4, 4), channels=3,
+                             out_channels=3, vbr=False), 2, 4, 4, 1),
+}
+
+
+def gen_ctxdec(name):
+    """Compressor.decode of the real reference on a synthetic q_latent: the `dec.*` parameters come
+    from synth (the rest of the module is untouched and unused), outputs stored in full for the small
+    configurations and as digests for the full-width ones."""
+    tree, cls, kw, up_index, hl, wl, B = CTXDEC[name]
+    ref = import_reference(tree)
+    net = getattr(ref.cm, cls)(**kw)
+    man = [(k, list(v.shape)) for k, v in net.state_dict().items() if k.startswith("dec.")]
+    sd = synth.unet_state_dict(man, seed=5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net.eval()
+    c0 = man[0][1][1]                                   # dec.0.0.block1.block.0.weight: [mid][Cin][3][3]
+    q = np.round(synth.normal("q_latent", (B, c0, hl, wl), seed=6, std=2.0)).astype(np.float32)
+    with torch.no_grad():
+        outs = [o.numpy() for o in net.decode(torch.from_numpy(q))]
+    json.dump({"kwargs": {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items()},
+               "class": cls, "tree": tree, "up_index": up_index, "manifest": man},
+              open(os.path.join(HERE, f"manifest_{name}.json"), "w"))
+    rec = {"q_latent": q}
+    for i, o in enumerate(outs):
+        if o.size <= 70000:
+            rec[f"out{i}"] = o
+        d = digest(o)
+        rec.update({f"out{i}_shape": np.array(o.shape), f"out{i}_idx": d["idx"], f"out{i}_val": d["val"],
+                    f"out{i}_sum": d["sum"], f"out{i}_sumsq": d["sumsq"]})
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "ok", [o.shape for o in outs])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_schedules()
@@ -256,3 +302,5 @@ if __name__ == "__main__":
     gen_decode("full_x", [3])
     gen_decode("full_eps", [3])
     gen_full_res()
+    for n in CTXDEC:
+        gen_ctxdec(n)

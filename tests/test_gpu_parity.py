@@ -3,6 +3,7 @@
 
 Tolerance: float32 path, max-abs error <= 1e-4 * max(1, max|ref|) (north_star: fp32 tolerance;
 observed reference-vs-fp64 round-off is ~7e-6, see tests/test_oracle.py)."""
+import json
 import os
 
 import numpy as np
@@ -239,3 +240,52 @@ def test_run_to_run_determinism(G):
     y0 = un(x, time, ctx)
     for _ in range(12):
         np.testing.assert_array_equal(un(x, time, ctx), y0)
+
+
+# ---- context decoder: Compressor.decode ----------------------------------
+
+def _ctxdec(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    kw = meta["kwargs"]
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    sd = synth.unet_state_dict(man, seed=5)
+    m = getattr(cdc, meta["class"])(**kw)
+    m.load_state_dict(sd)
+    rev = kw["reverse_dim_mults"] if "reverse_dim_mults" in kw else list(reversed(kw["dim_mults"]))
+    cfg = om.CompressorConfig(dim=kw["dim"], rev_mults=rev, out_channels=kw["out_channels"],
+                              up_index=meta["up_index"])
+    return m, cfg, sd, np.load(os.path.join(GOLDEN, f"{name}.npz"))
+
+
+@pytest.mark.parametrize("name", ["ctxdec_small_x", "ctxdec_small_eps", "ctxdec_full_x", "ctxdec_full_eps"])
+def test_context_decoder_matches_reference_golden(name):
+    m, cfg, sd, g = _ctxdec(name)
+    outs = m.decode(g["q_latent"])
+    assert len(outs) == len(cfg.rev_mults)
+    for i, o in enumerate(outs):
+        assert list(o.shape) == list(g[f"out{i}_shape"])
+        flat = o.reshape(-1)
+        assert relerr(flat[g[f"out{i}_idx"]], g[f"out{i}_val"]) < TOL
+        assert abs(float(flat.astype(np.float64).sum()) - float(g[f"out{i}_sum"])) < 1e-4 * flat.size
+        if f"out{i}" in g.files:
+            assert relerr(o, g[f"out{i}"]) < TOL
+
+
+def test_context_decoder_matches_oracle_other_shape_and_feeds_the_unet(O):
+    """Another batch / latent size against the CPU restatement, then the decoded pyramid drives the
+    denoising U-Net exactly like a host-made context list (decompress(q_latent, ...))."""
+    m, cfg, sd, _ = _ctxdec("ctxdec_full_x")
+    q = np.round(synth.normal("q2", (2, 256, 2, 4), seed=9, std=2.0)).astype(np.float32)
+    outs = m.decode(q)
+    ref = om.compressor_decode(O, cfg, sd, q)
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape
+        assert relerr(o, r) < TOL
+    un, kw, usd, x, time, ctx, g = make_unet("full_x")
+    diff = cdc.GaussianDiffusionX(un, m, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    shape = (2, 3, 32, 64)
+    init = synth.normal("init", shape, seed=1, std=0.8)
+    a = diff.decompress(q, shape, sample_steps=2, init=init)
+    b = diff.decompress(outs, shape, sample_steps=2, init=init)
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).all() and np.abs(a).max() <= 1.0 + 1e-6

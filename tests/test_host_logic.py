@@ -104,3 +104,37 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "synth.py", f"{f} mentions the oracle"
+
+
+# ---- context decoder -----------------------------------------------------
+
+def _ctxdec_model(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    cls = getattr(cdc, meta["class"])
+    return cls(**meta["kwargs"]), meta
+
+
+@pytest.mark.parametrize("name", ["ctxdec_small_x", "ctxdec_small_eps", "ctxdec_full_x", "ctxdec_full_eps"])
+def test_ctxdec_manifest_matches_reference_state_dict(name):
+    m, meta = _ctxdec_model(name)
+    assert [(n, list(s)) for n, s in m.manifest()] == [(n, list(s)) for n, s in meta["manifest"]]
+
+
+def test_ctxdec_load_state_dict_takes_dec_entries_only():
+    m, meta = _ctxdec_model("ctxdec_small_x")
+    sd = {k: np.zeros(s, np.float32) for k, s in meta["manifest"]}
+    bad = dict(sd)
+    bad.pop(meta["manifest"][3][0])
+    with pytest.raises(RuntimeError, match="missing"):
+        m.load_state_dict(bad)
+    bad = dict(sd)
+    bad["dec.9.0.block1.block.0.weight"] = np.zeros((1,), np.float32)
+    with pytest.raises(RuntimeError, match="unexpected"):
+        m.load_state_dict(bad)
+    with pytest.raises(NotImplementedError):
+        m.encode(np.zeros((1, 3, 64, 64), np.float32))
+    if not _has_gpu():
+        full = dict(sd)
+        full["enc.0.0.block1.block.0.weight"] = np.zeros((8, 3, 7, 7), np.float32)   # encoder keys are ignored
+        with pytest.raises(_lib.CdcError):      # finalize needs the GPU: loud failure, no CPU fallback
+            m.load_state_dict(full)

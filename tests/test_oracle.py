@@ -1,5 +1,6 @@
 """CPU tests: pin the oracle (oracle/) against golden vectors produced by the REAL reference
 (tests/golden/make_golden.py) and cross-check its C primitives against pure numpy."""
+import json
 import os
 
 import numpy as np
@@ -130,3 +131,44 @@ def test_full_width_decode_matches_reference(O):
         rec = om.p_sample_loop(O, cfg, sd, s, x.shape, ctx, clip, init=init)
         ref = g["decode_3"]
         assert np.abs(rec - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name
+
+
+# ---- context decoder -----------------------------------------------------
+
+CTXDEC_CASES = ["ctxdec_small_x", "ctxdec_small_eps", "ctxdec_full_x", "ctxdec_full_eps"]
+
+
+def _ctxdec_case(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    kw = meta["kwargs"]
+    rev = kw["reverse_dim_mults"] if "reverse_dim_mults" in kw else list(reversed(kw["dim_mults"]))
+    cfg = om.CompressorConfig(dim=kw["dim"], rev_mults=rev, out_channels=kw["out_channels"],
+                              up_index=meta["up_index"])
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    return cfg, man, g
+
+
+@pytest.mark.parametrize("name", CTXDEC_CASES)
+def test_ctxdec_manifest_matches_reference(name):
+    cfg, man, _ = _ctxdec_case(name)
+    assert om.compressor_dec_manifest(cfg) == man
+
+
+@pytest.mark.parametrize("name", CTXDEC_CASES)
+def test_ctxdec_oracle_matches_reference_golden(name):
+    """Compressor.decode of the real reference (synthetic `dec.*` parameters, integer-valued q_latent)
+    vs the CPU restatement: full tensors for the small configurations, digests for the full-width ones."""
+    cfg, man, g = _ctxdec_case(name)
+    sd = synth.unet_state_dict(man, seed=5)
+    outs = om.compressor_decode(oops.OrcOps("f32"), cfg, sd, g["q_latent"])
+    assert len(outs) == len(cfg.rev_mults)
+    for i, o in enumerate(outs):
+        assert list(o.shape) == list(g[f"out{i}_shape"])
+        flat = o.reshape(-1)
+        scale = max(1.0, float(np.abs(g[f"out{i}_val"]).max()))
+        assert np.abs(flat[g[f"out{i}_idx"]] - g[f"out{i}_val"]).max() <= 1e-4 * scale
+        assert abs(float(flat.astype(np.float64).sum()) - float(g[f"out{i}_sum"])) <= 1e-4 * flat.size
+        if f"out{i}" in g.files:
+            ref = g[f"out{i}"]
+            assert np.abs(o - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
