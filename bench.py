@@ -26,10 +26,10 @@ sys.path.insert(0, ROOT)
 FULL = {
     "x": dict(kw=dict(dim=64, channels=3, context_channels=64, dim_mults=(1, 2, 3, 4, 5, 6),
                       context_dim_mults=(1, 2, 3, 4)), ctx=[64, 64, 128, 192], T=8193, vs="cosine",
-              gflop_per_image_step=128.97),
+              gflop_per_image_step=128.97, gb_per_image_step=0.714),
     "eps": dict(kw=dict(dim=64, channels=3, context_channels=3, dim_mults=(1, 2, 3, 4, 5, 6),
                         context_dim_mults=(1, 2, 3, 4)), ctx=[3, 64, 128, 192], T=20000, vs="linear",
-                gflop_per_image_step=103.39),
+                gflop_per_image_step=103.39, gb_per_image_step=0.682),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak
@@ -176,12 +176,34 @@ def main():
                 "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                 "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                 "traffic": None,
+                # PMC pass of the dominant launch shape, collected separately (rocprofv3 --pmc FETCH_SIZE /
+                # WRITE_SIZE, gfx950 x2 read correction): profiles/pmc_r01_v4_conv3x3_64_256_traffic.txt
+                "traffic_sample": {"launch": "conv_split2_kernel<2,2,0>, 64->64 3x3 @256x256, batch 32",
+                                   "hbm_bytes": 2.0511e9, "algorithmic_bytes": 1.0737e9},
                 "whole_path_tflops": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value,
+                # both whole-path terms on the canonical (fused-minimum) work
+                "whole_path_mfma_frac_of_split_peak": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value / peak,
+                "whole_path_hbm_frac": ((cfgd["gb_per_image_step"] + 0.160 / B) * 1e9 * a.sample_steps * value) / 8e12,
                 "class_ms_share": {k: (v["ms"] / tot_ms if tot_ms else 0) for k, v in classes.items()},
                 "class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
                                  for k, v in classes.items()},
             },
         }
+        if world == 1 and a.param == "x" and S % 16 == 0:
+            # informational (outside the timed region): Compressor.decode on the GPU, q_latent -> pyramid
+            dec = cdc.ResnetCompressor(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                                       hyper_dims_mults=[4, 4, 4], channels=3, out_channels=64, device=local)
+            dec.load_state_dict(synth.unet_state_dict(dec.manifest(), seed=5))
+            q = torch.round(torch.randn((B, 256, S // 16, S // 16), generator=gen, device=dev) * 2.0)
+            dec.decode(q)
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(5):
+                pyr = dec.decode(q)
+            torch.cuda.synchronize()
+            out["context_decode"] = {"ms_per_batch": (time.perf_counter() - tq) / 5 * 1e3, "batch": B,
+                                     "finite": bool(all(torch.isfinite(p).all().item() for p in pyr)),
+                                     "note": "Compressor.decode (SURVEY 8f row 1), once per image, not in `value`"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
         out["roofline"]["class_ms_per_ddim_iter"] = {k: v["ms"] / max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps) for k, v in classes.items()}
