@@ -264,7 +264,9 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU)) conv
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int WN = nthr >> 6;
     int z = blockIdx.z, ks = 0;
+    unsigned bid0 = blockIdx.x;
     if (P.ksplit > 1) { ks = z / P.nzz; z -= ks * P.nzz; }
+    if (P.zfold) { const unsigned g8 = bid0 >> 5, r = bid0 & 31; z = (int)(r >> 3); bid0 = g8 * 8 + (r & 7); }
     const int cog = blockIdx.y;
 
     const int NBW = 1 << P.lognbw;
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU)) conv
     // Small feature maps: the workgroup covers ipw whole images, wpi waves each, so that the weight
     // stages are shared by four waves even when an image has only one or two 32-pixel blocks.
     const int ipw = P.ipw, wpi = WN / ipw;
-    int bid = blockIdx.x, tx = 0, ty = 0, b;
+    int bid = (int)bid0, tx = 0, ty = 0, b;
     if (ipw > 1) {
         b = bid * ipw + wave / wpi;
     } else {
@@ -518,6 +520,9 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU)) conv
 #endif
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats) + a_lane;
             int ky = (grp * TG) / P.KW, kx = grp * TG - ky * P.KW;      // uniform tap walk (SALU)
+#ifdef CDC_AB_PRIO
+            __builtin_amdgcn_s_setprio(CDC_AB_PRIO);
+#endif
             for (int t = 0; t < TG; ++t) {
                 const uint4 *xb = reinterpret_cast<const uint4 *>(xc) +
                                   (ky * PW + (s2 ? ((kx + xs) & 1) * (PW / 2) + ((kx + xs) >> 1) : kx));
@@ -549,6 +554,9 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU)) conv
 #endif
                 }
             }
+#ifdef CDC_AB_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             TL();
             dma_wait();
             TL();
