@@ -68,6 +68,7 @@ struct ConvArgs {
     // [ks*nchunk/ksplit, (ks+1)*nchunk/ksplit) and stores its partial sums at out + ks*out_ks (bias in
     // slice 0); the consumer (ln_kernel_sliced) adds the slices.
     int ksplit, nzz;
+    int xcd_remap;  // gridDim.x % 8 == 0: tile = (id % 8) * (gridDim.x / 8) + id / 8
     int zfold;      // transposed conv: the 4 phases of a tile are consecutive-by-8 workgroup ids in gridDim.x, so
                     // they run on ONE XCD at about the same time and the L2 merges their interleaved stores
     long long out_ks;

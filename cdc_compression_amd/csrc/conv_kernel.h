@@ -292,6 +292,7 @@ __global__ void __launch_bounds__(256, conv_min_waves(MB, NPW)) conv_mfma_kernel
     const int cog = blockIdx.y;
 
     int bid = blockIdx.x;
+    if (P.xcd_remap) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);   // one contiguous tile band per XCD
     const int tx = bid % P.tiles_x;
     bid /= P.tiles_x;
     const int ty = bid % P.tiles_y;

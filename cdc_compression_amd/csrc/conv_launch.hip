@@ -283,6 +283,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
               (unsigned)(nz * a.ksplit));
     a.zfold = 0;
+    a.xcd_remap = (p.split != 1 && p.ipw == 1 && grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
     if (p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0 && !getenv("CDC_NO_ZFOLD")) {
         a.zfold = 1; grid.x *= 4; grid.z = 1;
     }

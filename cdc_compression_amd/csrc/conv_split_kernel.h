@@ -267,6 +267,9 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU)) conv
     unsigned bid0 = blockIdx.x;
     if (P.ksplit > 1) { ks = z / P.nzz; z -= ks * P.nzz; }
     if (P.zfold) { const unsigned g8 = bid0 >> 5, r = bid0 & 31; z = (int)(r >> 3); bid0 = g8 * 8 + (r & 7); }
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs; give every XCD a contiguous band
+    // of tiles so that neighbouring tiles (shared halo rows, same weights) meet in ONE L2
+    else if (P.xcd_remap) bid0 = (bid0 & 7) * (gridDim.x >> 3) + (bid0 >> 3);
     const int cog = blockIdx.y;
 
     const int NBW = 1 << P.lognbw;
