@@ -1,0 +1,170 @@
+// attn_kernels.hip -- fused front half of the folded linear attention (network_components.py:128-136):
+//
+//     k, v = W_kv LN(x)          (1x1 projection, PreNorm LayerNorm folded into the weights)
+//     ctx  = softmax_N(k) v^T    (C x C per image)
+//
+// in ONE pass over x: k and v (2C x N floats per image, 2.1 GB at 256x256 / batch 32) never reach HBM and
+// the separate row-maximum pass disappears.  Per workgroup (image b, pixel split s), per 32-pixel tile:
+//   phase 1  kv[2C][32] = W'[2C][C] (x - mean)    v_mfma_f32_32x32x2_f32, the wave's rows of W' live in
+//            registers for the whole kernel; each wave owns 2C/128 row blocks; scaled by rstd, + W b_ln
+//   LDS      the tile is written [channel][pixel] so that phase 2 reads it transposed (lane = channel)
+//   phase 2  S[d][e] += sum_n exp(k[d][n] - m[d]) v[e][n]   with a running row maximum m (online softmax:
+//            when a tile raises m the accumulated rows are rescaled by exp(m_old - m_new))
+// Outputs per (b, s): S [C][C], Z[d] = sum_n exp(k - m), M[d] = m; ctx_r0 combines the splits.
+// All products and sums are IEEE fp32 (the f32 MFMA is an fmaf chain), exp is expf.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "cdc_internal.h"
+
+namespace cdc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CB>      // C = 32 * CB
+__global__ void __launch_bounds__(256, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtxArgs a) {
+    constexpr int C = 32 * CB, NBLK = 2 * CB;        // kv row blocks of 32 channels
+    constexpr int BPW = NBLK / 4;                     // row blocks per wave in phase 1
+    constexpr int SPW = CB * CB / 4;                  // S blocks per wave in phase 2
+    constexpr int LDK = 33;                           // padded pixel stride of the LDS tile
+    static_assert(NBLK % 4 == 0 && (CB * CB) % 4 == 0, "4 waves share the blocks evenly");
+    __shared__ float kv[2 * C * LDK];
+    __shared__ __attribute__((aligned(16))) float fac[4][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int N = a.N;
+    const int per = N / a.nsplit;                     // pixels of this split (multiple of 32, host-enforced)
+    const int p0 = sp * per;
+    const float *x = a.x + (size_t)b * a.x_bs;
+    const float *mean = a.mean + (size_t)b * N, *rstd = a.rstd + (size_t)b * N;
+
+    // ---- the wave's rows of W' (A operand: lane (i = j, k = kh) holds W'[row i][channel 2s + kh]) ----
+    float wr[BPW][C / 2], bias[BPW][16];
+#pragma unroll
+    for (int q = 0; q < BPW; ++q) {
+        const int blk = wave * BPW + q;
+#pragma unroll
+        for (int s = 0; s < C / 2; ++s) wr[q][s] = a.Wt[(size_t)(2 * s + kh) * (2 * C) + blk * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[q][r] = a.bias[blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+    }
+    // ---- phase-2 ownership: CB = 2: wave -> (d block wave>>1, e block wave&1); CB = 4: wave -> d block, all e
+    const int db = CB == 2 ? wave >> 1 : wave;
+    const int eb0 = CB == 2 ? (wave & 1) : 0;
+    f32x16 S[SPW];
+#pragma unroll
+    for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[q][r] = 0.f;
+    float m_run = -INFINITY, zsum = 0.f;             // row d = db*32 + j (both halves of the wave hold it)
+
+    // The tile's B operand (lane = pixel j, channel 2s + kh) is fetched one tile ahead: the loads of tile
+    // t+1 are in flight during the LDS / softmax / phase-2 part of tile t.
+    float xn[C / 2], mu_n, rs_n;
+    const char *xb = reinterpret_cast<const char *>(x);             // wave-uniform base; lane part = voff
+    {
+        const int px = p0 + j;
+        mu_n = mean[px]; rs_n = rstd[px];
+        const unsigned voff = (unsigned)(kh * N + px) * 4u;
+#pragma unroll
+        for (int s = 0; s < C / 2; ++s)
+            xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(2 * s) * N * 4 + voff);
+    }
+    for (int t0 = 0; t0 < per; t0 += 32) {
+        const float mu = mu_n, rs = rs_n;
+        // ---- phase 1 -------------------------------------------------------------------------------
+        f32x16 acc[BPW];
+#pragma unroll
+        for (int q = 0; q < BPW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < C / 2; ++s) {
+            const float xv = xn[s] - mu;
+#pragma unroll
+            for (int q = 0; q < BPW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[q][s], xv, acc[q], 0, 0, 0);
+        }
+        if (t0 + 32 < per) {
+            const int px = p0 + t0 + 32 + j;
+            mu_n = mean[px]; rs_n = rstd[px];
+            const unsigned voff = (unsigned)(kh * N + px) * 4u;
+#pragma unroll
+            for (int s = 0; s < C / 2; ++s)
+                xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(2 * s) * N * 4 + voff);
+        }
+        if (t0) __syncthreads();                      // every wave finished reading the previous tile
+#pragma unroll
+        for (int q = 0; q < BPW; ++q) {
+            const int blk = wave * BPW + q;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                kv[row * LDK + j] = acc[q][r] * rs + bias[q][r];
+            }
+        }
+        __syncthreads();
+        // ---- phase 2 -------------------------------------------------------------------------------
+        const float *krow = kv + (db * 32 + j) * LDK + kh;      // k[d][2s + kh]
+        float kk[16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { kk[s] = krow[2 * s]; tmax = fmaxf(tmax, kk[s]); }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        if (__any(tmax > m_run)) {                   // a new row maximum somewhere in the block: rescale
+            const float mn = fmaxf(m_run, tmax);
+            const float f = expf(m_run - mn);         // exp(-inf) = 0 on the first tile
+            m_run = mn;
+            zsum *= f;
+            if (kh == 0) fac[wave][j] = f;
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the wave's own LDS writes are visible
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 f4 = *reinterpret_cast<const float4 *>(&fac[wave][8 * r4 + 4 * kh]);
+#pragma unroll
+                for (int q = 0; q < SPW; ++q) {
+                    S[q][4 * r4 + 0] *= f4.x; S[q][4 * r4 + 1] *= f4.y;
+                    S[q][4 * r4 + 2] *= f4.z; S[q][4 * r4 + 3] *= f4.w;
+                }
+            }
+        }
+        float pv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { pv[s] = expf(kk[s] - m_run); zsum += pv[s]; }
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const float *vrow = kv + (C + (eb0 + q) * 32 + j) * LDK + kh;   // v[e][2s + kh]
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                S[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[s], vrow[2 * s], S[q], 0, 0, 0);
+        }
+    }
+    // ---- partial results of this split ---------------------------------------------------------------
+    const size_t slot = (size_t)b * a.nsplit + sp;
+#pragma unroll
+    for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            a.S[(slot * C + d) * C + (eb0 + q) * 32 + j] = S[q][r];
+        }
+    zsum += __shfl_xor(zsum, 32);
+    if (kh == 0 && eb0 == 0) {
+        a.Z[slot * C + db * 32 + j] = zsum;
+        a.M[slot * C + db * 32 + j] = m_run;
+    }
+}
+
+hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
+    if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)a.nsplit, (unsigned)B);
+    if (a.C == 64) hipLaunchKernelGGL(kvctx_kernel<2>, grid, dim3(256), 0, st, a);
+    else if (a.C == 128) hipLaunchKernelGGL(kvctx_kernel<4>, grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace cdc

@@ -481,15 +481,26 @@ constexpr int kFoldRows = 8;     // rows per workgroup: each WoT / T1 element is
 
 // R0: ctxn[b][d][e] = (sum_split S) / (sum_split Zp)   -- one thread per element, coalesced over e
 __global__ void __launch_bounds__(256) ctx_r0_kernel(const float *S, const float *Zp, int C, int nsplit,
-                                                     float *ctxn) {
+                                                     float *ctxn, const float *M) {
     const int b = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= C * C) return;
     const int d = idx / C;
     float s = 0.f, z = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
-        s += S[((size_t)b * nsplit + sp) * C * C + idx];
-        z += Zp[((size_t)b * nsplit + sp) * C + d];
+    if (M) {
+        // every split carries its own row maximum (kvctx_kernel): bring them to the common one
+        float mg = -INFINITY;
+        for (int sp = 0; sp < nsplit; ++sp) mg = fmaxf(mg, M[((size_t)b * nsplit + sp) * C + d]);
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float f = expf(M[((size_t)b * nsplit + sp) * C + d] - mg);
+            s += S[((size_t)b * nsplit + sp) * C * C + idx] * f;
+            z += Zp[((size_t)b * nsplit + sp) * C + d] * f;
+        }
+    } else {
+        for (int sp = 0; sp < nsplit; ++sp) {
+            s += S[((size_t)b * nsplit + sp) * C * C + idx];
+            z += Zp[((size_t)b * nsplit + sp) * C + d];
+        }
     }
     ctxn[(size_t)b * C * C + idx] = s / z;
 }
@@ -572,10 +583,10 @@ __global__ void __launch_bounds__(256) ctx_r3_kernel(const float *T1, const floa
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
-                           float *biasB, int B, hipStream_t st) {
+                           float *biasB, int B, hipStream_t st, const float *M) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     // Mt doubles as scratch for the normalised context (C*C <= Cin_pad*COP) until R2 overwrites it
-    hipLaunchKernelGGL(ctx_r0_kernel, dim3(ceil_div(C * C, 256), B), dim3(256), 0, st, S, ksum, C, nsplit, Mt);
+    hipLaunchKernelGGL(ctx_r0_kernel, dim3(ceil_div(C * C, 256), B), dim3(256), 0, st, S, ksum, C, nsplit, Mt, M);
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
                        sizeof(float) * kFoldRows * C, st, Mt, C, WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),

@@ -55,10 +55,11 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
                   ConvW c1u; bool has_unfold = false; bool has_mlp = true; };   // c1x as a KH x 1 conv over KW*cx unfolded channels
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
-               ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr; };   // folded output; uq = Wq b_ln
+               ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr;
+               float *kvWt = nullptr, *kvb = nullptr; };   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX } kind;
     int prof = PC_SMALL;
     int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
     char label[96] = {0};
@@ -72,7 +73,9 @@ struct Op {
     struct { const float *P, *bias; float *out; int Cout, KH, pad, H, W; } cb;
     DdimArgs ddim;
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
-    int cp_parts = 1; long long cp_part_stride = 0;   // COPY: dst = sum of cp_parts planes of src
+    int cp_parts = 1; long long cp_part_stride = 0;
+    KvCtxArgs kvc;
+    const float *at_M = nullptr;  // CTXF after KVCTX: per-split row maxima   // COPY: dst = sum of cp_parts planes of src
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
 };
 
@@ -468,6 +471,20 @@ int pack_attn(cdc_handle *h, const std::string &p, int c) {
             uq[d] = (float)acc;
         }
         if ((rc = upload(h, uq.data(), uq.size(), &a.uq, &h->weight_allocs))) return rc;
+        // fused kv-projection + context kernel (attn_kernels.hip): W' = W_kv diag(g) transposed, bias' = W_kv b_ln
+        const auto &g = hostp(h, p + ".fn.norm.g");
+        std::vector<float> wt((size_t)c * 2 * c), kb(2 * c);
+        for (int co = 0; co < 2 * c; ++co) {
+            double acc = 0;
+            for (int ci = 0; ci < c; ++ci) {
+                const float v = wq[(size_t)(c + co) * c + ci];          // k rows then v rows of to_qkv
+                wt[(size_t)ci * 2 * c + co] = v * g[ci];
+                acc += (double)v * bn[ci];
+            }
+            kb[co] = (float)acc;
+        }
+        if ((rc = upload(h, wt.data(), wt.size(), &a.kvWt, &h->weight_allocs))) return rc;
+        if ((rc = upload(h, kb.data(), kb.size(), &a.kvb, &h->weight_allocs))) return rc;
     }
     h->attns.push_back(a);
     return CDC_OK;
@@ -492,7 +509,7 @@ struct Builder {
         op.id = (int)h->op_ms.size();
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
-        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold"};
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx"};
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
@@ -501,6 +518,8 @@ struct Builder {
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
+        else if (op.kind == Op::KVCTX)
+            snprintf(buf, sizeof buf, "kvctx C=%d N=%d nsplit=%d", op.kvc.C, op.kvc.N, op.kvc.nsplit);
         else if (op.kind == Op::KSTATS || op.kind == Op::CTXP || op.kind == Op::CTXR || op.kind == Op::CTXF)
             snprintf(buf, sizeof buf, "%s C=%d N=%d nsplit=%d", kinds[op.kind], op.at.C, op.at.N, op.at.nsplit);
         else
@@ -822,16 +841,24 @@ struct Builder {
         if (rc) return Act();
         const int C = at.C, H = x.H, W = x.W, N = H * W;
         const bool fold = at.WoT && N >= 16 * C && !getenv("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
+        // C = 64 levels: k/v projection, row maxima and softmax(k) v^T in ONE pass over x (attn_kernels.hip)
+        const bool fused = fold && (C == 64 || (C == 128 && !getenv("CDC_NO_KVCTX128"))) && at.kvWt && N % 2048 == 0 && !getenv("CDC_NO_KVCTX");
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
-        Act qkv = new_act(kvc, H, W);
+        Act qkv = fused ? Act() : new_act(kvc, H, W);
         ConvOpts oq;                                   // LN(x) folded into the projection (LNMODE 2)
         oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_mode = 2;
-        conv(fold ? at.kv : at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
-        const float *kp = qkv.p + (size_t)(fold ? 0 : C) * N, *vp = kp + (size_t)C * N;
+        if (!fused)
+            conv(fold ? at.kv : at.qkv, x.p, C, x.bs(), nullptr, 0, H, W, qkv.p, qkv.bs(), oq, false, PC_CONV1);
+        const float *kp = fused ? nullptr : qkv.p + (size_t)(fold ? 0 : C) * N, *vp = fused ? nullptr : kp + (size_t)C * N;
         float *kmax = dalloc((size_t)B * C);
         const int tiles = ceil_div(C, 64);
         int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
         nsplit = std::min(nsplit, std::max(1, N / 64));
+        if (fused) {        // >= 2.6 rounds of 3 workgroups per CU (C = 64) / 4 rounds of one (C = 128)
+            nsplit = C == 64 ? ceil_div(2048, B) : ceil_div(1024, B);
+            while (nsplit > 1 && N % (32 * nsplit)) --nsplit;
+        }
+        float *kmaxs = fused ? dalloc((size_t)B * nsplit * C) : nullptr;   // per-split row maxima
         float *S = dalloc((size_t)B * nsplit * C * C);
         float *ksum = dalloc((size_t)B * nsplit * C);      // per-split partial sums of exp(k - max)
         const int Cin_pad = round_up(C, 16), COP = round_up(C, 32);
@@ -840,14 +867,22 @@ struct Builder {
         float *biasB = fold ? dalloc((size_t)B * C) : nullptr;
         if (rc) return Act();
         Op k; k.kind = Op::KSTATS; k.prof = PC_SMALL;
-        k.at = {kp, vp, qkv.bs(), C, N, kmax, ksum, S, ctxw, nsplit, Cin_pad, COP,
+        k.at = {kp, vp, fused ? 0 : qkv.bs(), C, N, kmax, ksum, S, ctxw, nsplit, Cin_pad, COP,
                 1.0f / sqrtf((float)C), at.WoT, at.WqT, T1, at.ng, at.uq, at.out.bias, biasB};
         k.bytes = 8.0 * B * C * N;
-        emit(k);
-        Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
-        p.flops = 2.0 * B * (double)C * C * N; p.bytes = 8.0 * B * C * N;
-        emit(p);
+        if (fused) {
+            Op f; f.kind = Op::KVCTX; f.prof = PC_ATTN_CTX;
+            f.kvc = {x.p, x.bs(), sm, sr, at.kvWt, at.kvb, C, N, nsplit, S, ksum, kmaxs};
+            f.flops = 6.0 * B * (double)C * C * N; f.bytes = 4.0 * B * C * N;
+            emit(f);
+        } else {
+            emit(k);
+            Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
+            p.flops = 2.0 * B * (double)C * C * N; p.bytes = 8.0 * B * C * N;
+            emit(p);
+        }
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
+        r.at_M = kmaxs;
         r.bytes = 4.0 * B * nsplit * C * C;
         r.flops = fold ? 4.0 * B * (double)C * C * C : 0.0;
         emit(r);
@@ -855,6 +890,7 @@ struct Builder {
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
         cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1; cw.bias = nullptr;
         Act y = new_act(C, H, W);
+        if (!fused)
         dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
         if (fold) {
@@ -1065,10 +1101,11 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             HIP_TRY(h, ctx_reduce_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale,
                                          op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
             break;
+        case Op::KVCTX: HIP_TRY(h, kvctx_launch(op.kvc, B, st)); break;
         case Op::CTXF:
             HIP_TRY(h, ctx_fold_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale, op.at.WoT,
                                        op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, op.at.ln_g,
-                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st));
+                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M));
             break;
         case Op::COMBINE:
             HIP_TRY(h, fold_combine_launch(op.cb.P, op.cb.bias, op.cb.out, op.cb.Cout, op.cb.KH, op.cb.pad,

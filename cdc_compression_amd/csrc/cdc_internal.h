@@ -74,6 +74,17 @@ struct TembArgs {
 hipError_t temb_launch(const TembArgs &a, int B, hipStream_t st);
 
 // k-softmax statistics over the spatial axis (network_components.py:134): per (b, channel) row
+// Fused k/v projection + softmax_N(k) v^T of the folded attention levels (attn_kernels.hip).
+struct KvCtxArgs {
+    const float *x; long long x_bs;     // PreNorm input [B][C][N]
+    const float *mean, *rstd;           // [B][N] LayerNorm statistics of x
+    const float *Wt;                    // [C][2C]: (W_kv diag(g))^T, k rows then v rows
+    const float *bias;                  // [2C]: W_kv b_ln
+    int C, N, nsplit;
+    float *S, *Z, *M;                   // [B][nsplit][C][C], [B][nsplit][C], [B][nsplit][C]
+};
+hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st);
+
 hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, int B,
                          hipStream_t st);
 // S[b][split][d][e] = sum_{n in split} exp(k[d,n]-kmax[d]) * v[e,n]      (:135, unnormalised)
@@ -88,7 +99,7 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
-                           float *biasB, int B, hipStream_t st);
+                           float *biasB, int B, hipStream_t st, const float *M = nullptr);
 hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
                                int pad, int H, int W, int B, hipStream_t st);
 

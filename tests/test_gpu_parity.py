@@ -97,7 +97,7 @@ def test_layernorm_matches_oracle(O, G):
     assert relerr(G.chan_layernorm(x, g, b), O.chan_layernorm(x, g, b)) < 1e-5
 
 
-@pytest.mark.parametrize("case", [(2, 16, 8, 8), (1, 64, 32, 32), (2, 128, 16, 16), (1, 384, 8, 8),
+@pytest.mark.parametrize("case", [(2, 16, 8, 8), (1, 64, 32, 32), (2, 64, 64, 64), (1, 128, 64, 64), (2, 128, 16, 16), (1, 384, 8, 8),
                                   (1, 24, 12, 20), (1, 64, 64, 64)])
 def test_linear_attention_matches_oracle(O, G, case):
     B, C, H, W = case
