@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtx
     constexpr int SPW = CB * CB / 4;                  // S blocks per wave in phase 2
     constexpr int LDK = 33;                           // padded pixel stride of the LDS tile
     static_assert(NBLK % 4 == 0 && (CB * CB) % 4 == 0, "4 waves share the blocks evenly");
-    __shared__ float kv[2 * C * LDK];
+    __shared__ float kvbuf[2][2 * C * LDK];         // double-buffered tile: one barrier per tile
     __shared__ __attribute__((aligned(16))) float fac[4][32];
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtx
             for (int s = 0; s < C / 2; ++s)
                 xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(2 * s) * N * 4 + voff);
         }
-        if (t0) __syncthreads();                      // every wave finished reading the previous tile
+        float *kv = kvbuf[(t0 >> 5) & 1];             // the barrier of tile t orders it after every read of tile t-2
 #pragma unroll
         for (int q = 0; q < BPW; ++q) {
             const int blk = wave * BPW + q;
