@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <stdlib.h>
 
 #include "cdc_internal.h"
 
@@ -22,15 +23,16 @@ namespace cdc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CB>      // C = 32 * CB
-__global__ void __launch_bounds__(256, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtxArgs a) {
+template <int CB, int NW>      // C = 32 * CB channels, NW waves per workgroup
+__global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtxArgs a) {
     constexpr int C = 32 * CB, NBLK = 2 * CB;        // kv row blocks of 32 channels
-    constexpr int BPW = NBLK / 4;                     // row blocks per wave in phase 1
-    constexpr int SPW = CB * CB / 4;                  // S blocks per wave in phase 2
+    constexpr int BPW = NBLK / NW;                    // row blocks per wave in phase 1
+    constexpr int SPW = CB * CB / NW;                 // S blocks per wave in phase 2
+    constexpr int WPD = NW / CB;                      // waves sharing one d block (each takes SPW e blocks)
     constexpr int LDK = 33;                           // padded pixel stride of the LDS tile
-    static_assert(NBLK % 4 == 0 && (CB * CB) % 4 == 0, "4 waves share the blocks evenly");
+    static_assert(NBLK % NW == 0 && (CB * CB) % NW == 0 && NW % CB == 0, "the waves share the blocks evenly");
     __shared__ float kvbuf[2][2 * C * LDK];         // double-buffered tile: one barrier per tile
-    __shared__ __attribute__((aligned(16))) float fac[4][32];
+    __shared__ __attribute__((aligned(16))) float fac[NW][32];
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,9 +53,9 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtx
 #pragma unroll
         for (int r = 0; r < 16; ++r) bias[q][r] = a.bias[blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
     }
-    // ---- phase-2 ownership: CB = 2: wave -> (d block wave>>1, e block wave&1); CB = 4: wave -> d block, all e
-    const int db = CB == 2 ? wave >> 1 : wave;
-    const int eb0 = CB == 2 ? (wave & 1) : 0;
+    // ---- phase-2 ownership: wave -> d block wave / WPD, e blocks (wave % WPD) * SPW .. + SPW
+    const int db = wave / WPD;
+    const int eb0 = (wave % WPD) * SPW;
     f32x16 S[SPW];
 #pragma unroll
     for (int q = 0; q < SPW; ++q)
@@ -161,8 +163,10 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtx
 hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
     if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
     dim3 grid((unsigned)a.nsplit, (unsigned)B);
-    if (a.C == 64) hipLaunchKernelGGL(kvctx_kernel<2>, grid, dim3(256), 0, st, a);
-    else if (a.C == 128) hipLaunchKernelGGL(kvctx_kernel<4>, grid, dim3(256), 0, st, a);
+    static const bool w8 = getenv("CDC_KVCTX_W8") != nullptr;      // experiment: 8 waves per workgroup (no gain measured)
+    if (a.C == 64) hipLaunchKernelGGL((kvctx_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else if (a.C == 128 && w8) hipLaunchKernelGGL((kvctx_kernel<4, 8>), grid, dim3(512), 0, st, a);
+    else if (a.C == 128) hipLaunchKernelGGL((kvctx_kernel<4, 4>), grid, dim3(256), 0, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

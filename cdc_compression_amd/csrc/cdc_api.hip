@@ -842,7 +842,8 @@ struct Builder {
         const int C = at.C, H = x.H, W = x.W, N = H * W;
         const bool fold = at.WoT && N >= 16 * C && !getenv("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
         // C = 64 levels: k/v projection, row maxima and softmax(k) v^T in ONE pass over x (attn_kernels.hip)
-        const bool fused = fold && (C == 64 || (C == 128 && !getenv("CDC_NO_KVCTX128"))) && at.kvWt && N % 2048 == 0 && !getenv("CDC_NO_KVCTX");
+        const bool fused = fold && (C == 64 || (C == 128 && !getenv("CDC_NO_KVCTX128"))) &&
+                           at.kvWt && N % 2048 == 0 && !getenv("CDC_NO_KVCTX");
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
         Act qkv = fused ? Act() : new_act(kvc, H, W);
         ConvOpts oq;                                   // LN(x) folded into the projection (LNMODE 2)
