@@ -592,6 +592,10 @@ struct Builder {
             s.Wo = (W + 2 * pad_x - w.KW) / w.stride + 1;
         }
         s.B = B; s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
+        const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
+                               w.nz == 1 && !w.transposed;
+        if (!getenv("CDC_NO_KSPLIT") && !getenv("CDC_NO_KSPLIT_PLAN"))
+            s.max_ksplit = o.max_ksplit > 1 ? o.max_ksplit : (linear_ep ? 4 : 1);
         if (need_all && (w.Cout % 32)) return false;
         ConvPlan plan;
         if (!conv_make_plan(s, &plan)) {

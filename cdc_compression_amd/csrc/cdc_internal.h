@@ -30,6 +30,7 @@ struct ConvShape {
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel
     int lnmode;          // 0 none, 1 in-LDS LayerNorm of the staged input, 2 folded (1x1 only)
+    int max_ksplit = 1;  // the caller can slice K (split-K): chip fill is scored with the slices
 };
 // Chooses MB/NPW/WN/KC/tiling.  Returns false if need_all_cout cannot be honoured.
 bool conv_make_plan(const ConvShape &s, ConvPlan *plan);

@@ -212,7 +212,8 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                 if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
                 const double wgs = (p.ipw > 1 ? (double)ceil_div(s.B, p.ipw) : (double)p.tiles_x * p.tiles_y * s.B) *
                                    p.groups * s.nz;
-                const double fill = std::min(1.0, wgs * p.WN / (p.split == 2 ? 2048.0 : 1024.0));
+                const int ks_ok = p.split == 2 ? std::max(1, std::min(s.max_ksplit, p.nchunk / 4)) : 1;
+                const double fill = std::min(1.0, wgs * ks_ok * p.WN / (p.split == 2 ? 2048.0 : 1024.0));
                 const double reuse = (double)(MB * NPW) / (MB + NPW);
                 // two co-resident workgroups overlap conversion / staging with the other's MFMAs
                 // 1x1 layers are bandwidth-bound: every extra channel group re-reads the input
