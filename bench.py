@@ -89,7 +89,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ       # under torchrun always (exercises the RCCL path at N=1 too)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -112,7 +113,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,12 +127,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         rec = diff.decompress(ctx, shape, sample_steps=a.sample_steps, init=init)
-        if world > 1:
+        if use_dist:
             gathered = [torch.empty_like(rec) for _ in range(world)]
             dist.all_gather(gathered, rec)                      # the trivial result gather (RCCL)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -208,7 +209,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
         out["roofline"]["class_ms_per_ddim_iter"] = {k: v["ms"] / max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps) for k, v in classes.items()}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

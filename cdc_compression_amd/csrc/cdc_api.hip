@@ -747,7 +747,7 @@ struct Builder {
         const size_t plane_f = (size_t)B * w.Cout * H * W;
         if (!pre_add && w.wsp && w.Cout <= 8 * 48 && plane_f * 4 * 4 <= (160u << 20)) {
             // low-resolution levels: split-K partial sums into scratch, summed by the LayerNorm kernel
-            const int kmax = 4;
+            const int kmax = getenv("CDC_KMAX") ? atoi(getenv("CDC_KMAX")) : 4;
             float *part = dalloc(plane_f * kmax);
             u.max_ksplit = kmax;
             conv(w, s0, C0, bs0, s1, bs1, H, W, part, out.bs(), u, false, prof);
