@@ -22,6 +22,15 @@
 namespace cdc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// exact three-way bf16 split of an fp32 value (truncation; see conv_split_kernel.h)
+__device__ __forceinline__ void split3(float a, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(a) & 0xFFFF0000u;
+    const float r = a - __uint_as_float(h);
+    m = __float_as_uint(r) & 0xFFFF0000u;
+    l = __float_as_uint(r - __uint_as_float(m));
+}
 
 template <int CB, int NW>      // C = 32 * CB channels, NW waves per workgroup
 __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtxArgs a) {
@@ -43,13 +52,27 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
     const float *x = a.x + (size_t)b * a.x_bs;
     const float *mean = a.mean + (size_t)b * N, *rstd = a.rstd + (size_t)b * N;
 
-    // ---- the wave's rows of W' (A operand: lane (i = j, k = kh) holds W'[row i][channel 2s + kh]) ----
-    float wr[BPW][C / 2], bias[BPW][16];
+    // ---- the wave's rows of W' ---------------------------------------------------------------------
+    // C = 64: the projection runs fp32-exact on the bf16 cores (three-way split operands, six products);
+    // A operand of v_mfma_f32_32x32x16_bf16: lane (i = j, kh) holds W'[row i][16q + 8kh .. +7] per plane.
+    // C = 128 keeps v_mfma_f32_32x32x2_f32 (its split planes would not fit the register file).
+    constexpr bool kSplitP1 = CB == 2;
+    float wr[kSplitP1 ? 1 : BPW][kSplitP1 ? 1 : C / 2], bias[BPW][16];
+    bf16x8 ws[kSplitP1 ? BPW : 1][kSplitP1 ? C / 16 : 1][3];
 #pragma unroll
     for (int q = 0; q < BPW; ++q) {
         const int blk = wave * BPW + q;
+        if constexpr (kSplitP1) {
+            const uint4 *wp = reinterpret_cast<const uint4 *>(a.Ws);
 #pragma unroll
-        for (int s = 0; s < C / 2; ++s) wr[q][s] = a.Wt[(size_t)(2 * s + kh) * (2 * C) + blk * 32 + j];
+            for (int c = 0; c < C / 16; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ws[q][c][pl] = __builtin_bit_cast(bf16x8, wp[(size_t)((c * 3 + pl) * 2 + kh) * (2 * C) + blk * 32 + j]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < C / 2; ++s) wr[q][s] = a.Wt[(size_t)(2 * s + kh) * (2 * C) + blk * 32 + j];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) bias[q][r] = a.bias[blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
     }
@@ -70,10 +93,11 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
     {
         const int px = p0 + j;
         mu_n = mean[px]; rs_n = rstd[px];
-        const unsigned voff = (unsigned)(kh * N + px) * 4u;
+        // f32 MFMA: register s <-> channel 2s + kh;  bf16 MFMA: register s <-> channel 16(s/8) + 8kh + s%8
+        const unsigned voff = (unsigned)((kSplitP1 ? 8 * kh : kh) * N + px) * 4u;
 #pragma unroll
         for (int s = 0; s < C / 2; ++s)
-            xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(2 * s) * N * 4 + voff);
+            xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(kSplitP1 ? 16 * (s >> 3) + (s & 7) : 2 * s) * N * 4 + voff);
     }
     for (int t0 = 0; t0 < per; t0 += 32) {
         const float mu = mu_n, rs = rs_n;
@@ -83,19 +107,45 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
         for (int q = 0; q < BPW; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        if constexpr (kSplitP1) {
 #pragma unroll
-        for (int s = 0; s < C / 2; ++s) {
-            const float xv = xn[s] - mu;
+            for (int c = 0; c < C / 16; ++c) {
+                unsigned hh[8], mm[8], ll[8];
 #pragma unroll
-            for (int q = 0; q < BPW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[q][s], xv, acc[q], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) split3(xn[8 * c + i] - mu, hh[i], mm[i], ll[i]);
+                uint4 vh, vm, vl;
+                vh.x = (hh[0] >> 16) | hh[1]; vh.y = (hh[2] >> 16) | hh[3];
+                vh.z = (hh[4] >> 16) | hh[5]; vh.w = (hh[6] >> 16) | hh[7];
+                vm.x = (mm[0] >> 16) | mm[1]; vm.y = (mm[2] >> 16) | mm[3];
+                vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
+                vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
+                vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
+                const bf16x8 B[3] = {__builtin_bit_cast(bf16x8, vh), __builtin_bit_cast(bf16x8, vm),
+                                     __builtin_bit_cast(bf16x8, vl)};
+#pragma unroll
+                for (int q = 0; q < BPW; ++q)
+#pragma unroll
+                    for (int pa = 2; pa >= 0; --pa)          // smallest terms first, six products in all
+#pragma unroll
+                        for (int pb = 2 - pa; pb >= 0; --pb)
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[q][c][pa], B[pb], acc[q], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < C / 2; ++s) {
+                const float xv = xn[s] - mu;
+#pragma unroll
+                for (int q = 0; q < BPW; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[q][s], xv, acc[q], 0, 0, 0);
+            }
         }
         if (t0 + 32 < per) {
             const int px = p0 + t0 + 32 + j;
             mu_n = mean[px]; rs_n = rstd[px];
-            const unsigned voff = (unsigned)(kh * N + px) * 4u;
+            const unsigned voff = (unsigned)((kSplitP1 ? 8 * kh : kh) * N + px) * 4u;
 #pragma unroll
             for (int s = 0; s < C / 2; ++s)
-                xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(2 * s) * N * 4 + voff);
+                xn[s] = *reinterpret_cast<const float *>(xb + (size_t)(kSplitP1 ? 16 * (s >> 3) + (s & 7) : 2 * s) * N * 4 + voff);
         }
         float *kv = kvbuf[(t0 >> 5) & 1];             // the barrier of tile t orders it after every read of tile t-2
 #pragma unroll

@@ -56,7 +56,7 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
                ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr;
-               float *kvWt = nullptr, *kvb = nullptr; };   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
+               float *kvWt = nullptr, *kvb = nullptr; unsigned short *kvWs = nullptr; };   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
     enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX } kind;
@@ -484,6 +484,26 @@ int pack_attn(cdc_handle *h, const std::string &p, int c) {
             kb[co] = (float)acc;
         }
         if ((rc = upload(h, wt.data(), wt.size(), &a.kvWt, &h->weight_allocs))) return rc;
+        if (c % 16 == 0) {      // three bf16 planes of W' in A-operand order (kvctx_kernel, C = 64)
+            std::vector<unsigned short> sp((size_t)(c / 16) * 3 * 2 * 2 * c * 8);
+            for (int co = 0; co < 2 * c; ++co)
+                for (int ci = 0; ci < c; ++ci) {
+                    const float v = wt[(size_t)ci * 2 * c + co];
+                    uint32_t u; memcpy(&u, &v, 4);
+                    const uint32_t h1 = u & 0xFFFF0000u; float f1; memcpy(&f1, &h1, 4);
+                    const float r = v - f1; uint32_t ur; memcpy(&ur, &r, 4);
+                    const uint32_t h2 = ur & 0xFFFF0000u; float f2; memcpy(&f2, &h2, 4);
+                    const float r2 = r - f2; uint32_t h3; memcpy(&h3, &r2, 4);
+                    const uint32_t parts[3] = {h1, h2, h3};
+                    const int q = ci >> 4, kh = (ci >> 3) & 1, i = ci & 7;
+                    for (int pl = 0; pl < 3; ++pl)
+                        sp[((size_t)((q * 3 + pl) * 2 + kh) * 2 * c + co) * 8 + i] = (unsigned short)(parts[pl] >> 16);
+                }
+            float *dsp = nullptr;
+            if ((rc = upload(h, reinterpret_cast<const float *>(sp.data()), (sp.size() + 1) / 2, &dsp, &h->weight_allocs)))
+                return rc;
+            a.kvWs = reinterpret_cast<unsigned short *>(dsp);
+        }
         if ((rc = upload(h, kb.data(), kb.size(), &a.kvb, &h->weight_allocs))) return rc;
     }
     h->attns.push_back(a);
@@ -877,7 +897,7 @@ struct Builder {
         k.bytes = 8.0 * B * C * N;
         if (fused) {
             Op f; f.kind = Op::KVCTX; f.prof = PC_ATTN_CTX;
-            f.kvc = {x.p, x.bs(), sm, sr, at.kvWt, at.kvb, C, N, nsplit, S, ksum, kmaxs};
+            f.kvc = {x.p, x.bs(), sm, sr, at.kvWt, at.kvb, at.kvWs, C, N, nsplit, S, ksum, kmaxs};
             f.flops = 6.0 * B * (double)C * C * N; f.bytes = 4.0 * B * C * N;
             emit(f);
         } else {

@@ -81,6 +81,7 @@ struct KvCtxArgs {
     const float *mean, *rstd;           // [B][N] LayerNorm statistics of x
     const float *Wt;                    // [C][2C]: (W_kv diag(g))^T, k rows then v rows
     const float *bias;                  // [2C]: W_kv b_ln
+    const unsigned short *Ws;           // [C/16][3 planes][2 k-halves][2C][8] bf16: exact 3-way split of Wt (C = 64)
     int C, N, nsplit;
     float *S, *Z, *M;                   // [B][nsplit][C][C], [B][nsplit][C], [B][nsplit][C]
 };
