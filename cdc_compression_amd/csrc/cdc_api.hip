@@ -741,7 +741,8 @@ struct Builder {
         if (!conv_make_plan(s, &pu)) return true;
         const double wf = (double)pf.tiles_x * pf.tiles_y * B * pf.WN;
         const double wu = (double)pu.tiles_x * pu.tiles_y * B * pu.groups * pu.WN;
-        if (wf >= 512) return true;              // >= half of the chip's 1024 SIMDs busy
+        static const double thr = getenv("CDC_FUSE_MIN_WAVES") ? atof(getenv("CDC_FUSE_MIN_WAVES")) : 512;
+        if (wf >= thr) return true;              // >= half of the chip's 1024 SIMDs busy
         return wu < 1.5 * wf;
     }
 
