@@ -178,9 +178,9 @@ def main():
                 "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                 "traffic": None,
                 # PMC pass of the dominant launch shape, collected separately (rocprofv3 --pmc FETCH_SIZE /
-                # WRITE_SIZE, gfx950 x2 read correction): profiles/pmc_r01_v4_conv3x3_64_256_traffic.txt
+                # WRITE_SIZE, gfx950 x2 read correction): profiles/pmc_r01_v6_conv3x3_64_256_traffic.txt
                 "traffic_sample": {"launch": "conv_split2_kernel<2,2,0>, 64->64 3x3 @256x256, batch 32",
-                                   "hbm_bytes": 2.0511e9, "algorithmic_bytes": 1.0737e9},
+                                   "hbm_bytes": 1.0998e9, "algorithmic_bytes": 1.0737e9},
                 "whole_path_tflops": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value,
                 # both whole-path terms on the canonical (fused-minimum) work
                 "whole_path_mfma_frac_of_split_peak": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value / peak,
