@@ -18,7 +18,8 @@ conv_kernel_fn conv_lookup_c(int MB, int NPW, int lnmode);   // MB 7..12
 conv_kernel_fn conv_lookup_abl(int MB, int NPW, int abl);    // tuning aid (CDC_ABLATE)
 conv_kernel_fn conv_lookup_split(int MB, int NPW);           // conv_split_kernel.h
 conv_kernel_fn conv_lookup_split_abl(int MB, int NPW, int abl);
-conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);   // register-staged variant, 2 WGs/CU
+conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);
+conv_kernel_fn conv_lookup_split2_t4(int MB);     // ConvTranspose2d(4,2,1): all four phases per workgroup   // register-staged variant, 2 WGs/CU
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;

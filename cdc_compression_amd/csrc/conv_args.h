@@ -90,6 +90,7 @@ struct ConvPlan {
     int ipw;                // images per workgroup (1: tiles inside one image)
     int ksplit = 1;         // K slices (split2 only)
     int xu = 1;             // patch units per thread (split2 only)
+    int t4 = 0;             // transposed convolution with all four phases per workgroup
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 
