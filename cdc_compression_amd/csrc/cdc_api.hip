@@ -1008,6 +1008,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, nullptr, nullptr); // mid_block2
     }
     float *fsm = nullptr, *fsr = nullptr;       // LN statistics of the last Upsample output
+    bool final_ln_done = false;                 // ... unless the Upsample epilogue already normalised it
     for (int i = 0; i < n - 1; ++i) {
         Act skip = skips.back();
         skips.pop_back();
@@ -1023,14 +1024,27 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         if (i == n - 2) {
             // the final LayerNorm (unet.py:104) needs per-pixel statistics of this output: emit them
             // from the epilogue when one workgroup owns all channels
-            fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl);
-            ou.stat_mean = fsm; ou.stat_rstd = fsr;
-            done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, true, PC_UP);
-            if (!done) { ou.stat_mean = ou.stat_rstd = nullptr; }
+            // ... or, better, apply that LayerNorm right there (every phase workgroup owns all channels of
+            // its pixels): the final convolution then reads an already normalised tensor
+            if (!getenv("CDC_NO_FINAL_LN_FUSE")) {
+                Builder::ConvOpts ol;
+                ol.ln_g = h->fin_g; ol.ln_b = h->fin_b;
+                done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ol, true, PC_UP);
+                final_ln_done = done;
+            }
+            if (!done) {
+                fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl);
+                ou.stat_mean = fsm; ou.stat_rstd = fsr;
+                done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, true, PC_UP);
+                if (!done) { ou.stat_mean = ou.stat_rstd = nullptr; }
+            }
         }
         if (!done) {
             bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, false, PC_UP);
-            if (i == n - 2) bd.ln(y.p, nullptr, y.C, y.H * y.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
+            if (i == n - 2) {
+                if (!fsm) { fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl); }
+                bd.ln(y.p, nullptr, y.C, y.H * y.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
+            }
         }
         x = y;
         if (bd.rc) return bd.rc;
@@ -1046,7 +1060,8 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     h->fin_P = bd.dalloc((size_t)B * h->out_dim * KHf * H * W);
     h->out_fx = bd.dalloc((size_t)B * h->out_dim * H * W);
     Builder::ConvOpts of;
-    of.pre_mean = fsm; of.pre_rstd = fsr; of.pre_g = h->fin_g; of.pre_b = h->fin_b; of.no_bias = true;
+    if (!final_ln_done) { of.pre_mean = fsm; of.pre_rstd = fsr; of.pre_g = h->fin_g; of.pre_b = h->fin_b; }
+    of.no_bias = true;
     bd.conv(h->fin_conv, x.p, x.C, x.bs(), nullptr, 0, H, W, h->fin_P, (long long)h->out_dim * KHf * H * W,
             of, false, PC_CONV7);
     Op cb; cb.kind = Op::COMBINE; cb.prof = PC_SMALL;
