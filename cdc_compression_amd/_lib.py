@@ -31,6 +31,10 @@ class CtxdecConfig(ctypes.Structure):
                 ("up_index", ctypes.c_int32)]
 
 
+class HyperdecConfig(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * (CDC_MAX_LEVELS + 1))]
+
+
 class CdcError(RuntimeError):
     pass
 
@@ -75,6 +79,9 @@ def lib():
     L.cdc_unet_forward.argtypes = [H, _vp, _vp, pp, _i, _vp, _i, _i, _i, _i, _vp]
     L.cdc_ctxdec_create.argtypes = [ctypes.POINTER(CtxdecConfig), _i, ctypes.POINTER(H)]
     L.cdc_ctxdec_decode.argtypes = [H, _vp, pp, _i, _i, _i, _i, _i, _vp]
+    L.cdc_hyperdec_create.argtypes = [ctypes.POINTER(HyperdecConfig), _i, ctypes.POINTER(H)]
+    L.cdc_hyperdec_decode.argtypes = [H, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _i, _vp]
+    L.cdc_dequantize.argtypes = [H, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp]
     L.cdc_set_schedule.argtypes = [H, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     L.cdc_ddim_step.argtypes = [H, _vp, _i, pp, _i, _vp, ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                 _i, _vp]
@@ -99,7 +106,8 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_set_schedule", "cdc_ddim_step", "cdc_decode", "cdc_prof_enable",
            "cdc_prof_num_classes", "cdc_prof_name", "cdc_prof_get", "cdc_prof_reset",
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
-           "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode"]
+           "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
+           "cdc_hyperdec_decode", "cdc_dequantize"]
 
 
 def check(handle, rc):

@@ -5,8 +5,12 @@
 only `decode(q_latent)` (compress_modules.py:68-74) -- the synthesis transform that turns the
 transmitted latents into the context pyramid of the denoising U-Net -- is implemented (SURVEY
 section 8f row 1).  `load_state_dict` accepts the reference compressor's full state_dict and takes its
-`dec.*` entries; `encode` / `bpp` / `forward` (analysis transform, hyperprior, rate estimate) raise
-NotImplementedError: the reference module stays in charge of those.
+`dec.*` (and, when present, `hyper_dec.*`) entries; `encode` / `bpp` / `forward` (analysis transform,
+hyper encoder, rate estimate) raise NotImplementedError: the reference module stays in charge of those.
+
+Decode side of the hyperprior: `hyper_decode(q_hyper_latent)` runs
+`hyper_dec` (compress_modules.py:54-59) and returns `(mean, scale.clamp(min=0.1))`; `dequantize(x, offset)`
+is `quantize(x, "dequantize", offset)` (utils.py:72-85).
 """
 import ctypes
 
@@ -27,6 +31,9 @@ class _ContextDecoder:
         self._h = None
         self._sd = {}
         self._finalized = False
+        self._hh = None
+        self._hyper_finalized = False
+        self.reversed_hyper_dims = None
 
     # ---- handle management ----------------------------------------------------------------
     def _handle(self):
@@ -51,6 +58,9 @@ class _ContextDecoder:
             if self._h is not None:
                 _lib.lib().cdc_destroy(self._h)
                 self._h = None
+            if self._hh is not None:
+                _lib.lib().cdc_destroy(self._hh)
+                self._hh = None
         except Exception:
             pass
 
@@ -105,6 +115,8 @@ class _ContextDecoder:
                 self._load_one(n, self._sd[n])
         _lib.check(h, _lib.lib().cdc_finalize_weights(h))
         self._finalized = True
+        if any(k.startswith("hyper_dec.") for k in state_dict):
+            self.load_hyper_state_dict(state_dict)
         return self
 
     def state_dict(self):
@@ -134,9 +146,81 @@ class _ContextDecoder:
         _lib.check(h, L.cdc_ctxdec_decode(h, aq.ptr, arr, n, B, hl, wl, aq.mem, _current_stream(aq.mem)))
         return outs
 
+    # ---- hyperprior, decode side -----------------------------------------------------------
+    def _hyper_handle(self):
+        if self._hh is None:
+            L = _lib.lib()
+            cfg = _lib.HyperdecConfig()
+            cfg.n_layers = len(self.reversed_hyper_dims) - 1
+            for i, d in enumerate(self.reversed_hyper_dims):
+                cfg.dims[i] = d
+            h = ctypes.c_void_p()
+            rc = L.cdc_hyperdec_create(ctypes.byref(cfg), self.device_index, ctypes.byref(h))
+            if rc != 0:
+                raise _lib.CdcError(f"cdc_hyperdec_create failed ({rc}): {L.cdc_last_error(None).decode()}")
+            self._hh = h
+        return self._hh
+
+    def hyper_manifest(self):
+        L, h = _lib.lib(), self._hyper_handle()
+        out = []
+        for i in range(L.cdc_num_tensors(h)):
+            name = ctypes.c_char_p()
+            shape = (ctypes.c_int64 * 4)()
+            nd = ctypes.c_int()
+            _lib.check(h, L.cdc_tensor_info(h, i, ctypes.byref(name), shape, ctypes.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value))))
+        return out
+
+    def load_hyper_state_dict(self, state_dict):
+        """`hyper_dec.*` entries of the reference compressor's state_dict."""
+        L, h = _lib.lib(), self._hyper_handle()
+        names = [n for n, _ in self.hyper_manifest()]
+        missing = [n for n in names if n not in state_dict]
+        unexpected = [k for k in state_dict if k.startswith("hyper_dec.") and k not in names]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}.hyper_dec: missing "
+                               f"{missing[:3]}, unexpected {unexpected[:3]}")
+        for n in names:
+            a = _as_host_f32(state_dict[n])
+            shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            _lib.check(h, L.cdc_load_tensor(h, n.encode(), a.ctypes.data, shape, a.ndim))
+        _lib.check(h, L.cdc_finalize_weights(h))
+        self._hyper_finalized = True
+        return self
+
+    def hyper_decode(self, q_hyper_latent, scale_min=0.1):
+        """compress_modules.py:54-59: (mean, scale) of the latent distribution from q_hyper_latent."""
+        L, h = _lib.lib(), self._hyper_handle()
+        if not self._hyper_finalized:
+            raise _lib.CdcError("load_hyper_state_dict() has not been called")
+        aq = _Arg(q_hyper_latent, self.device_index)
+        B, C, hh, wh = aq.shape
+        if C != self.reversed_hyper_dims[0]:
+            raise _lib.CdcError(f"q_hyper_latent has {C} channels, hyper_dec expects {self.reversed_hyper_dims[0]}")
+        shape = (B, self.reversed_hyper_dims[-1] // 2, hh * 4, wh * 4)
+        mean, pm, _ = _result_like(q_hyper_latent, shape, self.device_index)
+        scale, ps, _ = _result_like(q_hyper_latent, shape, self.device_index)
+        _lib.check(h, L.cdc_hyperdec_decode(h, aq.ptr, pm, ps, B, hh, wh, ctypes.c_float(scale_min), aq.mem,
+                                            _current_stream(aq.mem)))
+        return mean, scale
+
+    def dequantize(self, x, offset):
+        """quantize(x, "dequantize", offset) (utils.py:72-85)."""
+        L, h = _lib.lib(), self._handle()
+        ax, ao = _Arg(x, self.device_index), _Arg(offset, self.device_index)
+        if ax.mem != ao.mem or ax.shape != ao.shape:
+            raise _lib.CdcError("x and offset must have the same shape and live in the same memory")
+        out, po, _ = _result_like(x, ax.shape, self.device_index)
+        n = 1
+        for d in ax.shape:
+            n *= d
+        _lib.check(h, L.cdc_dequantize(h, ax.ptr, ao.ptr, po, n, ax.mem, _current_stream(ax.mem)))
+        return out
+
     def encode(self, *a, **k):
-        raise NotImplementedError("the analysis transform / hyperprior run in the reference module "
-                                  "(SURVEY section 8f rows 2-3)")
+        raise NotImplementedError("the analysis transform / hyper encoder run in the reference module "
+                                  "(SURVEY section 8f row 3)")
 
     bpp = forward = __call__ = encode
 
@@ -151,6 +235,8 @@ class ResnetCompressor(_ContextDecoder):
             raise AssertionError("dims[-1] == reversed_dims[0]")       # compress_modules.py:23
         super().__init__(dim, reverse_dim_mults, out_channels, device)
         self.dim_mults, self.hyper_dims_mults, self.channels = tuple(dim_mults), tuple(hyper_dims_mults), channels
+        # compress_modules.py:26-31
+        self.reversed_hyper_dims = list(reversed([dim * dim_mults[-1] * 2] + [dim * m for m in hyper_dims_mults]))
 
 
 class BigCompressor(_ContextDecoder):
@@ -163,3 +249,4 @@ class BigCompressor(_ContextDecoder):
             raise NotImplementedError("vbr=True (VBRCondition scalers) is not on the decode path")
         super().__init__(dim, tuple(reversed(dim_mults)), out_channels, device)
         self.dim_mults, self.hyper_dims_mults, self.channels = tuple(dim_mults), tuple(hyper_dims_mults), channels
+        self.reversed_hyper_dims = list(reversed([dim * dim_mults[-1] * 2] + [dim * m for m in hyper_dims_mults]))

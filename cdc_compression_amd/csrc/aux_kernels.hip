@@ -680,6 +680,31 @@ __global__ void __launch_bounds__(256) copy_kernel(const float *src, long long s
     }
 }
 
+// y = max(x, lo) in place over n floats per image (scale.clamp(min=0.1), compress_modules.py:59)
+__global__ void __launch_bounds__(256) clamp_min_kernel(float *x, long long bs, long long n, float lo) {
+    float *p = x + (size_t)blockIdx.y * bs;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = fmaxf(p[i], lo);
+}
+
+hipError_t clamp_min_launch(float *x, long long bs, long long n, float lo, int B, hipStream_t st) {
+    const int gx = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(clamp_min_kernel, dim3(gx, B), dim3(256), 0, st, x, bs, n, lo);
+    return hipGetLastError();
+}
+
+// round_w_offset (utils.py:72-75): out = round(x - loc) + loc, torch.round = round-half-to-even = rintf
+__global__ void __launch_bounds__(256) dequantize_kernel(const float *x, const float *loc, float *out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = rintf(x[i] - loc[i]) + loc[i];
+}
+
+hipError_t dequantize_launch(const float *x, const float *loc, float *out, long long n, hipStream_t st) {
+    const int gx = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(dequantize_kernel, dim3(gx), dim3(256), 0, st, x, loc, out, n);
+    return hipGetLastError();
+}
+
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
                                 long long n, int B, hipStream_t st, int parts, long long part_stride) {
     const int gx = (int)std::min<long long>((n + 255) / 256, 2048);

@@ -36,6 +36,7 @@ struct Param {                    // one state_dict entry
 struct ConvW {                    // packed convolution weights (device)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int pad_y = -1, pad_x = -1;   // override `pad` per axis when >= 0 (row-folded convolutions)
+    int tk = 4;                   // transposed: kernel size of the reference layer (4: (4,2,1); 5: (5,2,2,op 1))
     bool transposed = false;      // ConvTranspose2d 4x4 s2 p1 as four 2x2 phase convolutions
     int Cin_pad = 0, COP = 0, nz = 1;
     float *wp = nullptr, *bias = nullptr;
@@ -83,7 +84,9 @@ struct Op {
 
 struct cdc_handle {
     cdc_unet_config cfg;
-    int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode)
+    int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode), 2: hyper decoder
+    std::vector<int> hyper_dims;  // kind 2: reversed_hyper_dims
+    std::vector<ConvW> hconvs;    // kind 2: packed layers
     std::vector<int> rev_dims;    // kind 1: [dim*m for m in rev_mults] + [out_channels]
     int up_index = 1;
     std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
@@ -291,6 +294,26 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int CoutF, int C
                     packed[((size_t)t * cw->Cin_pad + ci) * cw->COP + co] =
                         w[((size_t)(co0 + co) * CinF + ci0 + ci) * taps + t];
         cw->w_zs = 0;
+    } else if (KH == 5) {
+        // ConvTranspose2d(5, stride 2, padding 2, output_padding 1) (hyper decoder, compress_modules.py:166-177):
+        // out[2m+py] takes ky = 2d + py + 2 from x[m-d]: phase 0 rows m-1, m, m+1 (ky 4, 2, 0), phase 1 rows m, m+1
+        // (ky 3, 1).  Every phase becomes a 3x3 / pad-1 convolution; the taps a phase lacks stay zero.
+        cw->KH = 3; cw->KW = 3; cw->nz = 4; cw->stride = 1; cw->tk = 5;
+        cw->w_zs = (long long)9 * cw->Cin_pad * cw->COP;
+        packed.assign((size_t)4 * cw->w_zs, 0.f);
+        for (int z = 0; z < 4; ++z) {
+            const int py = z >> 1, px = z & 1;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    const int ky = py == 0 ? 4 - 2 * a : 5 - 2 * a, kx = px == 0 ? 4 - 2 * b : 5 - 2 * b;
+                    if (ky > 4 || kx > 4) continue;          // (py = 1, a = 0): no such tap
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int co = 0; co < Cout; ++co)
+                            packed[(size_t)z * cw->w_zs +
+                                   ((size_t)(a * 3 + b) * cw->Cin_pad + ci) * cw->COP + co] =
+                                w[(((size_t)(ci0 + ci) * CoutF + co0 + co) * 5 + ky) * 5 + kx];
+                }
+        }
     } else {
         // out[2m+py][2n+px] = sum_{a,b in {0,1}} x[m+a-(1-py)][n+b-(1-px)] * w[ci][co][3-py-2a][3-px-2b]
         cw->KH = 2; cw->KW = 2; cw->nz = 4; cw->stride = 1;
@@ -570,6 +593,7 @@ struct Builder {
     struct ConvOpts {
         const float *ln_g = nullptr, *ln_b = nullptr;  // fused LN after bias
         int relu = 0;
+        float relu_slope = 0.f;                        // LeakyReLU slope (0 = ReLU)
         const float *shift = nullptr;                  // + shift[b][co]
         const float *resid = nullptr; long long resid_bs = 0, resid_cs = 0;
         const float *pre_add = nullptr;                // hoisted partial sums (same layout as out)
@@ -605,7 +629,7 @@ struct Builder {
         s.C0 = s1 ? C0 : 0;
         s.Win = W; s.nz = w.nz;
         s.allow_split = w.wsp != nullptr;
-        for (int z = 0; z < 4; ++z) s.pad_x[z] = w.transposed ? 1 - (z & 1) : pad_x;
+        for (int z = 0; z < 4; ++z) s.pad_x[z] = w.transposed ? (w.tk == 5 ? 1 : 1 - (z & 1)) : pad_x;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
             s.Ho = (H + 2 * pad_y - w.KH) / w.stride + 1;
@@ -669,7 +693,7 @@ struct Builder {
         if (w.transposed) {
             for (int z = 0; z < 4; ++z) {
                 const int py = z >> 1, px = z & 1;
-                a.pad_y[z] = 1 - py; a.pad_x[z] = 1 - px;
+                a.pad_y[z] = w.tk == 5 ? 1 : 1 - py; a.pad_x[z] = w.tk == 5 ? 1 : 1 - px;
                 a.out_zoff[z] = py * 2 * W + px;
             }
             a.out_cs = (long long)4 * H * W; a.out_ys = 4 * W; a.out_xs = 2;
@@ -680,7 +704,7 @@ struct Builder {
         a.Ho = s.Ho; a.Wo = s.Wo;
         a.bias = o.no_bias ? nullptr : w.bias;
         a.pre_add = o.pre_add;
-        a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu;
+        a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu; a.relu_slope = o.relu_slope;
         a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
@@ -1073,6 +1097,31 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     return CDC_OK;
 }
 
+// Launch program of Compressor.hyper_dec (compress_modules.py:54-60) for q_hyper_latent [B][dims[0]][hh][wh].
+int build_hyperdec_program(cdc_handle *h, int B, int hh, int wh) {
+    if (h->pB == B && h->pH == hh && h->pW == wh) return CDC_OK;
+    free_program(h);
+    Builder bd{h, B, &h->act_allocs};
+    h->in_x = bd.dalloc((size_t)B * h->hyper_dims[0] * hh * wh);
+    if (bd.rc) return bd.rc;
+    Act x; x.p = h->in_x; x.C = h->hyper_dims[0]; x.H = hh; x.W = wh;
+    const int n = (int)h->hconvs.size();
+    for (int i = 0; i < n; ++i) {
+        const ConvW &cw = h->hconvs[i];
+        const bool last = i == n - 1;
+        Act y = bd.new_act(cw.Cout, last ? x.H : x.H * 2, last ? x.W : x.W * 2);
+        Builder::ConvOpts o;
+        if (!last) { o.relu = 1; o.relu_slope = 0.2f; }           // nn.LeakyReLU(0.2)
+        bd.conv(cw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), o, false, last ? PC_CONV3 : PC_UP);
+        x = y;
+        if (bd.rc) return bd.rc;
+    }
+    h->dec_outs.clear();
+    h->dec_outs.push_back(x);
+    h->pB = B; h->pH = hh; h->pW = wh;
+    return CDC_OK;
+}
+
 // Launch program of Compressor.decode (compress_modules.py:68-74) for q_latent [B][rev[0]][hl][wl].
 int build_ctxdec_program(cdc_handle *h, int B, int hl, int wl) {
     if (h->pB == B && h->pH == hl && h->pW == wl) return CDC_OK;
@@ -1353,6 +1402,20 @@ int cdc_finalize_weights(cdc_handle *h) {
     free_program(h);
     free_pool(&h->weight_allocs);
     h->rbs.clear(); h->attns.clear(); h->downs.clear(); h->ups.clear();
+    if (h->kind == 2) {
+        const int n = (int)h->hyper_dims.size() - 1;
+        h->hconvs.clear();
+        for (int i = 0; i < n; ++i) {
+            const std::string p = "hyper_dec." + std::to_string(i) + ".0";
+            ConvW cw;
+            const bool last = i == n - 1;
+            if ((rc = pack_named_conv(h, p + ".weight", p + ".bias", last ? 1 : 2, last ? 1 : 2, !last, &cw))) return rc;
+            h->hconvs.push_back(cw);
+        }
+        h->shift_bs = 0;
+        h->finalized = true;
+        return CDC_OK;
+    }
     if (h->kind == 1) {
         // Compressor.dec: ResnetBlock(rev[i] -> rev[i+1] | rev[i] on the last level) + Upsample(-> rev[i+1])
         const int n = (int)h->rev_dims.size() - 1;
@@ -1436,6 +1499,77 @@ int cdc_finalize_weights(cdc_handle *h) {
     HIP_TRY(h, hipMemcpy(dl, tl.data(), tl.size() * sizeof(TembLayer), hipMemcpyHostToDevice));
     h->d_temb_layers = (TembLayer *)dl;
     h->finalized = true;
+    return CDC_OK;
+}
+
+int cdc_hyperdec_create(const cdc_hyperdec_config *cfg, int device, cdc_handle **out) {
+    if (!cfg || !out) return fail(nullptr, CDC_ERR_INVALID, "null argument");
+    if (cfg->n_layers < 1 || cfg->n_layers > CDC_MAX_LEVELS) return fail(nullptr, CDC_ERR_INVALID, "bad cdc_hyperdec_config");
+    if (device < 0) return fail(nullptr, CDC_ERR_INVALID, "device %d out of range", device);
+    std::unique_ptr<cdc_handle> h(new cdc_handle);
+    memset(&h->cfg, 0, sizeof h->cfg);
+    h->kind = 2;
+    h->device = device;
+    for (int i = 0; i <= cfg->n_layers; ++i) {
+        if (cfg->dims[i] < 1) return fail(nullptr, CDC_ERR_INVALID, "bad cdc_hyperdec_config");
+        h->hyper_dims.push_back(cfg->dims[i]);
+    }
+    if (h->hyper_dims.back() % 2) return fail(nullptr, CDC_ERR_INVALID, "the last layer must produce mean and scale");
+    for (int i = 0; i < cfg->n_layers; ++i) {
+        const std::string p = "hyper_dec." + std::to_string(i) + ".0";
+        const int din = h->hyper_dims[i], dout = h->hyper_dims[i + 1];
+        if (i == cfg->n_layers - 1) add_param(h.get(), p + ".weight", {dout, din, 3, 3});      // Conv2d
+        else add_param(h.get(), p + ".weight", {din, dout, 5, 5});                          // ConvTranspose2d
+        add_param(h.get(), p + ".bias", {dout});
+    }
+    *out = h.release();
+    return CDC_OK;
+}
+
+int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean, float *scale, int B, int hh,
+                        int wh, float scale_min, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->kind != 2) return fail(h, CDC_ERR_STATE, "handle is not a hyper decoder");
+    if (!q_hyper_latent || !mean || !scale || B < 1 || hh < 1 || wh < 1)
+        return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    if ((rc = build_hyperdec_program(h, B, hh, wh))) return rc;
+    hipStream_t st = pick_stream(h, stream, mem);
+    if ((rc = copy_in(h, h->in_x, q_hyper_latent, (size_t)B * h->hyper_dims[0] * hh * wh, mem, st))) return rc;
+    h->prof_now = true;
+    for (const Op &op : h->ops)
+        if ((rc = run_op(h, op, h->pB, st))) return rc;
+    const Act &o = h->dec_outs[0];                  // [B][2C][4hh][4wh]: mean = channels [0, C), scale = [C, 2C)
+    const int C = o.C / 2;
+    const long long half = (long long)C * o.H * o.W;
+    HIP_TRY(h, clamp_min_launch(o.p + half, o.bs(), half, scale_min, B, st));
+    for (int b = 0; b < B; ++b) {
+        if ((rc = copy_out(h, mean + (size_t)b * half, o.p + (size_t)b * o.bs(), (size_t)half, mem, st))) return rc;
+        if ((rc = copy_out(h, scale + (size_t)b * half, o.p + (size_t)b * o.bs() + half, (size_t)half, mem, st))) return rc;
+    }
+    return CDC_OK;
+}
+
+int cdc_dequantize(cdc_handle *h, const float *x, const float *offset, float *out, long long n, int mem, void *stream) {
+    if (!h) return CDC_ERR_INVALID;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if (!x || !offset || !out || n < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    hipStream_t st = pick_stream(h, stream, mem);
+    if (mem == CDC_MEM_DEVICE) {
+        HIP_TRY(h, dequantize_launch(x, offset, out, n, st));
+        return CDC_OK;
+    }
+    float *dx = nullptr, *dl = nullptr;
+    HIP_TRY(h, hipMalloc(&dx, sizeof(float) * n));
+    if (hipMalloc(&dl, sizeof(float) * n) != hipSuccess) { (void)hipFree(dx); return fail(h, CDC_ERR_NOMEM, "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(dx, x, sizeof(float) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dl, offset, sizeof(float) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = dequantize_launch(dx, dl, dx, n, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dx, sizeof(float) * n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dx); (void)hipFree(dl);
+    if (e != hipSuccess) return fail(h, CDC_ERR_HIP, "dequantize: %s", hipGetErrorString(e));
     return CDC_OK;
 }
 

@@ -54,6 +54,7 @@ struct ConvArgs {
     const float *ep_g, *ep_b;       // channel LayerNorm after bias (needs gridDim.y == 1)
     float eps;
     int relu;
+    float relu_slope;               // 0: ReLU; 0.2: LeakyReLU(0.2) of the hyper decoder (max(v, slope*v))
     const float *shift;             // [B][shift_bs] added after ReLU (time-embedding add)
     int shift_bs;
     const float *resid;             // same addressing as out, added last (ResnetBlock / Residual)

@@ -168,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], 0.f);
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], P.relu_slope * acc[m][n][r]);
         }
         if (P.shift) {
 #pragma unroll

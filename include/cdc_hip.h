@@ -138,6 +138,28 @@ int cdc_ctxdec_create(const cdc_ctxdec_config *cfg, int device, cdc_handle **out
 int cdc_ctxdec_decode(cdc_handle *h, const float *q_latent, float *const *outs, int n_outs, int B,
                       int h_latent, int w_latent, int mem_kind, void *stream);
 
+/* ---- hyperprior decoder (decode side) ------------------------------------ */
+
+/* Compressor.hyper_dec (xparam/modules/compress_modules.py:54-60,166-177; epsilonparam/...:58-66,171-185):
+ * n_layers-1 x [ConvTranspose2d(dims[i] -> dims[i+1], 5, stride 2, padding 2, output_padding 1), LeakyReLU(0.2)]
+ * then Conv2d(dims[n-1] -> dims[n], 3, padding 1).  dims = reversed_hyper_dims, e.g. {256,256,256,512}.
+ * Parameters: the reference's "hyper_dec.<i>.0.weight" / ".bias" through cdc_load_tensor. */
+typedef struct {
+    int32_t n_layers;
+    int32_t dims[CDC_MAX_LEVELS + 1];
+} cdc_hyperdec_config;
+
+int cdc_hyperdec_create(const cdc_hyperdec_config *cfg, int device, cdc_handle **out);
+
+/* q_hyper_latent [B][dims[0]][h][w] -> mean, scale [B][dims[n]/2][4h][4w] each:
+ * `mean, scale = hyper_dec(q_hyper_latent).chunk(2, 1)`, `scale.clamp(min=scale_min)` (compress_modules.py:58-59). */
+int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean, float *scale, int B,
+                        int h_hyper, int w_hyper, float scale_min, int mem_kind, void *stream);
+
+/* quantize(x, "dequantize", offset) = round(x - offset) + offset, round = half-to-even (utils.py:72-85). */
+int cdc_dequantize(cdc_handle *h, const float *x, const float *offset, float *out, long long n, int mem_kind,
+                   void *stream);
+
 /* Kernel-class timing: hipEvent pairs recorded (without host synchronisation) on the launch stream
  * around every kernel of a forward / DDIM iteration and resolved at cdc_prof_get.
  * on = 0: off (default); on = 1: every launch; on = n > 1: inside cdc_decode only the DDIM

@@ -369,3 +369,47 @@ def compressor_decode(ops, cfg, sd, q_latent):
         x = upsample(ops, sd, f"dec.{ind}.{cfg.up_index}", x)
         outs.append(x)
     return outs[::-1]
+
+
+# --------------------------------------------------------------------------------------------
+# hyperprior decoder (decode side)
+# --------------------------------------------------------------------------------------------
+
+
+def hyper_dec_manifest(dims):
+    """`hyper_dec.*` entries of the reference Compressor.state_dict(): n-1 ConvTranspose2d(5, 2, 2, 1)
+    ([Cin][Cout][5][5]) then Conv2d(3, 1, 1) (compress_modules.py:166-177); dims = reversed_hyper_dims."""
+    out = []
+    n = len(dims) - 1
+    for i in range(n):
+        p = f"hyper_dec.{i}.0"
+        if i == n - 1:
+            out += [(p + ".weight", (dims[i + 1], dims[i], 3, 3)), (p + ".bias", (dims[i + 1],))]
+        else:
+            out += [(p + ".weight", (dims[i], dims[i + 1], 5, 5)), (p + ".bias", (dims[i + 1],))]
+    return out
+
+
+def hyper_decode(ops, dims, sd, q_hyper_latent, scale_min=0.1):
+    """compress_modules.py:54-59: `for deconv, act in hyper_dec: x = act(deconv(x))`, LeakyReLU(0.2)
+    after every layer but the last; `mean, scale = x.chunk(2, 1)`; `scale.clamp(min=0.1)`."""
+    x = np.asarray(q_hyper_latent, np.float32)
+    n = len(dims) - 1
+    for i in range(n):
+        p = f"hyper_dec.{i}.0"
+        if i == n - 1:
+            x = ops.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=1, padding=1)
+        else:
+            x = ops.conv_transpose2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=2, padding=2,
+                                     output_padding=1)
+            x = np.where(x >= 0, x, np.float32(0.2) * x).astype(np.float32)
+    c = x.shape[1] // 2
+    return x[:, :c].copy(), np.maximum(x[:, c:], np.float32(scale_min)).astype(np.float32)
+
+
+def dequantize(x, offset):
+    """quantize(x, "dequantize", offset) = round(x - offset) + offset (utils.py:72-85); torch.round is
+    round-half-to-even, as is np.rint."""
+    x = np.asarray(x, np.float32)
+    offset = np.asarray(offset, np.float32)
+    return (np.rint(x - offset) + offset).astype(np.float32)

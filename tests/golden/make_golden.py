@@ -293,6 +293,59 @@ def gen_ctxdec(name):
     print(name, "ok", [o.shape for o in outs])
 
 
+HYPERDEC = {
+    # name: (tree, class, ctor kwargs, hyper-latent h, w, B)
+    "hyperdec_small_x": ("xparam", "ResnetCompressor",
+                         dict(dim=8, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                              hyper_dims_mults=[4, 4, 4], channels=3, out_channels=8), 2, 3, 2),
+    "hyperdec_full_x": ("xparam", "ResnetCompressor",
+                        dict(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                             hyper_dims_mults=[4, 4, 4], channels=3, out_channels=64), 4, 4, 1),
+    "hyperdec_full_eps": ("epsilonparam", "BigCompressor",
+                          dict(dim=64, dim_mults=(1, 2, 3, 4), hyper_dims_mults=(4, 4, 4), channels=3,
+                               out_channels=3, vbr=False), 3, 5, 1),
+}
+
+
+def gen_hyperdec(name):
+    """hyper_dec of the real reference (compress_modules.py:54-59) on a synthetic q_hyper_latent, plus the
+    reference's own dequantize (utils.py quantize(..., "dequantize", mean)) of a synthetic latent."""
+    tree, cls, kw, hh, wh, B = HYPERDEC[name]
+    ref = import_reference(tree)
+    net = getattr(ref.cm, cls)(**kw)
+    man = [(k, list(v.shape)) for k, v in net.state_dict().items() if k.startswith("hyper_dec.")]
+    sd = synth.unet_state_dict(man, seed=7)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net.eval()
+    c0 = man[0][1][0]                                   # hyper_dec.0.0.weight: ConvTranspose2d [Cin][Cout][5][5]
+    q = np.round(synth.normal("q_hyper", (B, c0, hh, wh), seed=8, std=2.0)).astype(np.float32) + np.float32(0.25)
+    import modules.utils as ut
+    with torch.no_grad():
+        x = torch.from_numpy(q)
+        for layer in net.hyper_dec:
+            for m in layer:
+                x = m(x)
+        mean, scale = x.chunk(2, 1)
+        scale = scale.clamp(min=0.1)
+        latent = torch.from_numpy(synth.normal("latent", tuple(mean.shape), seed=9, std=3.0))
+        ql = ut.quantize(latent, "dequantize", mean)
+    json.dump({"kwargs": {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items()},
+               "class": cls, "tree": tree, "dims": list(net.reversed_hyper_dims), "manifest": man},
+              open(os.path.join(HERE, f"manifest_{name}.json"), "w"))
+    rec = {"q_hyper_latent": q}
+    for key, t in (("mean", mean), ("scale", scale), ("q_latent", ql)):
+        a = t.numpy()
+        if a.size <= 70000:
+            rec[key] = a
+        d = digest(a)
+        rec.update({f"{key}_shape": np.array(a.shape), f"{key}_idx": d["idx"], f"{key}_val": d["val"],
+                    f"{key}_sum": d["sum"]})
+    if "q_latent" not in rec:
+        rec["latent_seed"] = np.array(9)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "ok", tuple(mean.shape), float(scale.min()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_schedules()
@@ -304,3 +357,5 @@ if __name__ == "__main__":
     gen_full_res()
     for n in CTXDEC:
         gen_ctxdec(n)
+    for n in HYPERDEC:
+        gen_hyperdec(n)

@@ -308,3 +308,51 @@ def test_batch32_launch_plans_match_batch1():
     for k in (0, 1, 17, 31):
         assert relerr(y32[k], y1[0]) < 1e-5, (k, relerr(y32[k], y1[0]))
     np.testing.assert_array_equal(y32[5], y32[26])
+
+
+# ---- hyperprior decoder (decode side) ---------------------------------------
+
+@pytest.mark.parametrize("name", ["hyperdec_small_x", "hyperdec_full_x", "hyperdec_full_eps"])
+def test_hyper_decoder_matches_reference_golden(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    sd = synth.unet_state_dict(man, seed=7)
+    m = getattr(cdc, meta["class"])(**meta["kwargs"])
+    m.load_hyper_state_dict(sd)
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    mean, scale = m.hyper_decode(g["q_hyper_latent"])
+    for key, a in (("mean", mean), ("scale", scale)):
+        assert list(a.shape) == list(g[f"{key}_shape"])
+        flat = a.reshape(-1)
+        assert relerr(flat[g[f"{key}_idx"]], g[f"{key}_val"]) < TOL
+        assert abs(float(flat.astype(np.float64).sum()) - float(g[f"{key}_sum"])) < 1e-4 * flat.size
+        if key in g.files:
+            assert relerr(a, g[key]) < TOL
+    assert float(scale.min()) >= 0.1
+    if "mean" in g.files and "q_latent" in g.files:
+        # dequantize is discrete: feed the reference's own mean -> the reference's q_latent, bit for bit
+        latent = synth.normal("latent", tuple(g["mean"].shape), seed=9, std=3.0)
+        np.testing.assert_array_equal(m.dequantize(latent, g["mean"]), g["q_latent"])
+
+
+def test_latents_to_image_chain(O):
+    """q_hyper_latent -> (mean, scale); symbols + mean -> q_latent; q_latent -> context pyramid -> 2-step
+    decode: the whole decoder side on the GPU, checked stage by stage against the CPU restatement."""
+    meta = json.load(open(os.path.join(GOLDEN, "manifest_hyperdec_full_x.json")))
+    hman = [(k, tuple(v)) for k, v in meta["manifest"]]
+    dmeta = json.load(open(os.path.join(GOLDEN, "manifest_ctxdec_full_x.json")))
+    dman = [(k, tuple(v)) for k, v in dmeta["manifest"]]
+    sd = {**synth.unet_state_dict(hman, seed=7), **synth.unet_state_dict(dman, seed=5)}
+    m = cdc.ResnetCompressor(**meta["kwargs"])
+    m.load_state_dict(sd)                                  # takes dec.* and hyper_dec.*
+    qh = np.round(synth.normal("qh", (1, 256, 1, 2), seed=12, std=2.0)).astype(np.float32)
+    mean, scale = m.hyper_decode(qh)
+    rmean, rscale = om.hyper_decode(O, meta["dims"], sd, qh)
+    assert relerr(mean, rmean) < TOL and relerr(scale, rscale) < TOL
+    sym = np.round(synth.normal("sym", mean.shape, seed=13, std=2.0)).astype(np.float32)
+    q_latent = m.dequantize(sym + rmean, rmean)            # integers + offset survive the round trip
+    np.testing.assert_array_equal(q_latent, om.dequantize(sym + rmean, rmean))
+    ctx = m.decode(q_latent)
+    cfg = om.CompressorConfig(64, (4, 3, 2, 1), 64, 1)
+    for a, r in zip(ctx, om.compressor_decode(O, cfg, sd, q_latent)):
+        assert relerr(a, r) < TOL

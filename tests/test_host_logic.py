@@ -138,3 +138,11 @@ def test_ctxdec_load_state_dict_takes_dec_entries_only():
         full["enc.0.0.block1.block.0.weight"] = np.zeros((8, 3, 7, 7), np.float32)   # encoder keys are ignored
         with pytest.raises(_lib.CdcError):      # finalize needs the GPU: loud failure, no CPU fallback
             m.load_state_dict(full)
+
+
+@pytest.mark.parametrize("name", ["hyperdec_small_x", "hyperdec_full_x", "hyperdec_full_eps"])
+def test_hyperdec_manifest_matches_reference_state_dict(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    m = getattr(cdc, meta["class"])(**meta["kwargs"])
+    assert m.reversed_hyper_dims == meta["dims"]
+    assert [(n, list(s)) for n, s in m.hyper_manifest()] == [(n, list(s)) for n, s in meta["manifest"]]

@@ -172,3 +172,37 @@ def test_ctxdec_oracle_matches_reference_golden(name):
         if f"out{i}" in g.files:
             ref = g[f"out{i}"]
             assert np.abs(o - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+# ---- hyperprior decoder (decode side) ---------------------------------------
+
+HYPERDEC_CASES = ["hyperdec_small_x", "hyperdec_full_x", "hyperdec_full_eps"]
+
+
+def _digest_close(a, g, key, tol=1e-4):
+    flat = np.asarray(a).reshape(-1)
+    assert list(np.asarray(a).shape) == list(g[f"{key}_shape"])
+    scale = max(1.0, float(np.abs(g[f"{key}_val"]).max()))
+    assert np.abs(flat[g[f"{key}_idx"]] - g[f"{key}_val"]).max() <= tol * scale
+    assert abs(float(flat.astype(np.float64).sum()) - float(g[f"{key}_sum"])) <= tol * flat.size
+    if key in g.files:
+        assert np.abs(a - g[key]).max() <= tol * max(1.0, float(np.abs(g[key]).max()))
+
+
+@pytest.mark.parametrize("name", HYPERDEC_CASES)
+def test_hyperdec_oracle_matches_reference_golden(name):
+    """hyper_dec of the real reference (ConvTranspose2d(5,2,2,1) x2 + Conv2d 3x3, LeakyReLU(0.2)), the
+    chunk / clamp, and the reference's own dequantize, vs the CPU restatement."""
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    assert om.hyper_dec_manifest(meta["dims"]) == man
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    sd = synth.unet_state_dict(man, seed=7)
+    mean, scale = om.hyper_decode(oops.OrcOps("f32"), meta["dims"], sd, g["q_hyper_latent"])
+    _digest_close(mean, g, "mean")
+    _digest_close(scale, g, "scale")
+    assert float(scale.min()) >= 0.1
+    # dequantize on the reference's own mean: exactly the reference's q_latent
+    if "mean" in g.files and "q_latent" in g.files:
+        latent = synth.normal("latent", tuple(g["mean"].shape), seed=9, std=3.0)
+        np.testing.assert_array_equal(om.dequantize(latent, g["mean"]), g["q_latent"])
