@@ -356,3 +356,19 @@ def test_latents_to_image_chain(O):
     cfg = om.CompressorConfig(64, (4, 3, 2, 1), 64, 1)
     for a, r in zip(ctx, om.compressor_decode(O, cfg, sd, q_latent)):
         assert relerr(a, r) < TOL
+
+
+def test_non_square_frame_against_double_accumulating_oracle():
+    """A non-square frame (192 x 320, batch 3) of the full-width model against the restatement built with
+    double accumulators: the HIP path sits an order of magnitude closer to it than fp32 CPU summation does
+    (measured at 512 x 768: HIP 2.9e-6, fp32 restatement 1.6e-4), so this pins the kernels, not round-off."""
+    kw, man, sd, _, _, _, _ = load_case("full_x")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    B, H, W = 3, 192, 320
+    x = synth.normal("x", (B, 3, H, W), seed=1, std=0.8)
+    ctx = synth.context_pyramid([64, 64, 128, 192], B, H, W, seed=3)
+    t = np.full((B, 1), 0.41, np.float32)
+    y = un(x, t, ctx)
+    ref64 = om.unet_forward(oops.OrcOps("f64"), oracle_cfg(kw), sd, x, t, ctx)
+    assert relerr(y, ref64) < 2e-5, relerr(y, ref64)
