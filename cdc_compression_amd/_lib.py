@@ -82,6 +82,7 @@ def lib():
     L.cdc_hyperdec_create.argtypes = [ctypes.POINTER(HyperdecConfig), _i, ctypes.POINTER(H)]
     L.cdc_hyperdec_decode.argtypes = [H, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _i, _vp]
     L.cdc_dequantize.argtypes = [H, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp]
+    L.cdc_bpp.argtypes = [H, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     L.cdc_set_schedule.argtypes = [H, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     L.cdc_ddim_step.argtypes = [H, _vp, _i, pp, _i, _vp, ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                 _i, _vp]
@@ -107,7 +108,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_prof_num_classes", "cdc_prof_name", "cdc_prof_get", "cdc_prof_reset",
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
-           "cdc_hyperdec_decode", "cdc_dequantize"]
+           "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp"]
 
 
 def check(handle, rc):

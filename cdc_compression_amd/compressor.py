@@ -14,6 +14,8 @@ is `quantize(x, "dequantize", offset)` (utils.py:72-85).
 """
 import ctypes
 
+import numpy as np
+
 from . import _lib
 from .unet import _Arg, _as_host_f32, _current_stream, _result_like
 
@@ -33,6 +35,8 @@ class _ContextDecoder:
         self._finalized = False
         self._hh = None
         self._hyper_finalized = False
+        self._prior_loaded = False
+        self._medians = None
         self.reversed_hyper_dims = None
 
     # ---- handle management ----------------------------------------------------------------
@@ -116,7 +120,7 @@ class _ContextDecoder:
         _lib.check(h, _lib.lib().cdc_finalize_weights(h))
         self._finalized = True
         if any(k.startswith("hyper_dec.") for k in state_dict):
-            self.load_hyper_state_dict(state_dict)
+            self.load_hyper_state_dict(state_dict)      # also takes prior.* when present
         return self
 
     def state_dict(self):
@@ -185,6 +189,22 @@ class _ContextDecoder:
             a = _as_host_f32(state_dict[n])
             shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
             _lib.check(h, L.cdc_load_tensor(h, n.encode(), a.ctypes.data, shape, a.ndim))
+        # FlexiblePrior (rate estimate only): reference shapes [C,1,1,in,out] / [C,1,1,1,out], singleton axes squeezed
+        self._prior_loaded = False
+        pk = [k for k in state_dict if k.startswith("prior.affine.") or k.startswith("prior.a.")]
+        if pk:
+            C = self.reversed_hyper_dims[0]
+            for k in pk:
+                a = _as_host_f32(state_dict[k])
+                a = np.ascontiguousarray(a.reshape((C,) + tuple(d for d in a.shape[3:] if True))
+                                         if a.ndim == 5 else a)
+                if a.ndim == 3 and not k.endswith(".weight"):
+                    a = np.ascontiguousarray(a.reshape(C, -1))
+                shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+                _lib.check(h, L.cdc_load_tensor(h, k.encode(), a.ctypes.data, shape, a.ndim))
+            self._prior_loaded = True
+        if "prior._medians" in state_dict:
+            self._medians = _as_host_f32(state_dict["prior._medians"]).reshape(1, -1, 1, 1)
         _lib.check(h, L.cdc_finalize_weights(h))
         self._hyper_finalized = True
         return self
@@ -218,11 +238,44 @@ class _ContextDecoder:
         _lib.check(h, L.cdc_dequantize(h, ax.ptr, ao.ptr, po, n, ax.mem, _current_stream(ax.mem)))
         return out
 
+    def rate(self, q_hyper_latent, q_latent, mean, scale, image_hw):
+        """bits per pixel of already quantised latents: the two likelihood sums of Compressor.bpp
+        (compress_modules.py:84-88) on the GPU."""
+        L, h = _lib.lib(), self._hyper_handle()
+        if not (self._hyper_finalized and self._prior_loaded):
+            raise _lib.CdcError("the prior.* tensors have not been loaded (load_state_dict with the full state_dict)")
+        args = [_Arg(t, self.device_index) for t in (q_hyper_latent, q_latent, mean, scale)]
+        if len({a.mem for a in args}) != 1:
+            raise _lib.CdcError("all inputs must live in the same memory")
+        B, _, hh, wh = args[0].shape
+        if args[1].shape != (B, self.reversed_hyper_dims[-1] // 2, 4 * hh, 4 * wh) or \
+                args[2].shape != args[1].shape or args[3].shape != args[1].shape:
+            raise _lib.CdcError(f"latent shapes {args[1].shape} do not belong to a {args[0].shape} hyper latent")
+        out, po, _ = _result_like(q_hyper_latent, (B,), self.device_index)
+        _lib.check(h, L.cdc_bpp(h, args[0].ptr, args[1].ptr, args[2].ptr, args[3].ptr, po, B, hh, wh,
+                                int(image_hw[0]), int(image_hw[1]), args[0].mem, _current_stream(args[0].mem)))
+        return out
+
+    def bpp(self, shape, state4bpp):
+        """Compressor.bpp (compress_modules.py:76-90) in eval mode: quantise with the medians / the predicted
+        mean, then the rate of both latents."""
+        B, _, H, W = shape
+        dist = state4bpp["latent_distribution"]
+        mean, scale = (dist.mean, dist.scale) if hasattr(dist, "mean") else dist
+        hyper = state4bpp["hyper_latent"]
+        med = np.broadcast_to(self._medians, tuple(_Arg(hyper, self.device_index).shape)).copy()
+        if type(hyper).__module__.startswith("torch"):
+            import torch
+            med = torch.from_numpy(med).to(hyper.device)
+        q_hyper = self.dequantize(hyper, med)
+        q_latent = self.dequantize(state4bpp["latent"], mean)
+        return self.rate(q_hyper, q_latent, mean, scale, (H, W))
+
     def encode(self, *a, **k):
         raise NotImplementedError("the analysis transform / hyper encoder run in the reference module "
                                   "(SURVEY section 8f row 3)")
 
-    bpp = forward = __call__ = encode
+    forward = __call__ = encode
 
 
 class ResnetCompressor(_ContextDecoder):

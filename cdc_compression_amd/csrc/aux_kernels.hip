@@ -680,6 +680,65 @@ __global__ void __launch_bounds__(256) copy_kernel(const float *src, long long s
     }
 }
 
+// Rate estimate Compressor.bpp (compress_modules.py:76-90), eval mode:
+//   hyper_rate = -log2 FlexiblePrior.likelihood(q_hyper_latent)   (network_components.py:342-378)
+//   cond_rate  = -log2 NormalDistribution(mean, scale).likelihood(q_latent)   (utils.py:147-159)
+//   bpp[b] = (sum hyper_rate + sum cond_rate) / (H * W)
+// One workgroup per image; per-thread partial sums in double, fixed-order tree reduction (deterministic).
+__device__ __forceinline__ float prior_logit(const float *p, float x) {
+    float h[3], g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { h[k] = x * p[k] + p[3 + k]; h[k] += p[6 + k] * tanhf(h[k]); }
+    p += 9;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[j] = h[0] * p[j] + h[1] * p[3 + j] + h[2] * p[6 + j] + p[9 + j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) h[j] = g[j] + p[12 + j] * tanhf(g[j]);
+        p += 15;
+    }
+    return h[0] * p[0] + h[1] * p[1] + h[2] * p[2] + p[3];
+}
+
+__global__ void __launch_bounds__(256) bpp_kernel(const float *qh, long long nh, int hw_h, const float *prior,
+                                                  const float *ql, const float *mean, const float *scale,
+                                                  long long nl, float inv_hw, float *bpp) {
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    double acc = 0.0;
+    const float *xh = qh + (size_t)b * nh;
+    for (long long i = threadIdx.x; i < nh; i += blockDim.x) {
+        const float *p = prior + (size_t)(i / hw_h) * 44;
+        const float x = xh[i];
+        const float lower = prior_logit(p, x - 0.5f), upper = prior_logit(p, x + 0.5f);
+        const float t = lower + upper;
+        const float sgn = t > 0.f ? -1.f : (t < 0.f ? 1.f : 0.f);            // -torch.sign(lower + upper)
+        const float su = 1.f / (1.f + expf(-upper * sgn)), sl = 1.f / (1.f + expf(-lower * sgn));
+        acc -= (double)log2f(fmaxf(fabsf(su - sl), 1e-9f));
+    }
+    const float *xl = ql + (size_t)b * nl, *mu = mean + (size_t)b * nl, *sc = scale + (size_t)b * nl;
+    for (long long i = threadIdx.x; i < nl; i += blockDim.x) {
+        const float d = fabsf(xl[i] - mu[i]), s = sc[i];
+        const float c = -0.70710678118654752440f;                            // -(2 ** -0.5)
+        const float upper = 0.5f * erfcf(c * ((0.5f - d) / s)), lower = 0.5f * erfcf(c * ((-0.5f - d) / s));
+        acc -= (double)log2f(fmaxf(upper - lower, 1e-9f));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bpp[b] = (float)(red[0] * (double)inv_hw);
+}
+
+hipError_t bpp_launch(const float *qh, long long nh, int hw_h, const float *prior, const float *ql, const float *mean,
+                      const float *scale, long long nl, float inv_hw, float *bpp, int B, hipStream_t st) {
+    hipLaunchKernelGGL(bpp_kernel, dim3(B), dim3(256), 0, st, qh, nh, hw_h, prior, ql, mean, scale, nl, inv_hw, bpp);
+    return hipGetLastError();
+}
+
 // y = max(x, lo) in place over n floats per image (scale.clamp(min=0.1), compress_modules.py:59)
 __global__ void __launch_bounds__(256) clamp_min_kernel(float *x, long long bs, long long n, float lo) {
     float *p = x + (size_t)blockIdx.y * bs;

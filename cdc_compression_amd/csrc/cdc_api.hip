@@ -30,6 +30,7 @@ struct Param {                    // one state_dict entry
     std::vector<int64_t> shape;
     std::vector<float> host;
     bool loaded = false;
+    bool optional = false;        // not part of the enumerated manifest; may stay unloaded (prior of the rate estimate)
     size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
 };
 
@@ -87,6 +88,7 @@ struct cdc_handle {
     int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode), 2: hyper decoder
     std::vector<int> hyper_dims;  // kind 2: reversed_hyper_dims
     std::vector<ConvW> hconvs;    // kind 2: packed layers
+    float *d_prior = nullptr;     // kind 2: FlexiblePrior per channel, 44 floats (softplus / tanh applied), or null
     std::vector<int> rev_dims;    // kind 1: [dim*m for m in rev_mults] + [out_channels]
     int up_index = 1;
     std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
@@ -170,9 +172,10 @@ int fail(cdc_handle *h, int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // manifest (reference state_dict order: time_mlp, downs, ups, mid_*, final_conv)
 // ------------------------------------------------------------------------------------------------
-void add_param(cdc_handle *h, const std::string &name, std::vector<int64_t> shape) {
+void add_param(cdc_handle *h, const std::string &name, std::vector<int64_t> shape, bool optional = false) {
     Param p;
     p.name = name;
+    p.optional = optional;
     p.shape = std::move(shape);
     h->pindex[name] = (int)h->params.size();
     h->params.push_back(std::move(p));
@@ -1359,7 +1362,12 @@ void cdc_destroy(cdc_handle *h) {
     delete h;
 }
 
-int cdc_num_tensors(const cdc_handle *h) { return h ? (int)h->params.size() : CDC_ERR_INVALID; }
+int cdc_num_tensors(const cdc_handle *h) {
+    if (!h) return CDC_ERR_INVALID;
+    int n = 0;
+    for (const Param &p : h->params) n += p.optional ? 0 : 1;     // optional entries sit at the end
+    return n;
+}
 
 int cdc_tensor_info(const cdc_handle *h, int index, const char **name, int64_t shape[4], int *ndim) {
     if (!h || index < 0 || index >= (int)h->params.size()) return CDC_ERR_INVALID;
@@ -1395,7 +1403,7 @@ int cdc_load_tensor(cdc_handle *h, const char *name, const float *data, const in
 int cdc_finalize_weights(cdc_handle *h) {
     if (!h) return CDC_ERR_INVALID;
     for (const Param &p : h->params)
-        if (!p.loaded) return fail(h, CDC_ERR_STATE, "missing key \"%s\"", p.name.c_str());
+        if (!p.loaded && !p.optional) return fail(h, CDC_ERR_STATE, "missing key \"%s\"", p.name.c_str());
     int rc = ensure_device(h);
     if (rc) return rc;
     HIP_TRY(h, hipDeviceSynchronize());
@@ -1411,6 +1419,35 @@ int cdc_finalize_weights(cdc_handle *h) {
             const bool last = i == n - 1;
             if ((rc = pack_named_conv(h, p + ".weight", p + ".bias", last ? 1 : 2, last ? 1 : 2, !last, &cw))) return rc;
             h->hconvs.push_back(cw);
+        }
+        h->d_prior = nullptr;
+        if (h->params[h->pindex.at("prior.affine.0.weight")].loaded) {
+            // per channel: softplus(W0)[3] b0[3] tanh(a0)[3] | softplus(W1)[9] b1[3] tanh(a1)[3] | softplus(W2)[9] b2[3]
+            // tanh(a2)[3] | softplus(W3)[3] b3[1] | pad  = 44 floats  (PriorFunction.forward, FlexiblePrior.cdf)
+            const int pc = h->hyper_dims[0];
+            std::vector<float> pk((size_t)pc * 44, 0.f);
+            auto sp = [](float v) { return v > 20.f ? v : (float)log1p(exp((double)v)); };      // F.softplus (threshold 20)
+            const int pd[5] = {1, 3, 3, 3, 1};
+            for (int c = 0; c < pc; ++c) {
+                float *o = &pk[(size_t)c * 44];
+                for (int i = 0; i < 4; ++i) {
+                    const std::string pi = "prior.affine." + std::to_string(i);
+                    for (const char *suf : {".weight", ".bias"})
+                        if (!h->params[h->pindex.at(pi + suf)].loaded) return fail(h, CDC_ERR_STATE, "missing key \"%s%s\"", pi.c_str(), suf);
+                    const auto &w = hostp(h, pi + ".weight");
+                    const auto &bb = hostp(h, pi + ".bias");
+                    const int nin = pd[i], nout = pd[i + 1];
+                    for (int k = 0; k < nin * nout; ++k) *o++ = sp(w[(size_t)c * nin * nout + k]);
+                    for (int k = 0; k < nout; ++k) *o++ = bb[(size_t)c * nout + k];
+                    if (i < 3) {
+                        const std::string ai = "prior.a." + std::to_string(i);
+                        if (!h->params[h->pindex.at(ai)].loaded) return fail(h, CDC_ERR_STATE, "missing key \"%s\"", ai.c_str());
+                        const auto &a = hostp(h, ai);
+                        for (int k = 0; k < nout; ++k) *o++ = (float)tanh((double)a[(size_t)c * nout + k]);
+                    }
+                }
+            }
+            if ((rc = upload(h, pk.data(), pk.size(), &h->d_prior, &h->weight_allocs))) return rc;
         }
         h->shift_bs = 0;
         h->finalized = true;
@@ -1522,7 +1559,55 @@ int cdc_hyperdec_create(const cdc_hyperdec_config *cfg, int device, cdc_handle *
         else add_param(h.get(), p + ".weight", {din, dout, 5, 5});                          // ConvTranspose2d
         add_param(h.get(), p + ".bias", {dout});
     }
+    // FlexiblePrior(channels = dims[0], dims = [3, 3, 3]) (network_components.py:316-336), squeezed shapes;
+    // optional: only cdc_bpp needs it
+    const int pc = h->hyper_dims[0], pd[5] = {1, 3, 3, 3, 1};
+    for (int i = 0; i < 4; ++i) {
+        add_param(h.get(), "prior.affine." + std::to_string(i) + ".weight", {pc, pd[i], pd[i + 1]}, true);
+        add_param(h.get(), "prior.affine." + std::to_string(i) + ".bias", {pc, pd[i + 1]}, true);
+        if (i < 3) add_param(h.get(), "prior.a." + std::to_string(i), {pc, pd[i + 1]}, true);
+    }
     *out = h.release();
+    return CDC_OK;
+}
+
+int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, const float *mean, const float *scale,
+            float *bpp, int B, int hh, int wh, int H_img, int W_img, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->kind != 2) return fail(h, CDC_ERR_STATE, "handle is not a hyper decoder");
+    if (!h->d_prior) return fail(h, CDC_ERR_STATE, "the prior.* tensors were not loaded");
+    if (!q_hyper_latent || !q_latent || !mean || !scale || !bpp || B < 1 || hh < 1 || wh < 1 || H_img < 1 || W_img < 1)
+        return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    const int Ch = h->hyper_dims[0], Cl = h->hyper_dims.back() / 2;
+    const long long nh = (long long)Ch * hh * wh, nl = (long long)Cl * 16 * hh * wh;
+    hipStream_t st = pick_stream(h, stream, mem);
+    std::vector<void *> tmp;
+    auto dev = [&](const float *p, long long n) -> const float * {
+        if (mem == CDC_MEM_DEVICE) return p;
+        void *d = nullptr;
+        if (hipMalloc(&d, sizeof(float) * n) != hipSuccess) return nullptr;
+        tmp.push_back(d);
+        (void)hipMemcpyAsync(d, p, sizeof(float) * n, hipMemcpyHostToDevice, st);
+        return (const float *)d;
+    };
+    const float *dqh = dev(q_hyper_latent, B * nh), *dql = dev(q_latent, B * nl), *dm = dev(mean, B * nl),
+                *ds = dev(scale, B * nl);
+    float *dout = nullptr;
+    hipError_t e = hipSuccess;
+    if (!dqh || !dql || !dm || !ds) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+        if (mem == CDC_MEM_DEVICE) dout = bpp;
+        else { e = hipMalloc(&dout, sizeof(float) * B); if (e == hipSuccess) tmp.push_back(dout); }
+    }
+    if (e == hipSuccess)
+        e = bpp_launch(dqh, nh, hh * wh, h->d_prior, dql, dm, ds, nl, 1.0f / ((float)H_img * (float)W_img), dout, B, st);
+    if (e == hipSuccess && mem != CDC_MEM_DEVICE) {
+        e = hipMemcpyAsync(bpp, dout, sizeof(float) * B, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (mem != CDC_MEM_DEVICE) { (void)hipStreamSynchronize(st); for (void *d : tmp) (void)hipFree(d); }
+    if (e != hipSuccess) return fail(h, CDC_ERR_HIP, "cdc_bpp: %s", hipGetErrorString(e));
     return CDC_OK;
 }
 

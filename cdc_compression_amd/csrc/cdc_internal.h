@@ -119,6 +119,8 @@ struct DdimArgs {
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
                                 long long n, int B, hipStream_t st, int parts = 1, long long part_stride = 0);
+hipError_t bpp_launch(const float *qh, long long nh, int hw_h, const float *prior, const float *ql, const float *mean,
+                      const float *scale, long long nl, float inv_hw, float *bpp, int B, hipStream_t st);
 hipError_t clamp_min_launch(float *x, long long bs, long long n, float lo, int B, hipStream_t st);
 hipError_t dequantize_launch(const float *x, const float *loc, float *out, long long n, hipStream_t st);
 hipError_t unfold_x_launch(const float *src, long long src_bs, float *dst, long long dst_bs, int C, int KW,

@@ -156,6 +156,15 @@ int cdc_hyperdec_create(const cdc_hyperdec_config *cfg, int device, cdc_handle *
 int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean, float *scale, int B,
                         int h_hyper, int w_hyper, float scale_min, int mem_kind, void *stream);
 
+/* Compressor.bpp, eval mode (compress_modules.py:76-90): bpp[b] = (sum -log2 FlexiblePrior.likelihood(q_hyper_latent)
+ * + sum -log2 NormalDistribution(mean, scale).likelihood(q_latent)) / (H_img * W_img).  Needs the FlexiblePrior
+ * tensors, loaded (optionally) through cdc_load_tensor under the reference's keys with the singleton axes squeezed:
+ * "prior.affine.<i>.weight" [C][in][out], "prior.affine.<i>.bias" [C][out], "prior.a.<i>" [C][out]
+ * (network_components.py:316-336; dims 1-3-3-3-1).  q_latent / mean / scale: [B][dims[n]/2][4h][4w]. */
+int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, const float *mean,
+            const float *scale, float *bpp, int B, int h_hyper, int w_hyper, int H_img, int W_img, int mem_kind,
+            void *stream);
+
 /* quantize(x, "dequantize", offset) = round(x - offset) + offset, round = half-to-even (utils.py:72-85). */
 int cdc_dequantize(cdc_handle *h, const float *x, const float *offset, float *out, long long n, int mem_kind,
                    void *stream);

@@ -413,3 +413,53 @@ def dequantize(x, offset):
     x = np.asarray(x, np.float32)
     offset = np.asarray(offset, np.float32)
     return (np.rint(x - offset) + offset).astype(np.float32)
+
+
+def _erfc(a):
+    from math import erfc
+    return np.frompyfunc(erfc, 1, 1)(np.asarray(a, np.float64)).astype(np.float64)
+
+
+def normal_likelihood(x, loc, scale, minimum=1e-9):
+    """NormalDistribution.likelihood utils.py:147-159: Phi((.5-|x-loc|)/scale) - Phi((-.5-|x-loc|)/scale),
+    Phi(t) = 0.5 erfc(-t / sqrt 2), lower-bounded (float64 here; the reference is float32)."""
+    d = np.abs(np.asarray(x, np.float64) - np.asarray(loc, np.float64))
+    s = np.asarray(scale, np.float64)
+    c = -(2.0 ** -0.5)
+    upper = 0.5 * _erfc(c * ((0.5 - d) / s))
+    lower = 0.5 * _erfc(c * ((-0.5 - d) / s))
+    return np.maximum(upper - lower, minimum)
+
+
+def flexible_prior_logits(sd, x):
+    """FlexiblePrior.cdf(x, logits=True) network_components.py:342-358 with PriorFunction.forward :305-309
+    (softplus weights); parameters under the reference keys, original 5-D shapes or squeezed."""
+    x = np.asarray(x, np.float64)
+    C = x.shape[1]
+    h = np.moveaxis(x, 1, 0)[..., None]                     # [C, B, H, W, 1]
+    for i in range(4):
+        w = np.asarray(sd[f"prior.affine.{i}.weight"], np.float64).reshape(C, 1, 1, -1, (1, 3, 3, 3, 1)[i + 1])
+        b = np.asarray(sd[f"prior.affine.{i}.bias"], np.float64).reshape(C, 1, 1, 1, -1)
+        spw = np.where(w > 20, w, np.log1p(np.exp(np.minimum(w, 20))))
+        h = np.matmul(h, spw) + b
+        if i < 3:
+            a = np.asarray(sd[f"prior.a.{i}"], np.float64).reshape(C, 1, 1, 1, -1)
+            h = h + np.tanh(a) * np.tanh(h)
+    return np.moveaxis(h[..., 0], 0, 1)
+
+
+def flexible_prior_likelihood(sd, x, minimum=1e-9):
+    """FlexiblePrior.likelihood network_components.py:372-378."""
+    lower = flexible_prior_logits(sd, np.asarray(x, np.float64) - 0.5)
+    upper = flexible_prior_logits(sd, np.asarray(x, np.float64) + 0.5)
+    sign = -np.sign(lower + upper)
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    return np.maximum(np.abs(sig(upper * sign) - sig(lower * sign)), minimum)
+
+
+def compressor_bpp(sd, image_hw, q_hyper_latent, q_latent, mean, scale):
+    """Compressor.bpp compress_modules.py:76-90 (eval mode, quantised inputs given)."""
+    hyper_rate = -np.log2(flexible_prior_likelihood(sd, q_hyper_latent))
+    cond_rate = -np.log2(normal_likelihood(q_latent, mean, scale))
+    H, W = image_hw
+    return ((hyper_rate.sum(axis=(1, 2, 3)) + cond_rate.sum(axis=(1, 2, 3))) / (H * W)).astype(np.float32)

@@ -329,10 +329,29 @@ def gen_hyperdec(name):
         scale = scale.clamp(min=0.1)
         latent = torch.from_numpy(synth.normal("latent", tuple(mean.shape), seed=9, std=3.0))
         ql = ut.quantize(latent, "dequantize", mean)
+    # rate estimate: the reference's own bpp() (eval mode) on synthetic latents, prior parameters from synth
+    pman = [(k, list(v.shape)) for k, v in net.state_dict().items()
+            if k.startswith("prior.affine") or k.startswith("prior.a.")]
+    psd = synth.unet_state_dict(pman, seed=11)
+    for k in psd:
+        if ".weight" in k:
+            psd[k] = (psd[k] * 2.0).astype(np.float32)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in psd.items()}, strict=False)
+    with torch.no_grad():
+        hyper_latent = torch.from_numpy(synth.normal("hyper_latent", (B, c0, hh, wh), seed=10, std=2.0))
+        latent_b = mean + torch.from_numpy(synth.normal("latent_b", tuple(mean.shape), seed=14, std=1.0)) * scale
+        state = {"latent": latent_b, "hyper_latent": hyper_latent,
+                 "latent_distribution": ut.NormalDistribution(mean, scale)}
+        img_hw = (hh * 64, wh * 64)
+        bpp = net.bpp((B, 3) + img_hw, state)
+        q_hyper_for_bpp = ut.quantize(hyper_latent, "dequantize", net.prior.medians)
+        q_latent_for_bpp = ut.quantize(latent_b, "dequantize", mean)
     json.dump({"kwargs": {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items()},
-               "class": cls, "tree": tree, "dims": list(net.reversed_hyper_dims), "manifest": man},
+               "class": cls, "tree": tree, "dims": list(net.reversed_hyper_dims), "manifest": man,
+               "prior_manifest": pman},
               open(os.path.join(HERE, f"manifest_{name}.json"), "w"))
-    rec = {"q_hyper_latent": q}
+    rec = {"q_hyper_latent": q, "bpp": bpp.numpy(), "q_hyper_for_bpp": q_hyper_for_bpp.numpy(), "q_latent_for_bpp": q_latent_for_bpp.numpy(),
+           "img_hw": np.array(img_hw)}
     for key, t in (("mean", mean), ("scale", scale), ("q_latent", ql)):
         a = t.numpy()
         if a.size <= 70000:

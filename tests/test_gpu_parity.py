@@ -372,3 +372,22 @@ def test_non_square_frame_against_double_accumulating_oracle():
     y = un(x, t, ctx)
     ref64 = om.unet_forward(oops.OrcOps("f64"), oracle_cfg(kw), sd, x, t, ctx)
     assert relerr(y, ref64) < 2e-5, relerr(y, ref64)
+
+
+@pytest.mark.parametrize("name", ["hyperdec_small_x", "hyperdec_full_x", "hyperdec_full_eps"])
+def test_rate_estimate_matches_reference_bpp(name):
+    """cdc_bpp (FlexiblePrior + NormalDistribution likelihoods, -log2, sums) against the reference's own bpp()."""
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    if "mean" not in g.files:
+        pytest.skip("digest-only fixture")
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    pman = [(k, tuple(v)) for k, v in meta["prior_manifest"]]
+    psd = synth.unet_state_dict(pman, seed=11)
+    sd = {**synth.unet_state_dict(man, seed=7),
+          **{k: ((v * 2.0).astype(np.float32) if ".weight" in k else v) for k, v in psd.items()}}
+    m = getattr(cdc, meta["class"])(**meta["kwargs"])
+    m.load_hyper_state_dict(sd)
+    b = m.rate(g["q_hyper_for_bpp"], g["q_latent_for_bpp"], g["mean"], g["scale"], tuple(g["img_hw"]))
+    assert b.shape == g["bpp"].shape
+    assert np.abs(b - g["bpp"]).max() <= 1e-4 * max(1.0, float(np.abs(g["bpp"]).max())), (b, g["bpp"])

@@ -206,3 +206,22 @@ def test_hyperdec_oracle_matches_reference_golden(name):
     if "mean" in g.files and "q_latent" in g.files:
         latent = synth.normal("latent", tuple(g["mean"].shape), seed=9, std=3.0)
         np.testing.assert_array_equal(om.dequantize(latent, g["mean"]), g["q_latent"])
+
+
+def _prior_sd(meta):
+    pman = [(k, tuple(v)) for k, v in meta["prior_manifest"]]
+    psd = synth.unet_state_dict(pman, seed=11)
+    return {k: ((v * 2.0).astype(np.float32) if ".weight" in k else v) for k, v in psd.items()}
+
+
+@pytest.mark.parametrize("name", HYPERDEC_CASES)
+def test_rate_estimate_matches_reference_bpp(name):
+    """Compressor.bpp of the real reference (eval mode; FlexiblePrior + NormalDistribution likelihoods) vs the
+    restatement, on the reference's own quantised latents."""
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    if "mean" not in g.files:
+        pytest.skip("digest-only fixture")
+    b = om.compressor_bpp(_prior_sd(meta), tuple(g["img_hw"]), g["q_hyper_for_bpp"], g["q_latent_for_bpp"],
+                          g["mean"], g["scale"])
+    assert np.abs(b - g["bpp"]).max() <= 1e-5 * max(1.0, float(np.abs(g["bpp"]).max()))
