@@ -35,6 +35,12 @@ class HyperdecConfig(ctypes.Structure):
     _fields_ = [("n_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * (CDC_MAX_LEVELS + 1))]
 
 
+class EncoderConfig(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int32), ("channels", ctypes.c_int32), ("n_dim_mults", ctypes.c_int32),
+                ("dim_mults", ctypes.c_int32 * CDC_MAX_LEVELS), ("n_hyper_mults", ctypes.c_int32),
+                ("hyper_mults", ctypes.c_int32 * CDC_MAX_LEVELS), ("down_index", ctypes.c_int32)]
+
+
 class CdcError(RuntimeError):
     pass
 
@@ -79,6 +85,8 @@ def lib():
     L.cdc_unet_forward.argtypes = [H, _vp, _vp, pp, _i, _vp, _i, _i, _i, _i, _vp]
     L.cdc_ctxdec_create.argtypes = [ctypes.POINTER(CtxdecConfig), _i, ctypes.POINTER(H)]
     L.cdc_ctxdec_decode.argtypes = [H, _vp, pp, _i, _i, _i, _i, _i, _vp]
+    L.cdc_encoder_create.argtypes = [ctypes.POINTER(EncoderConfig), _i, ctypes.POINTER(H)]
+    L.cdc_encoder_encode.argtypes = [H, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
     L.cdc_hyperdec_create.argtypes = [ctypes.POINTER(HyperdecConfig), _i, ctypes.POINTER(H)]
     L.cdc_hyperdec_decode.argtypes = [H, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _i, _vp]
     L.cdc_dequantize.argtypes = [H, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp]
@@ -108,7 +116,8 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_prof_num_classes", "cdc_prof_name", "cdc_prof_get", "cdc_prof_reset",
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
-           "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp"]
+           "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
+           "cdc_encoder_encode"]
 
 
 def check(handle, rc):

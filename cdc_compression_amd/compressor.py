@@ -2,9 +2,10 @@
 
 `ResnetCompressor` (xparam/modules/compress_modules.py:110-177) and `BigCompressor`
 (epsilonparam/modules/compress_modules.py:112-185) keep the reference constructors' argument names;
-only `decode(q_latent)` (compress_modules.py:68-74) -- the synthesis transform that turns the
-transmitted latents into the context pyramid of the denoising U-Net -- is implemented (SURVEY
-section 8f row 1).  `load_state_dict` accepts the reference compressor's full state_dict and takes its
+`decode(q_latent)` (compress_modules.py:68-74) -- the synthesis transform that turns the transmitted latents
+into the context pyramid of the denoising U-Net -- is SURVEY section 8f row 1; `encode(images)` / `forward(images)`
+(analysis transform + hyper encoder + quantisers, :43-66, :92-103) are row 3, so that a whole
+`GaussianDiffusion.compress()` runs on the GPU with no reference module in the loop.  `load_state_dict` accepts the reference compressor's full state_dict and takes its
 `dec.*` (and, when present, `hyper_dec.*`) entries; `encode` / `bpp` / `forward` (analysis transform,
 hyper encoder, rate estimate) raise NotImplementedError: the reference module stays in charge of those.
 
@@ -18,6 +19,17 @@ import numpy as np
 
 from . import _lib
 from .unet import _Arg, _as_host_f32, _current_stream, _result_like
+
+
+class NormalDistribution:
+    """Holder with the attribute names of utils.py:134-145 (`loc`, `scale`, `mean`)."""
+
+    def __init__(self, loc, scale):
+        self.loc, self.scale = loc, scale
+
+    @property
+    def mean(self):
+        return self.loc
 
 
 class _ContextDecoder:
@@ -37,6 +49,8 @@ class _ContextDecoder:
         self._hyper_finalized = False
         self._prior_loaded = False
         self._medians = None
+        self._eh = None
+        self._enc_finalized = False
         self.reversed_hyper_dims = None
 
     # ---- handle management ----------------------------------------------------------------
@@ -65,6 +79,9 @@ class _ContextDecoder:
             if self._hh is not None:
                 _lib.lib().cdc_destroy(self._hh)
                 self._hh = None
+            if self._eh is not None:
+                _lib.lib().cdc_destroy(self._eh)
+                self._eh = None
         except Exception:
             pass
 
@@ -121,6 +138,8 @@ class _ContextDecoder:
         self._finalized = True
         if any(k.startswith("hyper_dec.") for k in state_dict):
             self.load_hyper_state_dict(state_dict)      # also takes prior.* when present
+        if any(k.startswith("enc.") for k in state_dict):
+            self.load_encoder_state_dict(state_dict)
         return self
 
     def state_dict(self):
@@ -263,19 +282,99 @@ class _ContextDecoder:
         dist = state4bpp["latent_distribution"]
         mean, scale = (dist.mean, dist.scale) if hasattr(dist, "mean") else dist
         hyper = state4bpp["hyper_latent"]
-        med = np.broadcast_to(self._medians, tuple(_Arg(hyper, self.device_index).shape)).copy()
-        if type(hyper).__module__.startswith("torch"):
-            import torch
-            med = torch.from_numpy(med).to(hyper.device)
-        q_hyper = self.dequantize(hyper, med)
+        q_hyper = self.dequantize(hyper, self._medians_like(hyper))
         q_latent = self.dequantize(state4bpp["latent"], mean)
         return self.rate(q_hyper, q_latent, mean, scale, (H, W))
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("the analysis transform / hyper encoder run in the reference module "
-                                  "(SURVEY section 8f row 3)")
+    # ---- encoder ---------------------------------------------------
+    def _enc_handle(self):
+        if self._eh is None:
+            L = _lib.lib()
+            cfg = _lib.EncoderConfig()
+            cfg.dim, cfg.channels, cfg.down_index = self.dim, self.channels, self._up_index
+            cfg.n_dim_mults, cfg.n_hyper_mults = len(self.dim_mults), len(self.hyper_dims_mults)
+            for i, m in enumerate(self.dim_mults):
+                cfg.dim_mults[i] = m
+            for i, m in enumerate(self.hyper_dims_mults):
+                cfg.hyper_mults[i] = m
+            h = ctypes.c_void_p()
+            rc = L.cdc_encoder_create(ctypes.byref(cfg), self.device_index, ctypes.byref(h))
+            if rc != 0:
+                raise _lib.CdcError(f"cdc_encoder_create failed ({rc}): {L.cdc_last_error(None).decode()}")
+            self._eh = h
+        return self._eh
 
-    forward = __call__ = encode
+    def encoder_manifest(self):
+        L, h = _lib.lib(), self._enc_handle()
+        out = []
+        for i in range(L.cdc_num_tensors(h)):
+            name = ctypes.c_char_p()
+            shape = (ctypes.c_int64 * 4)()
+            nd = ctypes.c_int()
+            _lib.check(h, L.cdc_tensor_info(h, i, ctypes.byref(name), shape, ctypes.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value))))
+        return out
+
+    def load_encoder_state_dict(self, state_dict):
+        """`enc.*` and `hyper_enc.*` entries of the reference compressor's state_dict."""
+        L, h = _lib.lib(), self._enc_handle()
+        names = [n for n, _ in self.encoder_manifest()]
+        missing = [n for n in names if n not in state_dict]
+        unexpected = [k for k in state_dict if (k.startswith("enc.") or k.startswith("hyper_enc.")) and k not in names]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}.enc: missing "
+                               f"{missing[:3]}, unexpected {unexpected[:3]}")
+        for n in names:
+            a = _as_host_f32(state_dict[n])
+            shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            _lib.check(h, L.cdc_load_tensor(h, n.encode(), a.ctypes.data, shape, a.ndim))
+        _lib.check(h, L.cdc_finalize_weights(h))
+        self._enc_finalized = True
+        return self
+
+    def analysis(self, images):
+        """The unquantised (latent, hyper_latent) of Compressor.encode (compress_modules.py:43-51)."""
+        L, h = _lib.lib(), self._enc_handle()
+        if not self._enc_finalized:
+            raise _lib.CdcError("load_encoder_state_dict() has not been called")
+        ax = _Arg(images, self.device_index)
+        B, C, H, W = ax.shape
+        n, nh = len(self.dim_mults), len(self.hyper_dims_mults)
+        lat, pl, _ = _result_like(images, (B, self.dim * self.dim_mults[-1], H >> n, W >> n), self.device_index)
+        hyp, ph, _ = _result_like(images, (B, self.dim * self.hyper_dims_mults[-1], H >> (n + nh - 1), W >> (n + nh - 1)),
+                                  self.device_index)
+        _lib.check(h, L.cdc_encoder_encode(h, ax.ptr, pl, ph, B, H, W, ax.mem, _current_stream(ax.mem)))
+        return lat, hyp
+
+    def _medians_like(self, t):
+        shape = tuple(_Arg(t, self.device_index).shape)
+        med = self._medians if self._medians is not None else np.zeros((1, shape[1], 1, 1), np.float32)
+        med = np.broadcast_to(med, shape).copy()
+        if type(t).__module__.startswith("torch"):
+            import torch
+            med = torch.from_numpy(med).to(t.device)
+        return med
+
+    def encode(self, input, cond=None):
+        """Compressor.encode (compress_modules.py:43-66): (q_latent, q_hyper_latent, state4bpp)."""
+        if cond is not None:
+            raise NotImplementedError("vbr conditioning is not implemented (vbr=False)")
+        latent, hyper_latent = self.analysis(input)
+        q_hyper_latent = self.dequantize(hyper_latent, self._medians_like(hyper_latent))
+        mean, scale = self.hyper_decode(q_hyper_latent)
+        q_latent = self.dequantize(latent, mean)
+        state4bpp = {"latent": latent, "hyper_latent": hyper_latent,
+                     "latent_distribution": NormalDistribution(mean, scale)}
+        return q_latent, q_hyper_latent, state4bpp
+
+    def forward(self, input, cond=None):
+        """Compressor.forward (compress_modules.py:92-103)."""
+        q_latent, q_hyper_latent, state4bpp = self.encode(input, cond)
+        shape = tuple(_Arg(input, self.device_index).shape)
+        return {"output": self.decode(q_latent), "bpp": self.bpp(shape, state4bpp), "q_latent": q_latent,
+                "q_hyper_latent": q_hyper_latent}
+
+    __call__ = forward
 
 
 class ResnetCompressor(_ContextDecoder):

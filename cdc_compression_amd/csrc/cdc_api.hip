@@ -85,7 +85,10 @@ struct Op {
 
 struct cdc_handle {
     cdc_unet_config cfg;
-    int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode), 2: hyper decoder
+    int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode), 2: hyper decoder,
+                                  // 3: encoder (enc + hyper_enc)
+    std::vector<int> enc_dims, henc_dims;     // kind 3
+    int down_index = 1;
     std::vector<int> hyper_dims;  // kind 2: reversed_hyper_dims
     std::vector<ConvW> hconvs;    // kind 2: packed layers
     float *d_prior = nullptr;     // kind 2: FlexiblePrior per channel, 44 floats (softplus / tanh applied), or null
@@ -1100,6 +1103,43 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     return CDC_OK;
 }
 
+// Launch program of Compressor.encode up to the quantisers (compress_modules.py:43-51) for images [B][C][H][W].
+int build_encoder_program(cdc_handle *h, int B, int H, int W) {
+    if (h->pB == B && h->pH == H && h->pW == W) return CDC_OK;
+    free_program(h);
+    const int n = (int)h->enc_dims.size() - 1, nh = (int)h->henc_dims.size() - 1;
+    const int down = 1 << (n + nh - 1);
+    if (H % down || W % down)
+        return fail(h, CDC_ERR_INVALID, "H=%d, W=%d must be multiples of %d", H, W, down);
+    Builder bd{h, B, &h->act_allocs};
+    h->in_x = bd.dalloc((size_t)B * h->enc_dims[0] * H * W);
+    if (bd.rc) return bd.rc;
+    Act x; x.p = h->in_x; x.C = h->enc_dims[0]; x.H = H; x.W = W;
+    for (int i = 0; i < n; ++i) {
+        x = bd.resblock(h->rbs[i], x, nullptr, false, nullptr, nullptr);
+        const ConvW &dw = h->downs[i];
+        Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2);
+        bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false, PC_DOWN);
+        x = y;
+        if (bd.rc) return bd.rc;
+    }
+    h->dec_outs.clear();
+    h->dec_outs.push_back(x);                       // latent
+    for (int i = 0; i < nh; ++i) {
+        const ConvW &cw = h->hconvs[i];
+        const int s = i == 0 ? 1 : 2;
+        Act y = bd.new_act(cw.Cout, x.H / s, x.W / s);
+        Builder::ConvOpts o;
+        if (i < nh - 1) { o.relu = 1; o.relu_slope = 0.2f; }
+        bd.conv(cw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), o, false, i == 0 ? PC_CONV3 : PC_DOWN);
+        x = y;
+        if (bd.rc) return bd.rc;
+    }
+    h->dec_outs.push_back(x);                       // hyper_latent
+    h->pB = B; h->pH = H; h->pW = W;
+    return CDC_OK;
+}
+
 // Launch program of Compressor.hyper_dec (compress_modules.py:54-60) for q_hyper_latent [B][dims[0]][hh][wh].
 int build_hyperdec_program(cdc_handle *h, int B, int hh, int wh) {
     if (h->pB == B && h->pH == hh && h->pW == wh) return CDC_OK;
@@ -1410,6 +1450,30 @@ int cdc_finalize_weights(cdc_handle *h) {
     free_program(h);
     free_pool(&h->weight_allocs);
     h->rbs.clear(); h->attns.clear(); h->downs.clear(); h->ups.clear();
+    if (h->kind == 3) {
+        const int n = (int)h->enc_dims.size() - 1;
+        int shift_off = 0;
+        for (int i = 0; i < n; ++i) {
+            const std::string p = "enc." + std::to_string(i);
+            if ((rc = pack_resblock(h, p + ".0", h->enc_dims[i], h->enc_dims[i + 1], i == 0 ? 7 : 3, &shift_off, 0, false)))
+                return rc;
+            ConvW dw;
+            const std::string d = p + "." + std::to_string(h->down_index) + ".conv";
+            if ((rc = pack_named_conv(h, d + ".weight", d + ".bias", 2, 1, false, &dw))) return rc;
+            h->downs.push_back(dw);
+        }
+        h->hconvs.clear();
+        const int nh = (int)h->henc_dims.size() - 1;
+        for (int i = 0; i < nh; ++i) {
+            const std::string p = "hyper_enc." + std::to_string(i) + ".0";
+            ConvW cw;
+            if ((rc = pack_named_conv(h, p + ".weight", p + ".bias", i == 0 ? 1 : 2, i == 0 ? 1 : 2, false, &cw))) return rc;
+            h->hconvs.push_back(cw);
+        }
+        h->shift_bs = 0;
+        h->finalized = true;
+        return CDC_OK;
+    }
     if (h->kind == 2) {
         const int n = (int)h->hyper_dims.size() - 1;
         h->hconvs.clear();
@@ -1537,6 +1601,56 @@ int cdc_finalize_weights(cdc_handle *h) {
     h->d_temb_layers = (TembLayer *)dl;
     h->finalized = true;
     return CDC_OK;
+}
+
+int cdc_encoder_create(const cdc_encoder_config *cfg, int device, cdc_handle **out) {
+    if (!cfg || !out) return fail(nullptr, CDC_ERR_INVALID, "null argument");
+    if (cfg->dim <= 0 || cfg->channels < 1 || cfg->n_dim_mults < 1 || cfg->n_dim_mults > CDC_MAX_LEVELS ||
+        cfg->n_hyper_mults < 1 || cfg->n_hyper_mults > CDC_MAX_LEVELS || cfg->down_index < 1 || cfg->down_index > 2)
+        return fail(nullptr, CDC_ERR_INVALID, "bad cdc_encoder_config");
+    if (device < 0) return fail(nullptr, CDC_ERR_INVALID, "device %d out of range", device);
+    std::unique_ptr<cdc_handle> h(new cdc_handle);
+    memset(&h->cfg, 0, sizeof h->cfg);
+    h->cfg.dim = cfg->dim;
+    h->kind = 3;
+    h->device = device;
+    h->down_index = cfg->down_index;
+    h->enc_dims.push_back(cfg->channels);
+    for (int i = 0; i < cfg->n_dim_mults; ++i) h->enc_dims.push_back(cfg->dim * cfg->dim_mults[i]);
+    h->henc_dims.push_back(h->enc_dims.back());
+    for (int i = 0; i < cfg->n_hyper_mults; ++i) h->henc_dims.push_back(cfg->dim * cfg->hyper_mults[i]);
+    for (int i = 0; i < cfg->n_dim_mults; ++i) {          // registration order of Compressor.enc (:131-141)
+        const std::string p = "enc." + std::to_string(i);
+        add_resblock_params(h.get(), p + ".0", h->enc_dims[i], h->enc_dims[i + 1], i == 0 ? 7 : 3, false);
+        const std::string d = p + "." + std::to_string(cfg->down_index) + ".conv";
+        add_param(h.get(), d + ".weight", {h->enc_dims[i + 1], h->enc_dims[i + 1], 3, 3});
+        add_param(h.get(), d + ".bias", {h->enc_dims[i + 1]});
+    }
+    for (int i = 0; i < cfg->n_hyper_mults; ++i) {        // Compressor.hyper_enc (:155-165)
+        const std::string p = "hyper_enc." + std::to_string(i) + ".0";
+        const int k = i == 0 ? 3 : 5;
+        add_param(h.get(), p + ".weight", {h->henc_dims[i + 1], h->henc_dims[i], k, k});
+        add_param(h.get(), p + ".bias", {h->henc_dims[i + 1]});
+    }
+    *out = h.release();
+    return CDC_OK;
+}
+
+int cdc_encoder_encode(cdc_handle *h, const float *images, float *latent, float *hyper_latent, int B, int H, int W,
+                       int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->kind != 3) return fail(h, CDC_ERR_STATE, "handle is not an encoder");
+    if (!images || !latent || !hyper_latent || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    if ((rc = build_encoder_program(h, B, H, W))) return rc;
+    hipStream_t st = pick_stream(h, stream, mem);
+    if ((rc = copy_in(h, h->in_x, images, (size_t)B * h->enc_dims[0] * H * W, mem, st))) return rc;
+    h->prof_now = true;
+    for (const Op &op : h->ops)
+        if ((rc = run_op(h, op, h->pB, st))) return rc;
+    const Act &l = h->dec_outs[0], &hl = h->dec_outs[1];
+    if ((rc = copy_out(h, latent, l.p, (size_t)B * l.C * l.H * l.W, mem, st))) return rc;
+    return copy_out(h, hyper_latent, hl.p, (size_t)B * hl.C * hl.H * hl.W, mem, st);
 }
 
 int cdc_hyperdec_create(const cdc_hyperdec_config *cfg, int device, cdc_handle **out) {

@@ -138,6 +138,31 @@ int cdc_ctxdec_create(const cdc_ctxdec_config *cfg, int device, cdc_handle **out
 int cdc_ctxdec_decode(cdc_handle *h, const float *q_latent, float *const *outs, int n_outs, int B,
                       int h_latent, int w_latent, int mem_kind, void *stream);
 
+/* ---- encoder: analysis transform + hyper encoder --------------------- */
+
+/* Compressor.encode up to the quantisers (compress_modules.py:43-51,131-165): `enc` = n_dim_mults x
+ * [ResnetBlock(dims[i] -> dims[i+1], no time embedding, 7x7 first block on level 0), Downsample (Conv2d 3x3 s2)],
+ * then `hyper_enc` = Conv2d(3x3) + n_hyper-1 x Conv2d(5x5, stride 2, padding 2), LeakyReLU(0.2) between.
+ * dims = [channels] + [dim*m for m in dim_mults]; hyper dims = [dims[-1]] + [dim*m for m in hyper_mults].
+ * down_index: position of the Downsample in each `enc` ModuleList (1 xparam ResnetCompressor, 2 epsilonparam
+ * BigCompressor).  Parameters: the reference's "enc.*" / "hyper_enc.*" keys through cdc_load_tensor. */
+typedef struct {
+    int32_t dim, channels;
+    int32_t n_dim_mults;
+    int32_t dim_mults[CDC_MAX_LEVELS];
+    int32_t n_hyper_mults;
+    int32_t hyper_mults[CDC_MAX_LEVELS];
+    int32_t down_index;
+} cdc_encoder_config;
+
+int cdc_encoder_create(const cdc_encoder_config *cfg, int device, cdc_handle **out);
+
+/* images [B][channels][H][W] (H, W multiples of 2^(n_dim_mults + n_hyper_mults - 1)) ->
+ * latent [B][dims[-1]][H/2^n][W/2^n], hyper_latent [B][hyper_dims[-1]][...]: the UNquantised tensors
+ * (`latent`, `hyper_latent` of state4bpp); quantisation is cdc_dequantize with the prior medians / the mean. */
+int cdc_encoder_encode(cdc_handle *h, const float *images, float *latent, float *hyper_latent, int B, int H,
+                       int W, int mem_kind, void *stream);
+
 /* ---- hyperprior decoder (decode side) ------------------------------------ */
 
 /* Compressor.hyper_dec (xparam/modules/compress_modules.py:54-60,166-177; epsilonparam/...:58-66,171-185):

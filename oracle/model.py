@@ -463,3 +463,48 @@ def compressor_bpp(sd, image_hw, q_hyper_latent, q_latent, mean, scale):
     cond_rate = -np.log2(normal_likelihood(q_latent, mean, scale))
     H, W = image_hw
     return ((hyper_rate.sum(axis=(1, 2, 3)) + cond_rate.sum(axis=(1, 2, 3))) / (H * W)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# encoder: analysis transform + hyper encoder
+# --------------------------------------------------------------------------------------------
+
+
+def encoder_manifest(dim, dim_mults, hyper_mults, channels=3, down_index=1):
+    """`enc.*` and `hyper_enc.*` entries of the reference Compressor.state_dict() (compress_modules.py:131-165)."""
+    dims = [channels] + [dim * m for m in dim_mults]
+    out = []
+    for ind, (din, dout) in enumerate(zip(dims[:-1], dims[1:])):
+        k = 7 if ind == 0 else 3
+        p = f"enc.{ind}.0"
+        out += [(p + ".block1.block.0.weight", (dout, din, k, k)), (p + ".block1.block.0.bias", (dout,)),
+                (p + ".block1.block.1.g", (1, dout, 1, 1)), (p + ".block1.block.1.b", (1, dout, 1, 1)),
+                (p + ".block2.block.0.weight", (dout, dout, 3, 3)), (p + ".block2.block.0.bias", (dout,)),
+                (p + ".block2.block.1.g", (1, dout, 1, 1)), (p + ".block2.block.1.b", (1, dout, 1, 1))]
+        if din != dout:
+            out += [(p + ".res_conv.weight", (dout, din, 1, 1)), (p + ".res_conv.bias", (dout,))]
+        d = f"enc.{ind}.{down_index}.conv"
+        out += [(d + ".weight", (dout, dout, 3, 3)), (d + ".bias", (dout,))]
+    hd = [dims[-1]] + [dim * m for m in hyper_mults]
+    for ind, (din, dout) in enumerate(zip(hd[:-1], hd[1:])):
+        k = 3 if ind == 0 else 5
+        out += [(f"hyper_enc.{ind}.0.weight", (dout, din, k, k)), (f"hyper_enc.{ind}.0.bias", (dout,))]
+    return out
+
+
+def compressor_encode(ops, sd, x, n_levels, n_hyper, down_index=1):
+    """Compressor.encode compress_modules.py:43-51 up to the quantisers: returns (latent, hyper_latent)."""
+    x = np.asarray(x, np.float32)
+    for ind in range(n_levels):
+        x = resnet_block(ops, sd, f"enc.{ind}.0", x)
+        x = downsample(ops, sd, f"enc.{ind}.{down_index}", x)
+    latent = x
+    for ind in range(n_hyper):
+        p = f"hyper_enc.{ind}.0"
+        if ind == 0:
+            x = ops.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=1, padding=1)
+        else:
+            x = ops.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=2, padding=2)
+        if ind < n_hyper - 1:
+            x = np.where(x >= 0, x, np.float32(0.2) * x).astype(np.float32)
+    return latent, x

@@ -365,6 +365,53 @@ def gen_hyperdec(name):
     print(name, "ok", tuple(mean.shape), float(scale.min()))
 
 
+ENCODER = {
+    # name: (tree, class, ctor kwargs, down_index, H, W, B)
+    "encoder_small_x": ("xparam", "ResnetCompressor",
+                        dict(dim=8, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                             hyper_dims_mults=[4, 4, 4], channels=3, out_channels=8), 1, 64, 128, 2),
+    "encoder_full_x": ("xparam", "ResnetCompressor",
+                       dict(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                            hyper_dims_mults=[4, 4, 4], channels=3, out_channels=64), 1, 128, 128, 1),
+    "encoder_full_eps": ("epsilonparam", "BigCompressor",
+                         dict(dim=64, dim_mults=(1, 2, 3, 4), hyper_dims_mults=(4, 4, 4), channels=3,
+                              out_channels=3, vbr=False), 2, 64, 128, 1),
+}
+
+
+def gen_encoder(name):
+    """encode() of the real reference on a synthetic image: the unquantised latent / hyper_latent (the quantisers
+    are covered by the hyperdec fixtures), plus the whole forward() (bpp and the context pyramid) for the
+    end-to-end chain."""
+    tree, cls, kw, down_index, H, W, B = ENCODER[name]
+    ref = import_reference(tree)
+    net = getattr(ref.cm, cls)(**kw)
+    keep = ("enc.", "hyper_enc.", "hyper_dec.", "dec.", "prior.affine", "prior.a.")
+    man = [(k, list(v.shape)) for k, v in net.state_dict().items() if k.startswith(keep)]
+    sd = synth.unet_state_dict(man, seed=15)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net.eval()
+    x = (synth.normal("image", (B, 3, H, W), seed=16, std=0.5)).clip(-1, 1).astype(np.float32)
+    with torch.no_grad():
+        q_latent, q_hyper, st = net.encode(torch.from_numpy(x))
+        out = net(torch.from_numpy(x))
+    json.dump({"kwargs": {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items()},
+               "class": cls, "tree": tree, "down_index": down_index, "manifest": man,
+               "medians_shape": list(net.prior.medians.shape)},
+              open(os.path.join(HERE, f"manifest_{name}.json"), "w"))
+    rec = {"image_shape": np.array(x.shape), "bpp": out["bpp"].numpy()}
+    for key, t in (("latent", st["latent"]), ("hyper_latent", st["hyper_latent"]), ("q_latent", out["q_latent"]),
+                   ("q_hyper_latent", out["q_hyper_latent"]), ("ctx0", out["output"][0]), ("ctx3", out["output"][3])):
+        a = t.numpy()
+        if a.size <= 40000:
+            rec[key] = a
+        d = digest(a)
+        rec.update({f"{key}_shape": np.array(a.shape), f"{key}_idx": d["idx"], f"{key}_val": d["val"],
+                    f"{key}_sum": d["sum"]})
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "ok", tuple(st["latent"].shape), tuple(st["hyper_latent"].shape), out["bpp"].numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_schedules()
@@ -378,3 +425,5 @@ if __name__ == "__main__":
         gen_ctxdec(n)
     for n in HYPERDEC:
         gen_hyperdec(n)
+    for n in ENCODER:
+        gen_encoder(n)

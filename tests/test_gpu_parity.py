@@ -391,3 +391,62 @@ def test_rate_estimate_matches_reference_bpp(name):
     b = m.rate(g["q_hyper_for_bpp"], g["q_latent_for_bpp"], g["mean"], g["scale"], tuple(g["img_hw"]))
     assert b.shape == g["bpp"].shape
     assert np.abs(b - g["bpp"]).max() <= 1e-4 * max(1.0, float(np.abs(g["bpp"]).max())), (b, g["bpp"])
+
+
+# ---- encoder and the whole compressor forward ---------------------------------
+
+def _symbols_close(a, ref, max_flip_frac=2e-3):
+    """Quantised tensors: equal up to fp32 round-off except where a value sat within round-off of a rounding
+    boundary (then it differs by exactly one quantisation step): allow a small fraction of such flips."""
+    d = np.abs(a - ref)
+    near = d <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    flip = np.abs(d - 1.0) <= 1e-3
+    assert (near | flip).all()
+    assert flip.mean() <= max_flip_frac, float(flip.mean())
+
+
+@pytest.mark.parametrize("name", ["encoder_small_x", "encoder_full_x", "encoder_full_eps"])
+def test_compressor_forward_matches_reference_golden(name):
+    """Compressor.forward of the real reference -- analysis transform, hyper encoder, both quantisers, hyper
+    decoder, rate estimate and the synthesis transform -- entirely through the C-ABI."""
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    sd = synth.unet_state_dict(man, seed=15)
+    m = getattr(cdc, meta["class"])(**meta["kwargs"])
+    m.load_state_dict(sd)
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    x = synth.normal("image", tuple(g["image_shape"]), seed=16, std=0.5).clip(-1, 1).astype(np.float32)
+    latent, hyper = m.analysis(x)
+    for key, a in (("latent", latent), ("hyper_latent", hyper)):
+        assert list(a.shape) == list(g[f"{key}_shape"])
+        assert relerr(a.reshape(-1)[g[f"{key}_idx"]], g[f"{key}_val"]) < TOL
+        if key in g.files:
+            assert relerr(a, g[key]) < TOL
+    out = m(x)
+    assert set(out) == {"output", "bpp", "q_latent", "q_hyper_latent"}
+    for key in ("q_latent", "q_hyper_latent"):
+        if key in g.files:
+            _symbols_close(out[key], g[key])
+    assert np.abs(out["bpp"] - g["bpp"]).max() <= 2e-3 * max(1.0, float(np.abs(g["bpp"]).max())), (out["bpp"], g["bpp"])
+    assert len(out["output"]) == 4 and list(out["output"][0].shape) == list(g["ctx0_shape"])
+    # the pyramid depends on q_latent: where no symbol flipped it matches the reference
+    if "q_latent" in g.files and np.array_equal(out["q_latent"], g["q_latent"]):
+        assert relerr(out["output"][3].reshape(-1)[g["ctx3_idx"]], g["ctx3_val"]) < TOL
+        assert relerr(out["output"][0].reshape(-1)[g["ctx0_idx"]], g["ctx0_val"]) < TOL
+
+
+def test_compress_end_to_end_without_reference_module():
+    """GaussianDiffusion.compress with the GPU compressor as context_fn: images -> (reconstruction, bpp)."""
+    meta = json.load(open(os.path.join(GOLDEN, "manifest_encoder_full_x.json")))
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    comp = cdc.ResnetCompressor(**meta["kwargs"])
+    comp.load_state_dict(synth.unet_state_dict(man, seed=15))
+    un, kw, usd, _, _, _, _ = make_unet("full_x")
+    diff = cdc.GaussianDiffusionX(un, comp, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    x = synth.normal("image", (2, 3, 64, 128), seed=16, std=0.5).clip(-1, 1).astype(np.float32)
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    rec, bpp = diff.compress(x, sample_steps=2, bpp_return_mean=False, init=init)
+    assert rec.shape == x.shape and np.isfinite(rec).all() and np.abs(rec).max() <= 1.0 + 1e-6
+    assert bpp.shape == (2,) and np.isfinite(bpp).all() and (bpp > 0).all()
+    ctx = comp(x)["output"]
+    np.testing.assert_array_equal(rec, diff.decompress(ctx, x.shape, sample_steps=2, init=init))

@@ -131,7 +131,7 @@ def test_ctxdec_load_state_dict_takes_dec_entries_only():
     bad["dec.9.0.block1.block.0.weight"] = np.zeros((1,), np.float32)
     with pytest.raises(RuntimeError, match="unexpected"):
         m.load_state_dict(bad)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.CdcError, match="load_encoder_state_dict"):      # encoder weights never loaded
         m.encode(np.zeros((1, 3, 64, 64), np.float32))
     if not _has_gpu():
         full = dict(sd)
@@ -146,3 +146,11 @@ def test_hyperdec_manifest_matches_reference_state_dict(name):
     m = getattr(cdc, meta["class"])(**meta["kwargs"])
     assert m.reversed_hyper_dims == meta["dims"]
     assert [(n, list(s)) for n, s in m.hyper_manifest()] == [(n, list(s)) for n, s in meta["manifest"]]
+
+
+@pytest.mark.parametrize("name", ["encoder_small_x", "encoder_full_x", "encoder_full_eps"])
+def test_encoder_manifest_matches_reference_state_dict(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    m = getattr(cdc, meta["class"])(**meta["kwargs"])
+    want = [(n, list(s)) for n, s in meta["manifest"] if n.startswith("enc.") or n.startswith("hyper_enc.")]
+    assert [(n, list(s)) for n, s in m.encoder_manifest()] == want

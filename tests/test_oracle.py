@@ -225,3 +225,26 @@ def test_rate_estimate_matches_reference_bpp(name):
     b = om.compressor_bpp(_prior_sd(meta), tuple(g["img_hw"]), g["q_hyper_for_bpp"], g["q_latent_for_bpp"],
                           g["mean"], g["scale"])
     assert np.abs(b - g["bpp"]).max() <= 1e-5 * max(1.0, float(np.abs(g["bpp"]).max()))
+
+
+# ---- encoder ---------------------------------------------------------------
+
+ENCODER_CASES = ["encoder_small_x", "encoder_full_x", "encoder_full_eps"]
+
+
+@pytest.mark.parametrize("name", ENCODER_CASES)
+def test_encoder_oracle_matches_reference_golden(name):
+    """The unquantised latent / hyper_latent of the real reference's encode() vs the restatement."""
+    meta = json.load(open(os.path.join(GOLDEN, f"manifest_{name}.json")))
+    kw = meta["kwargs"]
+    man = [(k, tuple(v)) for k, v in meta["manifest"]]
+    eman = [(k, s) for k, s in man if k.startswith("enc.") or k.startswith("hyper_enc.")]
+    assert om.encoder_manifest(kw["dim"], kw["dim_mults"], kw["hyper_dims_mults"], kw["channels"],
+                               meta["down_index"]) == eman
+    sd = synth.unet_state_dict(man, seed=15)
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    x = synth.normal("image", tuple(g["image_shape"]), seed=16, std=0.5).clip(-1, 1).astype(np.float32)
+    latent, hyper = om.compressor_encode(oops.OrcOps("f32"), sd, x, len(kw["dim_mults"]),
+                                         len(kw["hyper_dims_mults"]), meta["down_index"])
+    _digest_close(latent, g, "latent")
+    _digest_close(hyper, g, "hyper_latent")
