@@ -90,10 +90,13 @@ class _ContextDecoder:
         if isinstance(device, str):
             idx = int(device.split(":")[1]) if ":" in device else 0
         idx = 0 if idx is None else int(idx)
-        if idx != self.device_index and self._h is not None:
-            _lib.lib().cdc_destroy(self._h)
-            self._h = None
-            self._finalized = False
+        if idx != self.device_index:
+            # the handles are bound to a device: drop them (parameters must be loaded again on the new one)
+            for attr in ("_h", "_hh", "_eh"):
+                if getattr(self, attr) is not None:
+                    _lib.lib().cdc_destroy(getattr(self, attr))
+                    setattr(self, attr, None)
+            self._finalized = self._hyper_finalized = self._enc_finalized = self._prior_loaded = False
         self.device_index = idx
         return self
 
