@@ -190,21 +190,41 @@ def main():
                                  for k, v in classes.items()},
             },
         }
-        if world == 1 and a.param == "x" and S % 16 == 0:
-            # informational (outside the timed region): Compressor.decode on the GPU, q_latent -> pyramid
-            dec = cdc.ResnetCompressor(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
-                                       hyper_dims_mults=[4, 4, 4], channels=3, out_channels=64, device=local)
-            dec.load_state_dict(synth.unet_state_dict(dec.manifest(), seed=5))
+        if world == 1 and a.param == "x" and S % 64 == 0:
+            # informational (outside the timed region): the compressor on the GPU -- Compressor.forward (analysis
+            # transform, hyper encoder/decoder, quantisers, rate estimate, synthesis transform) and decode alone
+            comp = cdc.ResnetCompressor(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],
+                                        hyper_dims_mults=[4, 4, 4], channels=3, out_channels=64, device=local)
+            man = comp.manifest() + comp.hyper_manifest() + comp.encoder_manifest()
+            csd = synth.unet_state_dict(man, seed=5)
+            C0 = comp.reversed_hyper_dims[0]
+            pd = (1, 3, 3, 3, 1)
+            for i in range(4):
+                csd[f"prior.affine.{i}.weight"] = synth.normal(f"pw{i}", (C0, 1, 1, pd[i], pd[i + 1]), 5, 1.0)
+                csd[f"prior.affine.{i}.bias"] = synth.normal(f"pb{i}", (C0, 1, 1, 1, pd[i + 1]), 5, 0.1)
+                if i < 3:
+                    csd[f"prior.a.{i}"] = synth.normal(f"pa{i}", (C0, 1, 1, 1, pd[i + 1]), 5, 0.5)
+            comp.load_state_dict(csd)
+            img = torch.rand((B, 3, S, S), generator=gen, device=dev) * 2 - 1
             q = torch.round(torch.randn((B, 256, S // 16, S // 16), generator=gen, device=dev) * 2.0)
-            dec.decode(q)
-            torch.cuda.synchronize()
-            tq = time.perf_counter()
-            for _ in range(5):
-                pyr = dec.decode(q)
-            torch.cuda.synchronize()
-            out["context_decode"] = {"ms_per_batch": (time.perf_counter() - tq) / 5 * 1e3, "batch": B,
+
+            def timed(fn, n=5):
+                fn()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    r = fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3, r
+            ms_dec, pyr = timed(lambda: comp.decode(q))
+            ms_fwd, fo = timed(lambda: comp(img))
+            out["context_decode"] = {"ms_per_batch": ms_dec, "batch": B,
                                      "finite": bool(all(torch.isfinite(p).all().item() for p in pyr)),
                                      "note": "Compressor.decode (SURVEY 8f row 1), once per image, not in `value`"}
+            out["compressor_forward"] = {"ms_per_batch": ms_fwd, "batch": B,
+                                         "finite": bool(torch.isfinite(fo["bpp"]).all().item()),
+                                         "note": "Compressor.forward = encode + bpp + decode (SURVEY 8f rows 1-3), "
+                                                 "once per image, not in `value`"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
         out["roofline"]["class_ms_per_ddim_iter"] = {k: v["ms"] / max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps) for k, v in classes.items()}
