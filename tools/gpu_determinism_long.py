@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Development aid: long race screen -- two 60-step batch-32 decodes and 150 repeated batch-2 forwards at 256x256
+must be bit-identical (split-K sums, online-softmax rescaling, LDS-DMA staging all have fixed orders)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import cdc_compression_amd as cdc
+from cdc_compression_amd import synth
+KW = dict(dim=64, channels=3, context_channels=64, dim_mults=(1, 2, 3, 4, 5, 6), context_dim_mults=(1, 2, 3, 4))
+un = cdc.Unet(**KW); un.load_state_dict(synth.unet_state_dict(un.manifest(), seed=0))
+diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+dev = torch.device("cuda", 0); g = torch.Generator(device=dev).manual_seed(3)
+B = 32
+init = torch.randn((B, 3, 256, 256), generator=g, device=dev) * 0.8
+ctx = [torch.randn((B, c, 256 >> l, 256 >> l), generator=g, device=dev) * 0.5 for l, c in enumerate([64, 64, 128, 192])]
+a = diff.decompress(ctx, (B, 3, 256, 256), sample_steps=60, init=init).clone()
+b = diff.decompress(ctx, (B, 3, 256, 256), sample_steps=60, init=init)
+print("decode x2 identical:", bool(torch.equal(a, b)), "finite:", bool(torch.isfinite(a).all()))
+x = torch.randn((2, 3, 256, 256), generator=g, device=dev); t = torch.full((2, 1), 0.3, device=dev)
+c2 = [c[:2].contiguous() for c in ctx]
+y0 = un(x, t, c2).clone(); bad = 0
+for i in range(150):
+    bad += int(not torch.equal(un(x, t, c2), y0))
+print("forward repeats differing:", bad, "of 150")
+assert torch.equal(a, b) and bad == 0
