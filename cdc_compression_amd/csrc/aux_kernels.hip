@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <stdlib.h>
 
 #include "cdc_internal.h"
 
@@ -174,7 +175,8 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache) {
-        if (a.HW <= 256)
+        static const int pl8_max = getenv("CDC_LN_PL8_MAX") ? atoi(getenv("CDC_LN_PL8_MAX")) : 256;
+        if (a.HW <= pl8_max)
             hipLaunchKernelGGL(ln_kernel_sliced<8>, dim3((unsigned)ceil_div(a.HW, 8), (unsigned)B), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL(ln_kernel_sliced<32>, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
