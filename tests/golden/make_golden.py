@@ -412,6 +412,47 @@ def gen_encoder(name):
     print(name, "ok", tuple(st["latent"].shape), tuple(st["hyper_latent"].shape), out["bpp"].numpy())
 
 
+def gen_kodak(steps=500):
+    """BASELINE configs[0]: the reference's full x-param compress() on the three Kodak images it ships
+    (imgs/1.png..3.png, centre crop rows 128:384 / cols 256:512 as in SURVEY 8(d)), synthetic parameters, 500 DDIM
+    steps on the CPU.  Stored: the crops (data), the reference's bpp, q_latent / reconstruction digests."""
+    from PIL import Image
+    tree = "xparam"
+    ref = import_reference(tree)
+    _, kw, _, _, _, _ = CONFIGS["full_x"]
+    net = ref.unet.Unet(**kw)
+    uman, usd = load_synth(net, seed=0)
+    ckw = ENCODER["encoder_full_x"][2]
+    comp = ref.cm.ResnetCompressor(**ckw)
+    keep = ("enc.", "hyper_enc.", "hyper_dec.", "dec.", "prior.affine", "prior.a.")
+    cman = [(k, list(v.shape)) for k, v in comp.state_dict().items() if k.startswith(keep)]
+    csd = synth.unet_state_dict(cman, seed=15)
+    comp.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()}, strict=False)
+    comp.eval()
+    crops = []
+    for i in (1, 2, 3):
+        im = np.asarray(Image.open(os.path.join(REF, "imgs", f"{i}.png")).convert("RGB"))
+        if im.shape[0] > im.shape[1]:
+            im = np.transpose(im, (1, 0, 2))
+        crops.append(im[128:384, 256:512].copy())
+    crops = np.stack(crops)                                         # [3, 256, 256, 3] uint8
+    x = torch.from_numpy(crops).permute(0, 3, 1, 2).float() / 255.0 * 2.0 - 1.0
+    diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=comp, ae_fn=None, **DIFF[tree])
+    diff.eval()
+    init = synth.normal("init", tuple(x.shape), seed=1, std=0.8)
+    with torch.no_grad():
+        cd = comp(x)
+        rec, bpp = diff.compress(x, sample_steps=steps, bpp_return_mean=False, init=torch.from_numpy(init.copy()))
+    rec = rec.numpy()
+    d = digest(rec, nsample=256)
+    dq = digest(cd["q_latent"].numpy(), nsample=256)
+    np.savez_compressed(os.path.join(HERE, f"kodak_x_{steps}.npz"), crops=crops, steps=np.array(steps),
+                        bpp=bpp.numpy(), rec_idx=d["idx"], rec_val=d["val"], rec_sum=d["sum"], rec_sumsq=d["sumsq"],
+                        q_idx=dq["idx"], q_val=dq["val"], q_sum=dq["sum"], q_latent=cd["q_latent"].numpy(),
+                        psnr=np.array([10 * np.log10(4.0 / np.mean((rec[i] - x[i].numpy()) ** 2)) for i in range(3)]))
+    print("kodak ok", bpp.numpy(), d["sum"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_schedules()
@@ -427,3 +468,4 @@ if __name__ == "__main__":
         gen_hyperdec(n)
     for n in ENCODER:
         gen_encoder(n)
+    gen_kodak()          # ~20 min on 8 cores
