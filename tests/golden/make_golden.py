@@ -453,6 +453,39 @@ def gen_kodak(steps=500):
     print("kodak ok", bpp.numpy(), d["sum"])
 
 
+def gen_kodak_eps(steps=1000):
+    """epsilon-param counterpart of gen_kodak (BASELINE configs[2] step count on the reference's own images):
+    BigCompressor + eps U-Net, compress(sample_mode="ddim"), 1000 steps, no clipping."""
+    from PIL import Image
+    tree = "epsilonparam"
+    ref = import_reference(tree)
+    _, kw, _, _, _, _ = CONFIGS["full_eps"]
+    net = ref.unet.Unet(**kw)
+    load_synth(net, seed=0, final_gain=0.2)
+    ckw = ENCODER["encoder_full_eps"][2]
+    comp = ref.cm.BigCompressor(**ckw)
+    keep = ("enc.", "hyper_enc.", "hyper_dec.", "dec.", "prior.affine", "prior.a.")
+    cman = [(k, list(v.shape)) for k, v in comp.state_dict().items() if k.startswith(keep)]
+    csd = synth.unet_state_dict(cman, seed=15)
+    comp.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()}, strict=False)
+    comp.eval()
+    crops = np.load(os.path.join(HERE, "kodak_x_500.npz"))["crops"]
+    x = torch.from_numpy(crops).permute(0, 3, 1, 2).float() / 255.0 * 2.0 - 1.0
+    diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=comp, **DIFF[tree])
+    diff.eval()
+    init = synth.normal("init", tuple(x.shape), seed=1, std=0.8)
+    with torch.no_grad():
+        cd = comp(x)
+        rec, bpp = diff.compress(x, sample_steps=steps, sample_mode="ddim", bpp_return_mean=False,
+                                 init=torch.from_numpy(init.copy()))
+    rec = rec.numpy()
+    d = digest(rec, nsample=256)
+    np.savez_compressed(os.path.join(HERE, f"kodak_eps_{steps}.npz"), steps=np.array(steps), bpp=bpp.numpy(),
+                        rec_idx=d["idx"], rec_val=d["val"], rec_sum=d["sum"], rec_sumsq=d["sumsq"],
+                        q_latent=cd["q_latent"].numpy())
+    print("kodak eps ok", bpp.numpy(), d["sum"], float(np.abs(rec).max()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_schedules()
@@ -468,4 +501,5 @@ if __name__ == "__main__":
         gen_hyperdec(n)
     for n in ENCODER:
         gen_encoder(n)
-    gen_kodak()          # ~20 min on 8 cores
+    gen_kodak()          # ~15 min on 8 cores
+    gen_kodak_eps()      # ~25 min

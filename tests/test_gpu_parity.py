@@ -478,3 +478,30 @@ def test_kodak_crops_500_steps_match_reference():
     assert flipped <= 20, flipped
     d2 = np.abs(rec2.reshape(-1)[g["rec_idx"]] - g["rec_val"])
     assert d2.mean() < (1e-5 if flipped == 0 else 5e-3), (flipped, float(d2.mean()))
+
+
+def test_kodak_crops_eps_1000_steps_match_reference():
+    """epsilon-param counterpart (BASELINE configs[2] step count): the reference's CPU run of
+    compress(sample_mode="ddim") with BigCompressor on the same three crops, 1000 steps, no clipping.  The decode
+    path alone (reference q_latent -> context decoder -> 1000 DDIM steps) must stay within 1e-3 of it."""
+    path = os.path.join(GOLDEN, "kodak_eps_1000.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g = np.load(path)
+    crops = np.load(os.path.join(GOLDEN, "kodak_x_500.npz"))["crops"]
+    un, kw, usd, _, _, _, _ = make_unet("full_eps")
+    meta = json.load(open(os.path.join(GOLDEN, "manifest_encoder_full_eps.json")))
+    comp = cdc.BigCompressor(**meta["kwargs"])
+    comp.load_state_dict(synth.unet_state_dict([(k, tuple(v)) for k, v in meta["manifest"]], seed=15))
+    diff = cdc.GaussianDiffusionEps(un, comp, num_timesteps=20000, clip_noise="none", pred_mode="noise",
+                                    var_schedule="linear")
+    x = (crops.astype(np.float32).transpose(0, 3, 1, 2) / 255.0 * 2.0 - 1.0).astype(np.float32)
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    steps = int(g["steps"])
+    rec = diff.decompress(comp.decode(g["q_latent"]), x.shape, sample_steps=steps, init=init)
+    scale = max(1.0, float(np.abs(g["rec_val"]).max()))
+    d = np.abs(rec.reshape(-1)[g["rec_idx"]] - g["rec_val"]) / scale
+    assert d.max() < 1e-3, float(d.max())
+    out = comp(x)
+    assert np.abs(out["bpp"] - g["bpp"]).max() <= 1e-5 * float(np.abs(g["bpp"]).max())
+    assert int((np.abs(out["q_latent"] - g["q_latent"]) > 0.5).sum()) <= 20
