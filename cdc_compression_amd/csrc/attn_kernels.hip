@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
     // ---- the wave's rows of W' ---------------------------------------------------------------------
     // C = 64: the projection runs fp32-exact on the bf16 cores (three-way split operands, six products);
     // A operand of v_mfma_f32_32x32x16_bf16: lane (i = j, kh) holds W'[row i][16q + 8kh .. +7] per plane.
-    // C = 128 keeps v_mfma_f32_32x32x2_f32 (its split planes would not fit the register file).
-    constexpr bool kSplitP1 = CB == 2;
+    // With two row blocks per wave (<4,4>) the split planes would not fit the register file: f32 MFMA there.
+    constexpr bool kSplitP1 = BPW == 1;               // <2,4> and <4,8>: 12 * C/16 registers of split weights
     float wr[kSplitP1 ? 1 : BPW][kSplitP1 ? 1 : C / 2], bias[BPW][16];
     bf16x8 ws[kSplitP1 ? BPW : 1][kSplitP1 ? C / 16 : 1][3];
 #pragma unroll
@@ -213,10 +213,10 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
 hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
     if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
     dim3 grid((unsigned)a.nsplit, (unsigned)B);
-    static const bool w8 = getenv("CDC_KVCTX_W8") != nullptr;      // experiment: 8 waves per workgroup (no gain measured)
+    static const bool w4 = getenv("CDC_KVCTX_W4") != nullptr;      // C = 128: 4 waves with the f32-MFMA projection
     if (a.C == 64) hipLaunchKernelGGL((kvctx_kernel<2, 4>), grid, dim3(256), 0, st, a);
-    else if (a.C == 128 && w8) hipLaunchKernelGGL((kvctx_kernel<4, 8>), grid, dim3(512), 0, st, a);
-    else if (a.C == 128) hipLaunchKernelGGL((kvctx_kernel<4, 4>), grid, dim3(256), 0, st, a);
+    else if (a.C == 128 && w4) hipLaunchKernelGGL((kvctx_kernel<4, 4>), grid, dim3(256), 0, st, a);
+    else if (a.C == 128) hipLaunchKernelGGL((kvctx_kernel<4, 8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
