@@ -221,4 +221,85 @@ hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Folded attention output (network_components.py:136-139 after the fold of DESIGN.md section 4):
+//     y[c][n] = rstd[n] * sum_ci M'[b][c][ci] (x[ci][n] - mean[n]) + bias[b][c] + x[c][n]
+// A bandwidth-bound C x C pointwise product with per-image weights: no LDS, no barrier.  Wave w owns output
+// channels [32w, 32w+32) with its three bf16 weight planes in registers for the whole pixel range; the pixel
+// operand is loaded per lane (lane = pixel: 128-byte rows), split in registers, six bf16 MFMAs per 16 input
+// channels; the accumulator layout (lane = pixel, 16 channels) stores 128-byte row segments directly.
+// ------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(64 * CB, 2) lnconv_kernel(const LnConvArgs a) {
+    constexpr int C = 32 * CB;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int N = a.N, per = N / a.nsplit, p0 = sp * per;
+    const float *x = a.x + (size_t)b * a.x_bs;
+    float *y = a.y + (size_t)b * a.y_bs;
+    const float *mean = a.mean + (size_t)b * N, *rstd = a.rstd + (size_t)b * N;
+    bf16x8 ws[C / 16][3];
+    {
+        const uint4 *wp = reinterpret_cast<const uint4 *>(a.Ws) + (size_t)b * (C / 16) * 6 * C;
+#pragma unroll
+        for (int c = 0; c < C / 16; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                ws[c][pl] = __builtin_bit_cast(bf16x8, wp[(size_t)((c * 3 + pl) * 2 + kh) * C + wave * 32 + j]);
+    }
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = a.bias[(size_t)b * C + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+    const char *xb = reinterpret_cast<const char *>(x);
+    char *yb = reinterpret_cast<char *>(y);
+    for (int t0 = 0; t0 < per; t0 += 32) {
+        const int px = p0 + t0 + j;
+        const float mu = mean[px], rs = rstd[px];
+        const unsigned voff = (unsigned)(8 * kh * N + px) * 4u;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C / 16; ++c) {
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                split3(*reinterpret_cast<const float *>(xb + (size_t)(16 * c + i) * N * 4 + voff) - mu, hh[i], mm[i], ll[i]);
+            uint4 vh, vm, vl;
+            vh.x = (hh[0] >> 16) | hh[1]; vh.y = (hh[2] >> 16) | hh[3];
+            vh.z = (hh[4] >> 16) | hh[5]; vh.w = (hh[6] >> 16) | hh[7];
+            vm.x = (mm[0] >> 16) | mm[1]; vm.y = (mm[2] >> 16) | mm[3];
+            vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
+            vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
+            vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
+            const bf16x8 B[3] = {__builtin_bit_cast(bf16x8, vh), __builtin_bit_cast(bf16x8, vm),
+                                 __builtin_bit_cast(bf16x8, vl)};
+#pragma unroll
+            for (int pa = 2; pa >= 0; --pa)
+#pragma unroll
+                for (int pb = 2 - pa; pb >= 0; --pb)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[c][pa], B[pb], acc, 0, 0, 0);
+        }
+        // epilogue: lane = pixel, register r = channel 32w + (r&3) + 8(r>>2) + 4kh
+        const unsigned eoff = (unsigned)((wave * 32 + 4 * kh) * N + px) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t row = (size_t)((r & 3) + 8 * (r >> 2)) * N * 4;
+            const float res = *reinterpret_cast<const float *>(xb + row + eoff);
+            *reinterpret_cast<float *>(yb + row + eoff) = acc[r] * rs + bias[r] + res;
+        }
+    }
+}
+
+hipError_t lnconv_launch(const LnConvArgs &a, int B, hipStream_t st) {
+    if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)a.nsplit, (unsigned)B);
+    if (a.C == 64) hipLaunchKernelGGL(lnconv_kernel<2>, grid, dim3(128), 0, st, a);
+    else if (a.C == 128) hipLaunchKernelGGL(lnconv_kernel<4>, grid, dim3(256), 0, st, a);
+    else if (a.C == 192) hipLaunchKernelGGL(lnconv_kernel<6>, grid, dim3(384), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace cdc

@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, c
 
 __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const float *WqT, int C,
                                                      float scale, const float *ln_g, float *Mt,
-                                                     int Cin_pad, int COP) {
+                                                     int Cin_pad, int COP, unsigned short *Ws) {
     extern __shared__ __attribute__((aligned(16))) float rows[];   // [C][kFoldRows]: WqT rows ci0..ci0+7, d-major
     const int ci0 = blockIdx.x * kFoldRows, b = blockIdx.y;
     for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
@@ -561,10 +561,31 @@ __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const floa
             }
         }
 #pragma unroll
-        for (int r = 0; r < kFoldRows; ++r)
-            if (ci0 + r < Cin_pad)      // PreNorm gain folded in (LNMODE 2 of the conv kernel)
-                Mt[((size_t)b * Cin_pad + ci0 + r) * COP + c] =
-                    acc[r] * scale * (ci0 + r < C ? ln_g[ci0 + r] : 0.f);
+        for (int r = 0; r < kFoldRows; ++r) {
+            acc[r] = acc[r] * scale * (ci0 + r < C ? ln_g[ci0 + r] : 0.f);   // PreNorm gain folded in (LNMODE 2)
+            if (ci0 + r < Cin_pad) Mt[((size_t)b * Cin_pad + ci0 + r) * COP + c] = acc[r];
+        }
+        if (Ws && c < C) {
+            // the same 8 input channels x this output channel as three bf16 planes in the A-operand order of
+            // lnconv_kernel: [ci/16][plane][(ci/8)&1][co][8] -- the 8 rows of this workgroup are one 16-byte unit
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                hh[r] = __float_as_uint(acc[r]) & 0xFFFF0000u;
+                const float r1 = acc[r] - __uint_as_float(hh[r]);
+                mm[r] = __float_as_uint(r1) & 0xFFFF0000u;
+                ll[r] = __float_as_uint(r1 - __uint_as_float(mm[r]));
+            }
+            uint4 v[3];
+            v[0] = make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]);
+            v[1] = make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]);
+            v[2] = make_uint4((ll[0] >> 16) | (ll[1] & 0xFFFF0000u), (ll[2] >> 16) | (ll[3] & 0xFFFF0000u),
+                              (ll[4] >> 16) | (ll[5] & 0xFFFF0000u), (ll[6] >> 16) | (ll[7] & 0xFFFF0000u));
+            const int q = ci0 >> 4, kh = (ci0 >> 3) & 1;
+            uint4 *dst = reinterpret_cast<uint4 *>(Ws) + (size_t)b * (C / 16) * 6 * C;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[(size_t)((q * 3 + pl) * 2 + kh) * C + c] = v[pl];
+        }
     }
 }
 
@@ -585,14 +606,14 @@ __global__ void __launch_bounds__(256) ctx_r3_kernel(const float *T1, const floa
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
-                           float *biasB, int B, hipStream_t st, const float *M) {
+                           float *biasB, int B, hipStream_t st, const float *M, unsigned short *Ws) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     // Mt doubles as scratch for the normalised context (C*C <= Cin_pad*COP) until R2 overwrites it
     hipLaunchKernelGGL(ctx_r0_kernel, dim3(ceil_div(C * C, 256), B), dim3(256), 0, st, S, ksum, C, nsplit, Mt, M);
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
                        sizeof(float) * kFoldRows * C, st, Mt, C, WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),
-                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, ln_g, Mt, Cin_pad, COP);
+                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, ln_g, Mt, Cin_pad, COP, Ws);
     hipLaunchKernelGGL(ctx_r3_kernel, dim3(ceil_div(C, 64), B), dim3(64), 0, st, T1, u, b_out, scale, biasB, C);
     return hipGetLastError();
 }

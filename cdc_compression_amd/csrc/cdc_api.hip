@@ -61,7 +61,7 @@ struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                float *kvWt = nullptr, *kvb = nullptr; unsigned short *kvWs = nullptr; };   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV } kind;
     int prof = PC_SMALL;
     int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
     char label[96] = {0};
@@ -77,6 +77,8 @@ struct Op {
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
     int cp_parts = 1; long long cp_part_stride = 0;
     KvCtxArgs kvc;
+    LnConvArgs lnc;
+    unsigned short *at_Ws = nullptr;   // CTXF: also emit M' as bf16 planes for lnconv_kernel
     const float *at_M = nullptr;  // CTXF after KVCTX: per-split row maxima   // COPY: dst = sum of cp_parts planes of src
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
 };
@@ -558,7 +560,7 @@ struct Builder {
         op.id = (int)h->op_ms.size();
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
-        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx"};
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv"};
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
@@ -569,6 +571,8 @@ struct Builder {
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
             snprintf(buf, sizeof buf, "kvctx C=%d N=%d nsplit=%d", op.kvc.C, op.kvc.N, op.kvc.nsplit);
+        else if (op.kind == Op::LNCONV)
+            snprintf(buf, sizeof buf, "lnconv C=%d N=%d nsplit=%d", op.lnc.C, op.lnc.N, op.lnc.nsplit);
         else if (op.kind == Op::KSTATS || op.kind == Op::CTXP || op.kind == Op::CTXR || op.kind == Op::CTXF)
             snprintf(buf, sizeof buf, "%s C=%d N=%d nsplit=%d", kinds[op.kind], op.at.C, op.at.N, op.at.nsplit);
         else
@@ -938,8 +942,12 @@ struct Builder {
             p.flops = 2.0 * B * (double)C * C * N; p.bytes = 8.0 * B * C * N;
             emit(p);
         }
+        // folded output as one streaming pass (lnconv_kernel) where the level is wide enough to be bandwidth-bound
+        const bool stream_out = fold && (C == 64 || C == 192 || (C == 128 && getenv("CDC_LNCONV128"))) && N >= 4096 && N % 1024 == 0 &&
+                                !getenv("CDC_NO_LNCONV");
+        unsigned short *Ws = stream_out ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
-        r.at_M = kmaxs;
+        r.at_M = kmaxs; r.at_Ws = Ws;
         r.bytes = 4.0 * B * nsplit * C * C;
         r.flops = fold ? 4.0 * B * (double)C * C * C : 0.0;
         emit(r);
@@ -950,6 +958,15 @@ struct Builder {
         if (!fused)
         dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
+        if (stream_out) {
+            Op f; f.kind = Op::LNCONV; f.prof = PC_CONV1;
+            int ns = std::max(1, ceil_div(2048, B));
+            while (ns > 1 && N % (32 * ns)) --ns;
+            f.lnc = {x.p, x.bs(), sm, sr, Ws, biasB, y.p, y.bs(), C, N, ns};
+            f.flops = 2.0 * B * (double)C * C * N; f.bytes = 12.0 * B * C * N;
+            emit(f);
+            return y;
+        }
         if (fold) {
             // y = M' LN(x) + b_out + x with g folded into M' and (M' b_ln + b_out) as per-image shift
             ConvOpts oy;
@@ -1236,10 +1253,11 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
                                          op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
             break;
         case Op::KVCTX: HIP_TRY(h, kvctx_launch(op.kvc, B, st)); break;
+        case Op::LNCONV: HIP_TRY(h, lnconv_launch(op.lnc, B, st)); break;
         case Op::CTXF:
             HIP_TRY(h, ctx_fold_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale, op.at.WoT,
                                        op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, op.at.ln_g,
-                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M));
+                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M, op.at_Ws));
             break;
         case Op::COMBINE:
             HIP_TRY(h, fold_combine_launch(op.cb.P, op.cb.bias, op.cb.out, op.cb.Cout, op.cb.KH, op.cb.pad,

@@ -88,6 +88,17 @@ struct KvCtxArgs {
 };
 hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st);
 
+// Folded attention output y = M'[b] (x - mean) rstd + bias[b] + x as one streaming pass (attn_kernels.hip).
+struct LnConvArgs {
+    const float *x; long long x_bs;     // [B][C][N], also the residual
+    const float *mean, *rstd;           // [B][N]
+    const unsigned short *Ws;           // [B][C/16][3][2][C][8] bf16 planes of M'[b] (ctx_r2_kernel)
+    const float *bias;                  // [B][C]
+    float *y; long long y_bs;
+    int C, N, nsplit;
+};
+hipError_t lnconv_launch(const LnConvArgs &a, int B, hipStream_t st);
+
 hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *kmax, int B,
                          hipStream_t st);
 // S[b][split][d][e] = sum_{n in split} exp(k[d,n]-kmax[d]) * v[e,n]      (:135, unnormalised)
@@ -102,7 +113,8 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
-                           float *biasB, int B, hipStream_t st, const float *M = nullptr);
+                           float *biasB, int B, hipStream_t st, const float *M = nullptr,
+                           unsigned short *Ws = nullptr);
 hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
                                int pad, int H, int W, int B, hipStream_t st);
 
