@@ -656,11 +656,12 @@ hipError_t fold_combine_launch(const float *P, const float *bias, float *out, in
 // epsilonparam/modules/denoising_diffusion.py:137-152.  Same operation order as the reference.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
-    const float c_recip = a.tab[0 * a.steps + a.i];
-    const float c_recipm1 = a.tab[1 * a.steps + a.i];
-    const float c_acp = a.tab[2 * a.steps + a.i];
-    const float c_1macp = a.tab[3 * a.steps + a.i];
-    const float sig = a.eta * a.tab[4 * a.steps + a.i];
+    const int si = a.step_ptr ? *a.step_ptr : a.i;
+    const float c_recip = a.tab[0 * a.steps + si];
+    const float c_recipm1 = a.tab[1 * a.steps + si];
+    const float c_acp = a.tab[2 * a.steps + si];
+    const float c_1macp = a.tab[3 * a.steps + si];
+    const float sig = a.eta * a.tab[4 * a.steps + si];
     float var = c_1macp - sig * sig;
     if (a.pred_mode == 0) var = fmaxf(var, 0.f);          // x-param .clamp(min=0) (:169)
     const float c_eps = sqrtf(var);
@@ -683,6 +684,14 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
     }
 }
 
+// end of a graph-replayed DDIM iteration: the next replay works on step - 1
+__global__ void step_dec_kernel(int *step) { *step -= 1; }
+
+hipError_t step_dec_launch(int *step, hipStream_t st) {
+    hipLaunchKernelGGL(step_dec_kernel, dim3(1), dim3(1), 0, st, step);
+    return hipGetLastError();
+}
+
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
     const int grid = (int)std::min<long long>((a.n + 255) / 256, 4096);
     hipLaunchKernelGGL(ddim_kernel, dim3(grid), dim3(256), 0, st, a);
@@ -691,9 +700,10 @@ hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
 
 // dst[b][i] = sum_k src[k*part_stride + b*src_bs + i]   (parts = 1: plain channel copy; > 1: split-K slices)
 __global__ void __launch_bounds__(256) copy_kernel(const float *src, long long src_bs, float *dst,
-                                                   long long dst_bs, long long n, int parts, long long part_stride) {
+                                                   long long dst_bs, long long n, int parts, long long part_stride,
+                                                   const int *step_ptr, long long step_stride) {
     const int b = blockIdx.y;
-    const float *s = src + (size_t)b * src_bs;
+    const float *s = src + (size_t)b * src_bs + (step_ptr ? (size_t)*step_ptr * step_stride : 0);
     float *d = dst + (size_t)b * dst_bs;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
@@ -788,9 +798,11 @@ hipError_t dequantize_launch(const float *x, const float *loc, float *out, long 
 }
 
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
-                                long long n, int B, hipStream_t st, int parts, long long part_stride) {
+                                long long n, int B, hipStream_t st, int parts, long long part_stride,
+                                const int *step_ptr, long long step_stride) {
     const int gx = (int)std::min<long long>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(copy_kernel, dim3(gx, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, n, parts, part_stride);
+    hipLaunchKernelGGL(copy_kernel, dim3(gx, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, n, parts, part_stride,
+                       step_ptr, step_stride);
     return hipGetLastError();
 }
 

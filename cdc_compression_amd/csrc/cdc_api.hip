@@ -76,6 +76,7 @@ struct Op {
     DdimArgs ddim;
     struct { const float *src; long long src_bs; float *dst; long long dst_bs, n; } cp;
     int cp_parts = 1; long long cp_part_stride = 0;
+    const int *cp_step = nullptr; long long cp_step_stride = 0;   // COPY: source row selected by a device step index
     KvCtxArgs kvc;
     LnConvArgs lnc;
     unsigned short *at_Ws = nullptr;   // CTXF: also emit M' as bf16 planes for lnconv_kernel
@@ -133,6 +134,11 @@ struct cdc_handle {
     std::vector<float> h_time_in;
     float *d_time_steps = nullptr;       // [steps] U-Net time input per sample step
     float *d_shift_tab = nullptr;        // [steps][shift_bs]: time-embedding shifts of every step
+    // hipGraph replay of one DDIM iteration (launch-bound small batches): the step index lives on the device
+    int *d_step = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t gev_in = nullptr, gev_out = nullptr;   // order the caller's stream around the graph stream
+    int graph_key[4] = {0, 0, 0, 0};      // steps, pred_mode, clip, stream-independent program generation
     int time_steps_B = 0;
     // profiling
     bool prof = false;
@@ -993,6 +999,7 @@ void free_program(cdc_handle *h) {
     h->ops.clear();
     h->pre_ops.clear();
     h->op_ms.clear(); h->op_n.clear(); h->op_label.clear(); h->op_flops.clear();
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     h->in_ctx.clear();
     h->dec_outs.clear();
     h->act_bytes = 0;
@@ -1270,7 +1277,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             break;
         case Op::COPY:
             HIP_TRY(h, copy_channels_launch(op.cp.src, op.cp.src_bs, op.cp.dst, op.cp.dst_bs, op.cp.n,
-                                            B, st, op.cp_parts, op.cp_part_stride));
+                                            B, st, op.cp_parts, op.cp_part_stride, op.cp_step, op.cp_step_stride));
             break;
     }
     if (prof) {
@@ -1295,10 +1302,11 @@ int run_pre(cdc_handle *h, hipStream_t st) {
 // step < 0: plain Unet.forward with the caller's per-image time values.
 int run_unet(cdc_handle *h, hipStream_t st, int step) {
     for (const Op &op : h->ops) {
-        if (op.kind == Op::TEMB && step >= 0) {
+        if (op.kind == Op::TEMB && (step >= 0 || step == -2)) {
             Op c = op;
             c.kind = Op::COPY;
-            c.cp = {h->d_shift_tab + (size_t)step * h->shift_bs, 0, h->shift, h->shift_bs, h->shift_bs};
+            c.cp = {h->d_shift_tab + (step >= 0 ? (size_t)step * h->shift_bs : 0), 0, h->shift, h->shift_bs, h->shift_bs};
+            if (step == -2) { c.cp_step = h->d_step; c.cp_step_stride = h->shift_bs; }
             int rc = run_op(h, c, h->pB, st);
             if (rc) return rc;
             continue;
@@ -1415,6 +1423,9 @@ void cdc_destroy(cdc_handle *h) {
     if (h->d_tab) (void)hipFree(h->d_tab);
     (void)resolve_pending(h);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
+    if (h->gev_in) (void)hipEventDestroy(h->gev_in);
+    if (h->gev_out) (void)hipEventDestroy(h->gev_out);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1916,8 +1927,8 @@ static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *
     if ((rc = run_unet(h, st, i))) return rc;
     Op op;
     op.kind = Op::DDIM; op.prof = PC_SMALL;
-    op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i,
-               pred_mode, clip, eta, (long long)n};
+    op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i < 0 ? 0 : i,
+               i == -2 ? h->d_step : nullptr, pred_mode, clip, eta, (long long)n};
     op.bytes = 16.0 * n;
     return run_op(h, op, B, st);
 }
@@ -1968,7 +1979,53 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     h->prof_now = false;
     if ((rc = run_pre(h, st))) return rc;       // hoisted context halves: once per decode
     // for i in reversed(range(steps)): img = ddim(img, i)      (x: :188-200 ; eps: :174-190)
-    for (int i = h->steps - 1; i >= 0; --i) {
+    // Optional (CDC_GRAPH=1): replay one captured DDIM iteration as a hipGraph; the step index lives in device memory
+    // and is decremented by the graph's last node.  Measured (tools/gpu_graph_latency.py): bit-identical, and NO
+    // faster -- 5.8 ms / iteration at batch 1 either way: the ~170 kernels of an iteration are bound by their own
+    // serial latency (tiny grids), not by host launches -- so the eager loop stays the default.
+    const char *genv = getenv("CDC_GRAPH");           // 0 / 1 overrides the batch-size rule
+    const bool use_graph = !h->prof && h->steps > 2 && genv && atoi(genv) != 0;
+    int i = h->steps - 1;
+    if (use_graph) {
+        // the legacy default stream cannot be captured: iterate on the library's own stream, fenced by events
+        hipStream_t cs = st;
+        if (!h->gev_in) { HIP_TRY(h, hipEventCreateWithFlags(&h->gev_in, hipEventDisableTiming));
+                          HIP_TRY(h, hipEventCreateWithFlags(&h->gev_out, hipEventDisableTiming)); }
+        if (st != h->own_stream) {
+            HIP_TRY(h, hipEventRecord(h->gev_in, cs));
+            st = h->own_stream;
+            HIP_TRY(h, hipStreamWaitEvent(st, h->gev_in, 0));
+        }
+        if (!h->d_step) { void *p = nullptr; HIP_TRY(h, hipMalloc(&p, sizeof(int))); h->d_step = (int *)p; h->weight_allocs.push_back(p); }
+        // first iteration eagerly (kernel attributes, code pages), then capture the second and replay it
+        if ((rc = ddim_on_device(h, h->in_x, i, nullptr, 0.f, h->in_x, B, H, W, pred_mode, clip, st))) return rc;
+        --i;
+        const int key[4] = {h->steps, pred_mode, clip, 1};
+        if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key)) {
+            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            rc = ddim_on_device(h, h->in_x, -2, nullptr, 0.f, h->in_x, B, H, W, pred_mode, clip, st);
+            hipError_t e = rc ? hipSuccess : step_dec_launch(h->d_step, st);
+            hipError_t e2 = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess || e2 != hipSuccess || !g)
+                return fail(h, CDC_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+            e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { h->graph_exec = nullptr; return fail(h, CDC_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+            memcpy(h->graph_key, key, sizeof key);
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_step, &i, sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipStreamSynchronize(st));      // `i` is a stack variable
+        for (; i >= 0; --i) HIP_TRY(h, hipGraphLaunch(h->graph_exec, st));
+        if (st != cs) {
+            HIP_TRY(h, hipEventRecord(h->gev_out, st));
+            HIP_TRY(h, hipStreamWaitEvent(cs, h->gev_out, 0));
+            st = cs;
+        }
+    }
+    for (; i >= 0; --i) {
         h->prof_now = (i % h->prof_every) == 0;
         if ((rc = ddim_on_device(h, h->in_x, i, nullptr, 0.f, h->in_x, B, H, W, pred_mode, clip, st)))
             return rc;

@@ -124,13 +124,16 @@ struct DdimArgs {
     const float *tab;   // device table [5][steps]: sqrt_recip, sqrt_recipm1, sqrt_ac_prev,
                         //                          one_minus_ac_prev, sigma
     int steps, i;
+    const int *step_ptr;   // non-null: the step index is read from device memory (hipGraph replay)
     int pred_mode, clip;
     float eta;
     long long n;
 };
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
-                                long long n, int B, hipStream_t st, int parts = 1, long long part_stride = 0);
+                                long long n, int B, hipStream_t st, int parts = 1, long long part_stride = 0,
+                                const int *step_ptr = nullptr, long long step_stride = 0);
+hipError_t step_dec_launch(int *step, hipStream_t st);
 hipError_t bpp_launch(const float *qh, long long nh, int hw_h, const float *prior, const float *ql, const float *mean,
                       const float *scale, long long nl, float inv_hw, float *bpp, int B, hipStream_t st);
 hipError_t clamp_min_launch(float *x, long long bs, long long n, float lo, int B, hipStream_t st);

@@ -505,3 +505,20 @@ def test_kodak_crops_eps_1000_steps_match_reference():
     out = comp(x)
     assert np.abs(out["bpp"] - g["bpp"]).max() <= 1e-5 * float(np.abs(g["bpp"]).max())
     assert int((np.abs(out["q_latent"] - g["q_latent"]) > 0.5).sum()) <= 20
+
+
+def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
+    """Small batches replay one captured DDIM iteration as a hipGraph (device-side step index): same kernels,
+    same order -> the same bits as the eager loop."""
+    un, kw, sd, x, time, ctx, g = make_unet("full_x")
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    shape = x.shape
+    init = synth.normal("init", shape, seed=1, std=0.8)
+    monkeypatch.setenv("CDC_GRAPH", "0")
+    eager = diff.decompress(ctx, shape, sample_steps=7, init=init)
+    monkeypatch.setenv("CDC_GRAPH", "1")
+    a = diff.decompress(ctx, shape, sample_steps=7, init=init)
+    b = diff.decompress(ctx, shape, sample_steps=5, init=init)      # new schedule -> new capture
+    monkeypatch.setenv("CDC_GRAPH", "0")
+    np.testing.assert_array_equal(a, eager)
+    np.testing.assert_array_equal(b, diff.decompress(ctx, shape, sample_steps=5, init=init))
