@@ -922,7 +922,7 @@ struct Builder {
         nsplit = std::min(nsplit, std::max(1, N / 64));
         if (fused) {        // >= 2.6 rounds of 3 workgroups per CU (C = 64) / 4 rounds of one (C = 128)
             static const int kv64 = getenv("CDC_KV64_WGS") ? atoi(getenv("CDC_KV64_WGS")) : 2048;
-            nsplit = C == 64 ? ceil_div(kv64, B) : ceil_div(1024, B);
+            nsplit = std::min(128, C == 64 ? ceil_div(kv64, B) : ceil_div(1024, B));   // (the fold sums the splits serially)
             while (nsplit > 1 && N % (32 * nsplit)) --nsplit;
         }
         float *kmaxs = fused ? dalloc((size_t)B * nsplit * C) : nullptr;   // per-split row maxima
