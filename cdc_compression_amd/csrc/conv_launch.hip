@@ -228,6 +228,7 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                 if (MB * NPW > 8 || MB > 6) continue;
                 if (NPW > 1 && NPW > nb_rows) continue;
                 if (f_npw && NPW != f_npw) continue;
+                if (s.KH == 7 && s.KW == 1 && getenv("CDC_71_NPW") && NPW != atoi(getenv("CDC_71_NPW"))) continue;
                 ConvPlan p;
                 p.split = 0;
                 if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
