@@ -555,6 +555,8 @@ void free_pool(std::vector<void *> *pool) {
 // ------------------------------------------------------------------------------------------------
 // program construction
 // ------------------------------------------------------------------------------------------------
+static int ks_target() { static const int v = getenv("CDC_KS_TARGET") ? atoi(getenv("CDC_KS_TARGET")) : 1024; return v; }
+
 struct Builder {
     cdc_handle *h;
     int B;
@@ -670,7 +672,7 @@ struct Builder {
             // >= 4 workgroups per CU; the LayerNorm kernel that follows adds the slices
             const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
                                   plan.groups * w.nz;
-            int ks = (int)std::min<long long>(ceil_div(1024, wgs), std::min(o.max_ksplit, plan.nchunk / 4));
+            int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(o.max_ksplit, plan.nchunk / 4));
             if (ks > 1) { plan.ksplit = ks; last_ksplit = ks; }
         }
         // Plain (linear) epilogues at the few-workgroup levels -- the attention projections and res_convs
@@ -681,7 +683,7 @@ struct Builder {
             !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed && !getenv("CDC_NO_KSPLIT")) {
             const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
                                   plan.groups;
-            const int ks = (int)std::min<long long>(ceil_div(1024, wgs), std::min(4, plan.nchunk / 4));
+            const int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(4, plan.nchunk / 4));
             if (ks > 1 && (size_t)B * dense_bs * 4 * ks <= (64u << 20)) {
                 plan.ksplit = ks;
                 ks_scratch = dalloc((size_t)ks * B * dense_bs);
