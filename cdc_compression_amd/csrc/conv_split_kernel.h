@@ -536,9 +536,8 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats) + a_lane;
             int ky = (g1 * TG) / P.KW, kx = g1 * TG - ky * P.KW;        // uniform tap walk (SALU)
             const int zoff = NZ == 4 ? (zz >> 1) * PW + (zz & 1) : 0;   // phase (py, px): window shifted by (py, px)
-#ifdef CDC_AB_PRIO
-            __builtin_amdgcn_s_setprio(CDC_AB_PRIO);
-#endif
+            __builtin_amdgcn_s_setprio(3);      // waves inside the tap loop win issue arbitration over waves that are
+                                                // converting / in an epilogue (+1 % measured, whole model)
             for (int t = 0; t < TG; ++t) {
                 const uint4 *xb = reinterpret_cast<const uint4 *>(xc) + zoff +
                                   (ky * PW + (s2 ? ((kx + xs) & 1) * (PW / 2) + ((kx + xs) >> 1) : kx));
@@ -570,9 +569,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
 #endif
                 }
             }
-#ifdef CDC_AB_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
             TL();
             dma_wait();
             TL();
