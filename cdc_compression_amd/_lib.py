@@ -77,6 +77,8 @@ def lib():
     L.cdc_last_error.argtypes = [H]
     L.cdc_last_error.restype = ctypes.c_char_p
     L.cdc_version.restype = ctypes.c_char_p
+    L.cdc_set_arith.argtypes = [H, _i]
+    L.cdc_get_arith.argtypes = [H]
     L.cdc_num_tensors.argtypes = [H]
     L.cdc_tensor_info.argtypes = [H, _i, ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_i)]
@@ -117,7 +119,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
-           "cdc_encoder_encode"]
+           "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith"]
 
 
 def check(handle, rc):

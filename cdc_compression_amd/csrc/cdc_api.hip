@@ -44,6 +44,8 @@ struct ConvW {                    // packed convolution weights (device)
     long long w_zs = 0, w_bs = 0;
     unsigned short *wsp = nullptr;   // three-plane bf16 form for conv_split_kernel (k x k, Cin >= 16)
     long long wsp_zs = 0;
+    unsigned short *wsh = nullptr;   // fp16 planes {WH, WL, WH2} of w * 2^s (conv_split2_kernel AR = 1), same layout
+    float wscale_inv = 1.f;          // 2^-s
 };
 
 struct Act { float *p = nullptr; int C = 0, H = 0, W = 0;
@@ -86,6 +88,11 @@ struct Op {
 
 }  // namespace
 
+static int default_arith() {      // CDC_ARITH=0 selects the three-plane bf16 arithmetic for new handles
+    const char *e = getenv("CDC_ARITH");
+    return e ? (atoi(e) ? 1 : 0) : 1;
+}
+
 struct cdc_handle {
     cdc_unet_config cfg;
     int kind = 0;                 // 0: denoising U-Net, 1: context decoder (Compressor.decode), 2: hyper decoder,
@@ -99,6 +106,7 @@ struct cdc_handle {
     int up_index = 1;
     std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
     int device = 0;
+    int arith = default_arith();  // k x k / wide 1x1 convolutions: 1 two fp16 planes (3 MFMA products), 0 three bf16 planes (6)
     std::string err;
     hipStream_t own_stream = nullptr;
     // architecture (unet.py:33-35)
@@ -378,6 +386,36 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int CoutF, int C
             return rc;
         cw->wsp = reinterpret_cast<unsigned short *>(dsp);
         cw->wsp_zs = (long long)per_z;
+        // fp16 planes of w * 2^s, max |w| 2^s in [2^13, 2^14): WH = fp16(w 2^s), WL = fp16(w 2^s - WH), WH2 = WH 2^-11
+        // (exact: a power-of-two scale of a normal fp16; |WH| < 2^-3 may round -- 17 binades below the layer's
+        // largest weight).  See conv_split_kernel.h (AR = 1).
+        float wmax = 0.f;
+        for (float v : packed) wmax = std::max(wmax, fabsf(v));
+        int sexp = 0;
+        if (wmax > 0.f && std::isfinite(wmax)) { int e; frexpf(wmax, &e); sexp = 14 - e; }   // wmax = m 2^e, m in [.5, 1)
+        sexp = std::max(-100, std::min(100, sexp));
+        const float scl = ldexpf(1.f, sexp);
+        std::vector<unsigned short> sh(per_z * cw->nz, 0);
+        auto f16bits = [](float f) { const _Float16 hf = (_Float16)f; unsigned short u; memcpy(&u, &hf, 2); return u; };
+        for (int z = 0; z < cw->nz; ++z)
+            for (int t = 0; t < taps; ++t)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int co = 0; co < Cout; ++co) {
+                        const float v = packed[(size_t)z * (size_t)taps * cw->Cin_pad * cw->COP +
+                                               ((size_t)t * cw->Cin_pad + ci) * cw->COP + co] * scl;
+                        const _Float16 wh = (_Float16)v;
+                        const float wl = v - (float)wh;
+                        const unsigned short parts[3] = {f16bits((float)wh), f16bits(wl), f16bits((float)wh * (1.0f / 2048.0f))};
+                        const int c16 = ci >> 4, kg = (ci >> 3) & 1, q = ci & 7;
+                        for (int pl = 0; pl < 3; ++pl)
+                            sh[(size_t)z * per_z +
+                               ((((size_t)t * nc16 + c16) * 6 + pl * 2 + kg) * cw->COP + co) * 8 + q] = parts[pl];
+                    }
+        float *dsh = nullptr;
+        if ((rc = upload(h, reinterpret_cast<const float *>(sh.data()), (sh.size() + 1) / 2, &dsh, pool)))
+            return rc;
+        cw->wsh = reinterpret_cast<unsigned short *>(dsh);
+        cw->wscale_inv = ldexpf(1.f, -sexp);
     }
     cw->bias = nullptr;
     if (bias) rc = upload(h, bias + co0, Cout, &cw->bias, pool);
@@ -572,7 +610,7 @@ struct Builder {
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? " SPLIT2" : (op.plan.split ? " SPLIT" : ""),
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? " SPLIT2H" : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)
@@ -647,6 +685,7 @@ struct Builder {
         s.C0 = s1 ? C0 : 0;
         s.Win = W; s.nz = w.nz;
         s.allow_split = w.wsp != nullptr;
+        s.arith = (h->arith == 1 && w.wsh) ? 1 : 0;
         for (int z = 0; z < 4; ++z) s.pad_x[z] = w.transposed ? (w.tk == 5 ? 1 : 1 - (z & 1)) : pad_x;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
@@ -705,6 +744,8 @@ struct Builder {
         a.ln_mean = o.pre_mean; a.ln_rstd = o.pre_rstd; a.ln_g = o.pre_g; a.ln_b = o.pre_b;
         a.wp = w.wp; a.w_bs = o.w_bs; a.w_zs = w.w_zs;
         a.wsp = w.wsp; a.wsp_zs = w.wsp_zs;
+        a.acc_scale = 1.f;
+        if (plan.split == 2 && plan.arith == 1) { a.wsp = w.wsh; a.acc_scale = w.wscale_inv; }
         a.KH = w.KH; a.KW = w.KW; a.stride = w.stride;
         a.Cin_pad = w.Cin_pad; a.COP = w.COP; a.Cout = w.Cout;
         a.out = out; a.out_bs = out_bs;
@@ -1433,6 +1474,19 @@ void cdc_destroy(cdc_handle *h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
+
+int cdc_set_arith(cdc_handle *h, int mode) {
+    if (!h) return CDC_ERR_INVALID;
+    if (mode != CDC_ARITH_BF16X3 && mode != CDC_ARITH_F16X2) return fail(h, CDC_ERR_INVALID, "arith mode %d", mode);
+    if (mode != h->arith) {
+        if (h->own_stream) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+        free_program(h);          // launch plans and LDS carve-up depend on the operand format
+        h->arith = mode;
+    }
+    return CDC_OK;
+}
+
+int cdc_get_arith(const cdc_handle *h) { return h ? h->arith : CDC_ERR_INVALID; }
 
 int cdc_num_tensors(const cdc_handle *h) {
     if (!h) return CDC_ERR_INVALID;

@@ -19,6 +19,7 @@ conv_kernel_fn conv_lookup_abl(int MB, int NPW, int abl);    // tuning aid (CDC_
 conv_kernel_fn conv_lookup_split(int MB, int NPW);           // conv_split_kernel.h
 conv_kernel_fn conv_lookup_split_abl(int MB, int NPW, int abl);
 conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);
+conv_kernel_fn conv_lookup_split2h(int MB, int NPW, int lnmode, int xu = 1);   // AR = 1: two fp16 planes
 conv_kernel_fn conv_lookup_split2_t4(int MB);     // ConvTranspose2d(4,2,1): all four phases per workgroup   // register-staged variant, 2 WGs/CU
 
 struct ConvShape {
@@ -27,6 +28,7 @@ struct ConvShape {
     int Win = 0;         // input width and per-phase x padding: 16-byte input pieces need Win % 4 == 0
     int nz = 1, pad_x[4] = {0, 0, 0, 0};
     bool allow_split = false;   // split-bf16 weights exist for this layer
+    int arith = 0;              // 1: the layer's split weights are the fp16 planes (conv_split2_kernel AR = 1 only)
     int Ho, Wo;          // output extent (per phase for ConvTranspose)
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel

@@ -32,6 +32,9 @@ struct ConvArgs {
     // split-bf16 form (conv_split_kernel.h): [z][tap][Cin_pad/16][plane 3][k-half 2][COP][8] bf16
     const unsigned short *wsp;
     long long wsp_zs;
+    // arith 1 (conv_split2_kernel AR = 1): wsp holds the fp16 planes {WH, WL, WH2} of w * 2^s in the same
+    // layout and the epilogue multiplies the accumulators by acc_scale = 2^-s (1 otherwise)
+    float acc_scale;
     int tg;                         // taps per LDS weight stage (conv_split2_kernel)
     int ipw, B;                     // images per workgroup (small feature maps), batch size
     int KH, KW, stride;
@@ -92,6 +95,7 @@ struct ConvPlan {
     int ksplit = 1;         // K slices (split2 only)
     int xu = 1;             // patch units per thread (split2 only)
     int t4 = 0;             // transposed convolution with all four phases per workgroup
+    int arith = 0;          // split2 only: 0 three bf16 planes (6 MFMA products), 1 two fp16 planes (3 products)
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 

@@ -113,8 +113,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
         for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if constexpr (LNMODE == 2) acc[m][n][r] *= prstd[n];
-                acc[m][n][r] += epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+                const float sc = LNMODE == 2 ? prstd[n] * P.acc_scale : P.acc_scale;
+                acc[m][n][r] = acc[m][n][r] * sc + epl[m * 32 + (r & 3) + 8 * (r >> 2)];
             }
         const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
         if (P.pre_add) {

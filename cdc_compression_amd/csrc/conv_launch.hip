@@ -106,6 +106,9 @@ static int kernel_vgprs(conv_kernel_fn f) {
 // Split-bf16 kernel: 16-channel chunks, one workgroup per CU; LDS = split patch (96 B/position) +
 // fp32 landing area (64 B/position) + two weight-row stages.
 static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *p, bool allow_ipw = true) {
+    const int ar = s.arith;                          // 1: two fp16 planes (register-staged variant only)
+    const int xpl = ar ? 16 : 24;                    // floats of split patch per position
+    auto lookup2 = [&](int mb, int npw, int ln, int xu) { return ar ? conv_lookup_split2h(mb, npw, ln, xu) : conv_lookup_split2(mb, npw, ln, xu); };
     const int nblocks = ceil_div(s.Cout, 32);
     if (nblocks % MB) return false;
     const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
@@ -128,13 +131,13 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // variant 2 (patch staged through registers, two workgroups per CU) when it fits
     // weight stages of one kernel row if that fits next to a second workgroup, else one tap each
     int tg = s.KW;
-    const size_t lds_tap = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * 24 * COPT);
-    size_t lds2 = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * tg * 24 * COPT);
+    const size_t lds_tap = sizeof(float) * ((size_t)ipw * xpl * plane + (size_t)2 * 24 * COPT);
+    size_t lds2 = sizeof(float) * ((size_t)ipw * xpl * plane + (size_t)2 * tg * 24 * COPT);
     if (lds2 > 80 * 1024) { tg = 1; lds2 = lds_tap; }
     // a third workgroup per CU (+12 % measured on 64->64 @256^2) when single-tap stages bring the LDS
     // footprint under 160/3 KiB and the kernel's registers allow three waves per SIMD
     if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !getenv("CDC_NO_TG1"))
-        if (conv_kernel_fn f = conv_lookup_split2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
+        if (conv_kernel_fn f = lookup2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
             if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
     // Few workgroups (low-resolution levels): the chip cannot hide the weight-stage latency by occupancy,
     // so stage ALL taps of a chunk at once -- one barrier and one DMA wait per 16 channels, and the DMA of
@@ -143,16 +146,17 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
         const int taps = s.KH * s.KW;
         const long long wgs = (long long)(ipw > 1 ? ceil_div(s.B, ipw) : ceil_div(s.Wo, NBW) * ceil_div(s.Ho, TH) * s.B) *
                               (nblocks / MB) * s.nz;
-        const size_t lds_all = sizeof(float) * ((size_t)ipw * 24 * plane + (size_t)2 * taps * 24 * COPT);
+        const size_t lds_all = sizeof(float) * ((size_t)ipw * xpl * plane + (size_t)2 * taps * 24 * COPT);
         static const char *force = getenv("CDC_TGALL");
         const bool few = wgs <= 3 * 256 && lds_all <= 72 * 1024;
         if (taps > tg && ((force && atoi(force) && lds_all <= 150 * 1024) || (!force && few))) { tg = taps; lds2 = lds_all; }
     }
     // patch units per thread: stride 2 always runs the two-unit / parity-plane variant
     const int xu = s.stride == 2 ? 2 : 1;
-    const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && conv_lookup_split2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
+    const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && lookup2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
                     (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && getenv("CDC_XU2_SMALL"))) && !getenv("CDC_NO_XU2"))) && !getenv("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
+    if (!v2 && ar) { ConvShape s0 = s; s0.arith = 0; return try_plan_split(s0, MB, NPW, lognbw, p, allow_ipw); }
     if (!v2 && (s.lnmode != 0 || !conv_lookup_split(MB, NPW) || 4 * plane > kXS * nthr)) return false;
     const size_t lds = v2 ? lds2 : sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);
     if (lds > 160 * 1024) return false;
@@ -172,6 +176,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->tg = v2 ? tg : s.KW;
     p->ipw = ipw;
     p->xu = v2 ? xu : 1;
+    p->arith = v2 ? ar : 0;
     return true;
 }
 
@@ -290,7 +295,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
-    conv_kernel_fn fn = p.t4 ? conv_lookup_split2_t4(p.MB) : p.split == 2 ? conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu)
+    conv_kernel_fn fn = p.t4 ? conv_lookup_split2_t4(p.MB) : p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
     if (ablate && p.split == 1)
         if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;

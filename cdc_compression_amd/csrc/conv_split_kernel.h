@@ -19,6 +19,24 @@
 namespace cdc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// ---- AR = 1: two-plane fp16 operands -----------------------------------------------------------------
+// a = h + l' * 2^-11 with h = fp16(a) (round to nearest) and l' = fp16((a - h) * 2^11): the residual is
+// scaled back into h's binade, so it is a NORMAL fp16 number wherever h is (no subnormal loss for small
+// activations) and the pair carries 22-23 significant bits for 6e-5 <= |a| < 65504 (absolute error
+// <= 1.5e-11 below that).  The weights come pre-scaled by a per-layer power of two 2^s (max |w| 2^s in
+// [2^13, 2^14)) as three planes WH = fp16(w 2^s), WL = fp16(w 2^s - WH), WH2 = WH 2^-11 (exact), and
+//      a * w 2^s = h WH + h WL + l' WH2  + O(2^-22 |a w 2^s|)
+// is three v_mfma_f32_32x32x16_f16 per 16-deep K step (fp16 x fp16 products are exact in the fp32
+// accumulator); the epilogue multiplies the accumulators by 2^-s (exact).  |a| >= 65504 becomes inf / NaN
+// and propagates to the output, where the sampler kernels flag it (the caller then re-runs the exact
+// three-plane bf16 arithmetic, AR = 0).
+__device__ __forceinline__ void split2h(float a, _Float16 &h, _Float16 &l) {
+    h = (_Float16)a;
+    l = (_Float16)((a - (float)h) * 2048.0f);
+}
 
 // a -> (hi, mid, lo) as fp32 bit patterns whose low 16 bits are zero; exact: a == hi + mid + lo
 __device__ __forceinline__ void split3(float a, unsigned &h, unsigned &m, unsigned &l) {
@@ -237,7 +255,7 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 // LNMODE 2 (1x1 only): PreNorm LayerNorm folded as in conv_kernel.h -- the pixel mean is subtracted before
 // the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
 // three workgroups per CU wherever the accumulators leave room (<= 168 VGPRs)
-constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int NZ = 1) {
+constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int NZ = 1, int AR = 0) {
     if (XU > 1 || NZ > 1) return 2;
     return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (LNMODE == 2 && (MB * NPW == 3 || (MB == 4 && NPW == 1))))) ? 3 : 2;
 }
@@ -249,8 +267,9 @@ constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int NZ = 1
 // (TH+2) x (NBW+2) input patch (a pad-1 3x3 window), so it is fetched and split once instead of four times,
 // a chunk carries 16 (phase, tap) stages instead of 4, and a lane ends up holding out[2y+py][2x], out[..][2x+1]
 // which go out as 8-byte stores (full lines) instead of two interleaved 4-byte-strided writes.
-template <int MB, int NPW, int LNMODE = 0, int XU = 1, int NZ = 1>
-__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) conv_split2_kernel(const ConvArgs P) {
+template <int MB, int NPW, int LNMODE = 0, int XU = 1, int NZ = 1, int AR = 0>
+__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, AR)) conv_split2_kernel(const ConvArgs P) {
+    constexpr int NP = AR == 1 ? 2 : 3;               // B-operand (activation) planes
     static_assert(XU == 1 || LNMODE == 0, "two-unit variant carries no LayerNorm-on-load");
     static_assert(NZ == 1 || (NZ == 4 && XU == 1 && LNMODE == 0), "all-phase variant: plain transposed convolution");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -306,7 +325,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
     const int TG = P.tg;                              // taps per weight stage (a kernel row, or 1)
     const int ntg1 = (P.KH * P.KW) / TG;              // stages per phase
     const int ntg = NZ * ntg1;                        // stages per chunk (NZ = 4: phase-major)
-    const int xc_floats = 24 * plane, wst_floats = TG * 24 * COPT;
+    const int xc_floats = NP * 8 * plane, wst_floats = TG * 24 * COPT;
     float *xc = smem + (ipw > 1 ? (wave / wpi) * xc_floats : 0);     // one split patch per image
     float *wl = smem + ipw * xc_floats;
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
@@ -398,6 +417,22 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    const int pos = urc[u] + (t & 1) * ustep1 + (t >> 1) * ustep2;
+                    if constexpr (AR == 1) {
+                        f16x8 vh, vl;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            float v = t == 0 ? xr[u][q].x : (t == 1 ? xr[u][q].y : (t == 2 ? xr[u][q].z : xr[u][q].w));
+                            if constexpr (LNMODE == 2) v -= umean[t];
+                            if constexpr (LNMODE == 1) v = xsp[u] >= 0 ? (v - umean[t]) * urstd[t] * lg[q] + lb[q] : 0.f;
+                            _Float16 hq, lq;
+                            split2h(v, hq, lq);
+                            vh[q] = hq; vl[q] = lq;
+                        }
+                        dst[(0 * 2 + ukg[u]) * plane + pos] = __builtin_bit_cast(uint4, vh);
+                        dst[(1 * 2 + ukg[u]) * plane + pos] = __builtin_bit_cast(uint4, vl);
+                        continue;
+                    }
                     unsigned hh[8], mm[8], ll[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -413,7 +448,6 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
                     vm.z = (mm[4] >> 16) | mm[5]; vm.w = (mm[6] >> 16) | mm[7];
                     vl.x = (ll[0] >> 16) | (ll[1] & 0xFFFF0000u); vl.y = (ll[2] >> 16) | (ll[3] & 0xFFFF0000u);
                     vl.z = (ll[4] >> 16) | (ll[5] & 0xFFFF0000u); vl.w = (ll[6] >> 16) | (ll[7] & 0xFFFF0000u);
-                    const int pos = urc[u] + (t & 1) * ustep1 + (t >> 1) * ustep2;
                     dst[(0 * 2 + ukg[u]) * plane + pos] = vh;
                     dst[(1 * 2 + ukg[u]) * plane + pos] = vm;
                     dst[(2 * 2 + ukg[u]) * plane + pos] = vl;
@@ -494,9 +528,9 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
     const int b_lane = half * plane + (rb * NPW * NBH + pr) * P.stride * PW + (s2 ? pc : pc + xs);
     const int nb_stride = NBH * P.stride * PW;
     const int a_lane = half * COPT + j;
-    int bidx[3][NPW];                                 // B-operand unit index of tap (0,0), per plane / block
+    int bidx[NP][NPW];                                // B-operand unit index of tap (0,0), per plane / block
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             bidx[p][n] = (p * 2) * plane + b_lane + n * nb_stride;
@@ -544,6 +578,29 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
                 if (++kx == P.KW) { kx = 0; ++ky; }
                 // B planes stay live for the tap; the A planes are fetched one at a time, smallest
                 // first: plane 2 feeds one product term, plane 1 two, plane 0 three (six in all)
+                if constexpr (AR == 1) {
+                    // planes: B = {h, l'}, A = {WH, WL, WH2}; terms smallest first: WL.h, WH2.l', WH.h
+                    f16x8 Bh[2][NPW];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n) Bh[p][n] = __builtin_bit_cast(f16x8, xb[bidx[p][n]]);
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+                        constexpr int PA[3] = {1, 2, 0};
+                        constexpr int PB[3] = {0, 1, 0};
+                        f16x8 Ah[MB];
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+                            Ah[m] = __builtin_bit_cast(f16x8, wa[(t * 6 + PA[term] * 2) * COPT + m * 32]);
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+#pragma unroll
+                            for (int n = 0; n < NPW; ++n)
+                                acc[zz][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m], Bh[PB[term]][n], acc[zz][m][n],
+                                                                                       0, 0, 0);
+                    }
+                } else {
                 bf16x8 Bv[3][NPW];
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
@@ -567,6 +624,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
 #else
                                 acc[zz][m][n][0] += __builtin_bit_cast(float4, A[m]).x * __builtin_bit_cast(float4, Bv[pb][n]).y;
 #endif
+                }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -612,7 +670,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ)) 
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[q][m][n][r] += epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+                    for (int r = 0; r < 16; ++r) acc[q][m][n][r] = acc[q][m][n][r] * P.acc_scale + epl[m * 32 + (r & 3) + 8 * (r >> 2)];
             if (P.stat_mean) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

@@ -63,6 +63,20 @@ void cdc_destroy(cdc_handle *h);
 const char *cdc_last_error(const cdc_handle *h);   /* h may be NULL: last cdc_create error */
 const char *cdc_version(void);
 
+/* ---- arithmetic of the dense contractions ------------------------------------------------------
+ * Tensors are float32 everywhere; the k x k (and wide 1x1) convolutions form their fp32 products on the
+ * 16-bit matrix cores from split operands (no reference counterpart -- torch delegates to oneDNN / cuDNN fp32):
+ *   CDC_ARITH_F16X2 (default)  a = h + l*2^-11 as two fp16 numbers, w*2^s as {WH, WL}: three
+ *                              v_mfma_f32_32x32x16_f16 per product block, error <= 3 fp32 ulp per product,
+ *                              activations must satisfy |a| < 65504 (else the result is NaN, never silently wrong);
+ *   CDC_ARITH_BF16X3           a = a1 + a2 + a3 exactly as three bf16 numbers: six v_mfma_f32_32x32x16_bf16,
+ *                              full fp32 range.
+ * Changing the mode drops the handle's launch program (rebuilt on the next call).  New handles take
+ * CDC_ARITH_F16X2 unless the environment says CDC_ARITH=0. */
+enum { CDC_ARITH_BF16X3 = 0, CDC_ARITH_F16X2 = 1 };
+int cdc_set_arith(cdc_handle *h, int mode);
+int cdc_get_arith(const cdc_handle *h);
+
 /* ---- parameters: replaces nn.Module.load_state_dict on the Unet (test_xparam.py:62-68) ------- */
 
 /* Manifest of the reference Unet.state_dict(): count, then (name, shape) per index. */
