@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CDC_HIP_LIB") or os.path.join(_HERE, "libcdc_hip.so")
 
 CDC_MEM_HOST, CDC_MEM_DEVICE = 0, 1
-CDC_PRED_X, CDC_PRED_NOISE = 0, 1
+CDC_PRED_X, CDC_PRED_NOISE, CDC_PRED_NOISE_XTREE = 0, 1, 2
+CDC_CLIP_NONE, CDC_CLIP_ALL, CDC_CLIP_HALF = 0, 1, 2
 CDC_MAX_LEVELS = 8
 
 _f = ctypes.POINTER(ctypes.c_float)
@@ -85,6 +86,7 @@ def lib():
     L.cdc_load_tensor.argtypes = [H, ctypes.c_char_p, _vp, ctypes.POINTER(ctypes.c_int64), _i]
     L.cdc_finalize_weights.argtypes = [H]
     L.cdc_unet_forward.argtypes = [H, _vp, _vp, pp, _i, _vp, _i, _i, _i, _i, _vp]
+    L.cdc_unet_tap.argtypes = [H, ctypes.c_char_p, _vp, ctypes.POINTER(ctypes.c_int64)]
     L.cdc_ctxdec_create.argtypes = [ctypes.POINTER(CtxdecConfig), _i, ctypes.POINTER(H)]
     L.cdc_ctxdec_decode.argtypes = [H, _vp, pp, _i, _i, _i, _i, _i, _vp]
     L.cdc_encoder_create.argtypes = [ctypes.POINTER(EncoderConfig), _i, ctypes.POINTER(H)]
@@ -119,7 +121,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
-           "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith"]
+           "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap"]
 
 
 def check(handle, rc):

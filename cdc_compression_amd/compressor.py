@@ -5,9 +5,9 @@
 `decode(q_latent)` (compress_modules.py:68-74) -- the synthesis transform that turns the transmitted latents
 into the context pyramid of the denoising U-Net -- is SURVEY section 8f row 1; `encode(images)` / `forward(images)`
 (analysis transform + hyper encoder + quantisers, :43-66, :92-103) are row 3, so that a whole
-`GaussianDiffusion.compress()` runs on the GPU with no reference module in the loop.  `load_state_dict` accepts the reference compressor's full state_dict and takes its
-`dec.*` (and, when present, `hyper_dec.*`) entries; `encode` / `bpp` / `forward` (analysis transform,
-hyper encoder, rate estimate) raise NotImplementedError: the reference module stays in charge of those.
+`GaussianDiffusion.compress()` runs on the GPU with no reference module in the loop.  `load_state_dict` accepts the
+reference compressor's full state_dict: `dec.*` is mandatory, `hyper_dec.*` / `prior.*` / `enc.*` / `hyper_enc.*`
+are taken when present (each enables the corresponding entry points: `hyper_decode` + `bpp`, `encode` + `forward`).
 
 Decode side of the hyperprior: `hyper_decode(q_hyper_latent)` runs
 `hyper_dec` (compress_modules.py:54-59) and returns `(mean, scale.clamp(min=0.1))`; `dequantize(x, offset)`
@@ -52,6 +52,7 @@ class _ContextDecoder:
         self._eh = None
         self._enc_finalized = False
         self.reversed_hyper_dims = None
+        self._full_sd = None          # host copy of every entry load_state_dict() used (replayed by .to())
 
     # ---- handle management ----------------------------------------------------------------
     def _handle(self):
@@ -91,12 +92,16 @@ class _ContextDecoder:
             idx = int(device.split(":")[1]) if ":" in device else 0
         idx = 0 if idx is None else int(idx)
         if idx != self.device_index:
-            # the handles are bound to a device: drop them (parameters must be loaded again on the new one)
+            # the handles are bound to a device: drop them and replay the parameters on the new one
             for attr in ("_h", "_hh", "_eh"):
                 if getattr(self, attr) is not None:
                     _lib.lib().cdc_destroy(getattr(self, attr))
                     setattr(self, attr, None)
             self._finalized = self._hyper_finalized = self._enc_finalized = self._prior_loaded = False
+            self.device_index = idx
+            if self._full_sd:
+                full, self._sd = self._full_sd, {}
+                self.load_state_dict(full, strict=False)
         self.device_index = idx
         return self
 
@@ -127,6 +132,8 @@ class _ContextDecoder:
         """Takes the `dec.*` entries; the encoder / hyperprior entries of a full reference state_dict are
         not this module's.  strict: every `dec.*` key must match the manifest."""
         h = self._handle()
+        self._full_sd = {k: _as_host_f32(v).copy() for k, v in state_dict.items()
+                         if k.split(".")[0] in ("dec", "hyper_dec", "enc", "hyper_enc", "prior")}
         names = [n for n, _ in self.manifest()]
         missing = [n for n in names if n not in state_dict]
         unexpected = [k for k in state_dict if k.startswith("dec.") and k not in names]
@@ -240,7 +247,8 @@ class _ContextDecoder:
         B, C, hh, wh = aq.shape
         if C != self.reversed_hyper_dims[0]:
             raise _lib.CdcError(f"q_hyper_latent has {C} channels, hyper_dec expects {self.reversed_hyper_dims[0]}")
-        shape = (B, self.reversed_hyper_dims[-1] // 2, hh * 4, wh * 4)
+        up = 2 ** (len(self.reversed_hyper_dims) - 2)       # one stride-2 ConvTranspose2d per hyper_dec layer but the last
+        shape = (B, self.reversed_hyper_dims[-1] // 2, hh * up, wh * up)
         mean, pm, _ = _result_like(q_hyper_latent, shape, self.device_index)
         scale, ps, _ = _result_like(q_hyper_latent, shape, self.device_index)
         _lib.check(h, L.cdc_hyperdec_decode(h, aq.ptr, pm, ps, B, hh, wh, ctypes.c_float(scale_min), aq.mem,
@@ -398,7 +406,7 @@ class BigCompressor(_ContextDecoder):
     """epsilonparam/modules/compress_modules.py:112-185 (decoder half, vbr=False)."""
     _up_index = 2
 
-    def __init__(self, dim=64, dim_mults=(1, 2, 3, 3), hyper_dims_mults=(3, 3, 3), channels=3,
+    def __init__(self, dim=64, dim_mults=(1, 3, 3, 3), hyper_dims_mults=(3, 3, 3), channels=3,
                  out_channels=3, vbr=False, device=0):
         if vbr:
             raise NotImplementedError("vbr=True (VBRCondition scalers) is not on the decode path")

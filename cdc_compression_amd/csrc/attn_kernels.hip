@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "cdc_internal.h"
+#include "conv_kernel.h"     // pf_store_block (PF copy of the attention output)
 
 namespace cdc {
 
@@ -287,7 +288,14 @@ __global__ void __launch_bounds__(64 * CB, 2) lnconv_kernel(const LnConvArgs a) 
         for (int r = 0; r < 16; ++r) {
             const size_t row = (size_t)((r & 3) + 8 * (r >> 2)) * N * 4;
             const float res = *reinterpret_cast<const float *>(xb + row + eoff);
-            *reinterpret_cast<float *>(yb + row + eoff) = acc[r] * rs + bias[r] + res;
+            acc[r] = acc[r] * rs + bias[r] + res;
+            *reinterpret_cast<float *>(yb + row + eoff) = acc[r];
+        }
+        if (a.y_pf) {
+            const int yy = px / a.W, xx = px - yy * a.W;
+            const long long u0 = (long long)b * a.pf_bs + (long long)(yy + 1) * (a.W + 2) + xx + 1 +
+                                 (long long)(wave * 4) * 2 * a.pf_ps;
+            pf_store_block(reinterpret_cast<uint4 *>(a.y_pf), u0, a.pf_ps, kh, acc);
         }
     }
 }

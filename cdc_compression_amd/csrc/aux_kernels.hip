@@ -663,25 +663,31 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
     const float c_1macp = a.tab[3 * a.steps + si];
     const float sig = a.eta * a.tab[4 * a.steps + si];
     float var = c_1macp - sig * sig;
-    if (a.pred_mode == 0) var = fmaxf(var, 0.f);          // x-param .clamp(min=0) (:169)
+    // x-tree (pred_mode 0 "x", 2 "noise"): .clamp(min=0) under the square root (xparam :169); eps-tree: none
+    if (a.pred_mode != 1) var = fmaxf(var, 0.f);
     const float c_eps = sqrtf(var);
+    // clip: 0 none, 1 every image, 2 the first B/2 images only (eps-tree clip_noise "half", eps :142-143)
+    const long long clip_n = a.clip == 1 ? a.n : (a.clip == 2 ? a.clip_half_n : 0);
+    bool bad = false;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n;
          idx += (long long)gridDim.x * blockDim.x) {
         const float fx = a.fx[idx], x = a.x[idx];
+        bad |= !(fabsf(fx) <= 3.0e38f);                    // inf / NaN from the U-Net (fp16-plane range overflow)
         float x0, eps;
         if (a.pred_mode == 0) {
             x0 = fx;
-            if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (idx < clip_n) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
             eps = (c_recip * x - x0) / c_recipm1;
         } else {
             eps = fx;
             x0 = c_recip * x - c_recipm1 * eps;
-            if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (idx < clip_n) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         }
         float xn = c_acp * x0 + c_eps * eps;
         if (a.noise) xn += sig * a.noise[idx];
         a.x_next[idx] = xn;
     }
+    if (bad && a.fault) *a.fault = 1;                      // sticky, read by the host after the decode
 }
 
 // end of a graph-replayed DDIM iteration: the next replay works on step - 1

@@ -63,12 +63,13 @@ struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                float *kvWt = nullptr, *kvb = nullptr; unsigned short *kvWs = nullptr; };   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV, CONVPF, PFPACK } kind;
     int prof = PC_SMALL;
     int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
     char label[96] = {0};
     double flops = 0, bytes = 0;
     ConvArgs conv; ConvPlan plan; int nz = 1;
+    PfArgs pf; PfPlan pfplan;     // CONVPF: pre-split fp16 operands by LDS-DMA (conv_pf_kernel.h)
     LnArgs ln;
     TembArgs temb;
     struct { const float *k, *v; long long bs; int C, N; float *kmax, *ksum, *S, *ctxw;
@@ -84,6 +85,7 @@ struct Op {
     unsigned short *at_Ws = nullptr;   // CTXF: also emit M' as bf16 planes for lnconv_kernel
     const float *at_M = nullptr;  // CTXF after KVCTX: per-split row maxima   // COPY: dst = sum of cp_parts planes of src
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
+    struct { const float *src; long long src_bs; void *dst; long long dst_bs; int C, H, W; } pk;   // PFPACK
 };
 
 }  // namespace
@@ -135,15 +137,21 @@ struct cdc_handle {
     size_t act_bytes = 0;
     float *in_x = nullptr, *in_time = nullptr, *out_fx = nullptr, *shift = nullptr;
     std::vector<Act> in_ctx;
+    std::map<std::string, Act> taps;     // named intermediate activations of the last forward (cdc_unet_tap)
     float *xa = nullptr, *xb = nullptr, *noise_buf = nullptr;     // decode ping-pong
     // schedule
     int steps = 0;
     float *d_tab = nullptr;              // [5][steps]
+    std::vector<float> h_tab;            // host copy of d_tab: an unchanged schedule is not uploaded again
+    size_t tab_cap = 0, trows_cap = 0;   // capacities (floats) of d_tab / d_shift_tab: buffers are reused, not leaked
+    int sched_gen = 0;                   // bumped whenever the device tables change (invalidates the captured graph)
     std::vector<float> h_time_in;
     float *d_time_steps = nullptr;       // [steps] U-Net time input per sample step
     float *d_shift_tab = nullptr;        // [steps][shift_bs]: time-embedding shifts of every step
     // hipGraph replay of one DDIM iteration (launch-bound small batches): the step index lives on the device
     int *d_step = nullptr;
+    int range_faults = 0;                // decodes repeated in bf16x3 arithmetic after an fp16 range overflow
+    int *d_fault = nullptr;              // sticky "non-finite U-Net output" flag written by the sampler kernel
     hipGraphExec_t graph_exec = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;   // order the caller's stream around the graph stream
     int graph_key[4] = {0, 0, 0, 0};      // steps, pred_mode, clip, stream-independent program generation
@@ -606,13 +614,17 @@ struct Builder {
         op.id = (int)h->op_ms.size();
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
-        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv"};
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack"};
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
                      op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? " SPLIT2H" : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
+        else if (op.kind == Op::CONVPF)
+            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d PF%s%s%s", op.pf.KH, op.pf.KW,
+                     op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
+                     op.pfplan.groups, op.pfplan.ring, op.pf.ep_g ? " LN" : "", op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -640,9 +652,44 @@ struct Builder {
         h->act_bytes += bytes;
         return (float *)p;
     }
-    Act new_act(int C, int H, int W) {
+    // ---- PF twins: a second copy of an activation as two fp16 planes with a zero halo (conv_pf_kernel.h),
+    // keyed by the fp32 tensor's address; `valid` once a producer of this program has emitted it.
+    struct PfTwin { void *p = nullptr; int C = 0, H = 0, W = 0; bool valid = false;
+                    long long ps() const { return (long long)(H + 2) * (W + 2); }
+                    long long bs() const { return (long long)(C / 8) * 2 * ps(); } };
+    std::map<const float *, PfTwin> pfmap;
+    // Opt-in (CDC_PF=1): the kernel's main loop is ~20 % faster than the register-staged split kernel, but every
+    // tensor that is also needed in fp32 (residual stream, attention input) is then written twice, and at batch 32
+    // the extra HBM writes cost slightly more than the main loop gains (3.64 vs 3.75 images/s, round 2).
+    bool pf_on() const { const char *e = getenv("CDC_PF"); return h->arith == 1 && e && atoi(e); }
+    PfTwin *twin(const float *p) { auto it = pfmap.find(p); return it == pfmap.end() ? nullptr : &it->second; }
+    void add_twin(const float *p, int C, int H, int W) {
+        if (rc || !p || !pf_on() || (C % 16) || W < 32 || H < 2) return;
+        PfTwin t; t.C = C; t.H = H; t.W = W;
+        const size_t bytes = (size_t)B * t.bs() * 16;
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e == hipSuccess) e = hipMemset(q, 0, bytes);           // the halo is written here and never again
+        if (e != hipSuccess) { rc = fail(h, CDC_ERR_NOMEM, "PF tensor (%zu bytes): %s", bytes, hipGetErrorString(e)); return; }
+        pool->push_back(q);
+        h->act_bytes += bytes;
+        t.p = q;
+        pfmap[p] = t;
+    }
+    // fp32 -> PF for a tensor whose producer cannot emit planes (a caller-supplied input)
+    void pack(const float *p, long long bs) {
+        PfTwin *t = twin(p);
+        if (rc || !t) return;
+        Op op; op.kind = Op::PFPACK; op.prof = PC_SMALL;
+        op.pk = {p, bs, t->p, t->bs(), t->C, t->H, t->W};
+        op.bytes = 8.0 * B * t->C * t->H * t->W;
+        emit(op);
+        t->valid = true;
+    }
+    Act new_act(int C, int H, int W, bool want_twin = true) {
         Act a; a.C = C; a.H = H; a.W = W;
         a.p = dalloc((size_t)B * C * H * W);
+        if (want_twin) add_twin(a.p, C, H, W);
         return a;
     }
 
@@ -661,9 +708,94 @@ struct Builder {
         bool no_bias = false;
         const float *res3_w = nullptr, *res3_x = nullptr; long long res3_bs = 0;   // 3-channel res_conv in the epilogue
         int max_ksplit = 1;                            // > 1: `out` has room for that many partial-sum planes
+        bool emit_pf = false;                          // `out` holds final values: also write its PF twin (if it has one)
+        bool pf_only = false;                          // plan with conv_pf_kernel or return false
+        bool no_f32 = false;                           // PF path only: nobody reads the fp32 copy of `out`
     };
     int last_ksplit = 1;                               // slices the last conv() call really used
     const float *next_res3_w = nullptr, *next_res3_x = nullptr; long long next_res3_bs = 0;   // for the next block()
+
+    // Would a single-source 3x3 / 1x1 layer with fused LayerNorm run on conv_pf_kernel (given a PF input)?
+    bool pf_would_plan(const ConvW &w, int H, int W) {
+        if (!pf_on() || !w.wsh || w.stride != 1 || w.transposed) return false;
+        if (!((w.KH == 3 && w.KW == 3) || (w.KH == 1 && w.KW == 1))) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2) return false;
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = w.KH; ps.KW = w.KW; ps.Ho = H; ps.Wo = W; ps.B = B; ps.need_all_cout = true;
+        PfPlan plan;
+        return (w.Cin % 16) == 0 && pf_make_plan(ps, &plan);
+    }
+
+    // Plans the convolution on conv_pf_kernel when every source has a valid PF twin and the layer is a stride-1
+    // k x k / 1x1 / phase-decomposed transposed convolution with "same" geometry.
+    bool try_pf(const ConvW &w, const float *s0, int C0, const float *s1, int H, int W, float *out, long long out_bs,
+                const ConvOpts &o, bool need_all, int prof, const ConvShape &s) {
+        if (!pf_on() || !w.wsh || w.stride != 1 || o.pre_mean || o.w_bs || o.max_ksplit > 1) return false;
+        PfTwin *t0 = twin(s0), *t1 = s1 ? twin(s1) : nullptr;
+        if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
+        if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
+        if (s1 ? (t0->C != C0 || t0->C + t1->C != w.Cin) : t0->C != w.Cin) return false;
+        static const bool pf_t = getenv("CDC_PF_TRANSPOSED") != nullptr;   // measured slower than the phase-folded split kernel
+        const bool k3 = w.KH == 3 && w.KW == 3 && !w.transposed, k1 = w.KH == 1 && w.KW == 1, k2 = w.transposed && w.tk == 4 && pf_t;
+        if (!(k3 || k1 || k2)) return false;
+        if (!w.transposed && ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2)) return false;
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = w.KH; ps.KW = w.KW; ps.nz = w.nz;
+        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = B; ps.need_all_cout = need_all;
+        PfPlan plan;
+        if (!pf_make_plan(ps, &plan)) return false;
+        Op op;
+        op.kind = Op::CONVPF; op.prof = prof; op.pfplan = plan; op.nz = w.nz;
+        PfArgs &a = op.pf;
+        memset(&a, 0, sizeof a);
+        a.src0 = t0->p; a.src0_bs = t0->bs();
+        if (t1) { a.src1 = t1->p; a.src1_bs = t1->bs(); }
+        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
+        a.w = w.wsh; a.w_zs = w.wsp_zs / 8;            // planes of 8 halfs = one unit
+        a.KH = w.KH; a.KW = w.KW; a.nz = w.nz;
+        a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout;
+        a.acc_scale = w.wscale_inv;
+        a.out = o.no_f32 ? nullptr : out; a.out_bs = out_bs;
+        const int Ht = w.transposed ? 2 * H : s.Ho, Wt = w.transposed ? 2 * W : s.Wo;
+        if (w.transposed) {
+            for (int z = 0; z < 4; ++z) {
+                const int py = z >> 1, px = z & 1;
+                a.pad_y[z] = w.tk == 5 ? 1 : 1 - py; a.pad_x[z] = w.tk == 5 ? 1 : 1 - px;
+                a.out_zoff[z] = py * 2 * W + px;
+            }
+            a.out_cs = (long long)4 * H * W; a.out_ys = 4 * W; a.out_xs = 2;
+        } else {
+            a.pad_y[0] = w.KH / 2; a.pad_x[0] = w.KW / 2;
+            a.out_cs = (long long)s.Ho * s.Wo; a.out_ys = s.Wo; a.out_xs = 1;
+        }
+        a.Ho = s.Ho; a.Wo = s.Wo;
+        PfTwin *to = o.emit_pf ? twin(out) : nullptr;
+        if (to && to->C == w.Cout && to->H == Ht && to->W == Wt && out_bs == (long long)w.Cout * Ht * Wt) {
+            a.out_pf = to->p; a.pf_bs = to->bs(); a.pf_ps = to->ps();
+            if (w.transposed) {
+                a.pf_ys = 2 * (Wt + 2); a.pf_xs = 2;
+                for (int z = 0; z < 4; ++z) a.pf_zoff[z] = ((z >> 1) + 1) * (Wt + 2) + (z & 1) + 1;
+            } else {
+                a.pf_ys = Wt + 2; a.pf_xs = 1; a.pf_zoff[0] = (Wt + 2) + 1;
+            }
+            to->valid = true;
+        } else if (o.no_f32) {
+            a.out = out;                                // nothing else would hold the result
+        }
+        a.bias = o.no_bias ? nullptr : w.bias;
+        a.pre_add = o.pre_add;
+        a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu; a.relu_slope = o.relu_slope;
+        a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
+        a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
+        a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
+        a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
+        const double px = (double)B * s.Ho * s.Wo * w.nz;
+        op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
+        op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
+        last_ksplit = 1;
+        emit(op);
+        return true;
+    }
 
     // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
@@ -693,6 +825,8 @@ struct Builder {
             s.Wo = (W + 2 * pad_x - w.KW) / w.stride + 1;
         }
         s.B = B; s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
+        if (try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
+        if (o.pf_only) return false;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
         if (!getenv("CDC_NO_KSPLIT") && !getenv("CDC_NO_KSPLIT_PLAN"))
@@ -769,6 +903,20 @@ struct Builder {
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.out_ks = (long long)B * out_bs;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
+        if (o.emit_pf && !ks_scratch && plan.ksplit <= 1 && (w.Cout % 32) == 0)
+            if (PfTwin *to = twin(out)) {
+                const int Ht = w.transposed ? 2 * H : s.Ho, Wt = w.transposed ? 2 * W : s.Wo;
+                if (to->C == w.Cout && to->H == Ht && to->W == Wt && out_bs == (long long)w.Cout * Ht * Wt) {
+                    a.out_pf = to->p; a.pf_bs = to->bs(); a.pf_ps = to->ps();
+                    if (w.transposed) {
+                        a.pf_ys = 2 * (Wt + 2); a.pf_xs = 2;
+                        for (int z = 0; z < 4; ++z) a.pf_zoff[z] = ((z >> 1) + 1) * (Wt + 2) + (z & 1) + 1;
+                    } else {
+                        a.pf_ys = Wt + 2; a.pf_xs = 1; a.pf_zoff[0] = (Wt + 2) + 1;
+                    }
+                    to->valid = true;
+                }
+            }
         const double px = (double)B * s.Ho * s.Wo * w.nz;
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
@@ -834,8 +982,9 @@ struct Builder {
     void block(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1,
                int H, int W, Act out, const float *g, const float *b, const float *shift,
                const float *pre_add, const float *resid, long long resid_bs, float *sm, float *sr,
-               int prof) {
+               int prof, bool pf_only_out = false) {
         ConvOpts o;
+        o.no_f32 = pf_only_out;
         o.ln_g = g; o.ln_b = b; o.relu = 1; o.shift = shift; o.pre_add = pre_add;
         o.no_bias = pre_add != nullptr;          // the hoisted partial already carries the bias
         o.resid = resid; o.resid_bs = resid_bs; o.resid_cs = (long long)H * W;
@@ -843,6 +992,12 @@ struct Builder {
         o.res3_w = next_res3_w; o.res3_x = next_res3_x; o.res3_bs = next_res3_bs;
         const bool want_res3 = next_res3_w != nullptr;
         next_res3_w = next_res3_x = nullptr;
+        o.emit_pf = true;
+        {   // pre-split operands first: there the fused LayerNorm reduces across waves (up to 256 channels)
+            ConvOpts op = o;
+            op.pf_only = true;
+            if (conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), op, true, prof)) return;
+        }
         if (prefer_fused(w, H, W) && conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), o, true, prof))
             return;
         if (want_res3) { rc = fail(h, CDC_ERR_UNSUPPORTED, "epilogue res_conv needs the fused LayerNorm plan"); return; }
@@ -871,35 +1026,38 @@ struct Builder {
         const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
         const float *shift = rb.has_mlp ? h->shift + rb.shift_off : nullptr;   // Compressor blocks: no time embedding
         Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W);
+        // h1 feeds block2 only: when block2 runs on the pre-split operand kernel the fp32 copy is never read
+        static const bool keep_h1 = getenv("CDC_PF_KEEP_H1") != nullptr;
+        const bool h1_pf_only = !keep_h1 && twin(h1.p) && pf_would_plan(rb.c2, H, W);
         if (a1 && a1_is_context && rb.hoist_cx == a0.C) {
             std::vector<Op> *saved = cur;
-            Act p1 = new_act(rb.cout, H, W);
+            Act p1 = new_act(rb.cout, H, W, false);
             cur = &h->pre_ops;
             conv(rb.c1c, a1->p, a1->C, a1->bs(), nullptr, 0, H, W, p1.p, p1.bs(), ConvOpts(), false, prof1);
             const float *res = nullptr;
             long long res_bs = 0;
             Act pr, cat;
             if (rb.has_res) {
-                pr = new_act(rb.cout, H, W);
+                pr = new_act(rb.cout, H, W, false);
                 conv(rb.cresc, a1->p, a1->C, a1->bs(), nullptr, 0, H, W, pr.p, pr.bs(), ConvOpts(), false,
                      PC_CONV1);
             } else {
                 // identity residual over the concatenation (downs.1.0): context half copied once
-                cat = new_act(a0.C + a1->C, H, W);
+                cat = new_act(a0.C + a1->C, H, W, false);
                 copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
             }
             cur = saved;
             if (rb.has_unfold && (W & 3) == 0) {
-                Act u = new_act(a0.C * rb.k, H, W);
+                Act u = new_act(a0.C * rb.k, H, W, false);
                 Op uo; uo.kind = Op::UNFOLD; uo.prof = prof1;
                 uo.uf = {a0.p, a0.bs(), u.p, u.bs(), a0.C, rb.k, rb.k / 2, H, W};
                 uo.bytes = 4.0 * B * (a0.C + u.C) * HW;
                 emit(uo);
                 block(rb.c1u, u.p, u.C, u.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
-                      nullptr, nullptr, prof1);
+                      nullptr, nullptr, prof1, h1_pf_only);
             } else
             block(rb.c1x, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
-                  nullptr, nullptr, prof1);
+                  nullptr, nullptr, prof1, h1_pf_only);
             if (rb.has_res && a0.C == 3 && rb.cresx.COP == round_up(rb.cout, 32) && prefer_fused(rb.c2, H, W) &&
                 !getenv("CDC_NO_RES3")) {
                 // res_conv over the 3 image channels rides in block2's epilogue; its context half (with
@@ -907,7 +1065,7 @@ struct Builder {
                 res = pr.p; res_bs = pr.bs();
                 next_res3_w = rb.cresx.wp; next_res3_x = a0.p; next_res3_bs = a0.bs();
             } else if (rb.has_res) {
-                Act r = new_act(rb.cout, H, W);
+                Act r = new_act(rb.cout, H, W, false);
                 ConvOpts orr; orr.pre_add = pr.p; orr.no_bias = true;
                 conv(rb.cresx, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, r.p, r.bs(), orr, false, PC_CONV1);
                 res = r.p; res_bs = r.bs();
@@ -923,17 +1081,17 @@ struct Builder {
         int C0 = a0.C;
         long long bs0 = a0.bs(), bs1 = a1 ? a1->bs() : 0;
         if (!rb.has_res && a1) {
-            Act cat = new_act(a0.C + a1->C, H, W);
+            Act cat = new_act(a0.C + a1->C, H, W, false);
             copy(a0.p, a0.bs(), cat.p, cat.bs(), a0.bs());
             copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
             s0 = cat.p; s1 = nullptr; C0 = cat.C; bs0 = cat.bs(); bs1 = 0;
         }
         block(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1, rb.g1, rb.b1, shift, nullptr, nullptr, 0, nullptr,
-              nullptr, prof1);
+              nullptr, prof1, h1_pf_only);
         const float *res = s0;
         long long res_bs = bs0;
         if (rb.has_res) {
-            Act r = new_act(rb.cout, H, W);
+            Act r = new_act(rb.cout, H, W, false);
             conv(rb.cres, s0, C0, bs0, s1, bs1, H, W, r.p, r.bs(), ConvOpts(), false, PC_CONV1);
             res = r.p; res_bs = r.bs();
         }
@@ -953,7 +1111,7 @@ struct Builder {
         const bool fused = fold && (C == 64 || (C == 128 && !getenv("CDC_NO_KVCTX128"))) &&
                            at.kvWt && N % 2048 == 0 && !getenv("CDC_NO_KVCTX");
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
-        Act qkv = fused ? Act() : new_act(kvc, H, W);
+        Act qkv = fused ? Act() : new_act(kvc, H, W, false);
         ConvOpts oq;                                   // LN(x) folded into the projection (LNMODE 2)
         oq.pre_mean = sm; oq.pre_rstd = sr; oq.pre_mode = 2;
         if (!fused)
@@ -1012,6 +1170,8 @@ struct Builder {
             int ns = std::max(1, ceil_div(2048, B));
             while (ns > 1 && N % (32 * ns)) --ns;
             f.lnc = {x.p, x.bs(), sm, sr, Ws, biasB, y.p, y.bs(), C, N, ns};
+            if (PfTwin *ty = twin(y.p))
+                if ((W % 32) == 0) { f.lnc.y_pf = ty->p; f.lnc.pf_bs = ty->bs(); f.lnc.pf_ps = ty->ps(); f.lnc.W = W; ty->valid = true; }
             f.flops = 2.0 * B * (double)C * C * N; f.bytes = 12.0 * B * C * N;
             emit(f);
             return y;
@@ -1023,15 +1183,17 @@ struct Builder {
             oy.w_bs = (long long)Cin_pad * COP;
             oy.shift = biasB; oy.shift_bs = C;
             oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
+            oy.emit_pf = true;
             conv(cw, x.p, C, x.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
             return y;
         }
         // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
-        Act o = new_act(C, H, W);
+        Act o = new_act(C, H, W, false);
         dbg_taps.push_back({o.p, (size_t)B * C * N});
         ConvOpts oo; oo.w_bs = (long long)Cin_pad * COP; oo.no_bias = true;
         conv(cw, qkv.p, C, qkv.bs(), nullptr, 0, H, W, o.p, o.bs(), oo, false, PC_CONV1);
         ConvOpts oy; oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
+        oy.emit_pf = true;
         conv(at.out, o.p, C, o.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
         return y;
     }
@@ -1044,11 +1206,10 @@ void free_program(cdc_handle *h) {
     h->op_ms.clear(); h->op_n.clear(); h->op_label.clear(); h->op_flops.clear();
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     h->in_ctx.clear();
+    h->taps.clear();
     h->dec_outs.clear();
     h->act_bytes = 0;
     h->pB = h->pH = h->pW = 0;
-    h->d_time_steps = nullptr;
-    h->d_shift_tab = nullptr;
     h->time_steps_B = 0;
 }
 
@@ -1069,7 +1230,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     h->xb = bd.dalloc((size_t)B * h->cfg.channels * H * W);
     h->noise_buf = bd.dalloc((size_t)B * h->cfg.channels * H * W);
     const int n_ctx = std::min(n - 1, (int)h->context_dims.size() - 1);   // unet.py:65-68,109
-    for (int l = 0; l < n_ctx; ++l) h->in_ctx.push_back(bd.new_act(h->context_dims[l], H >> l, W >> l));
+    for (int l = 0; l < n_ctx; ++l) h->in_ctx.push_back(bd.new_act(h->context_dims[l], H >> l, W >> l, false));
     if (bd.rc) return bd.rc;
 
     Op t; t.kind = Op::TEMB; t.prof = PC_SMALL;
@@ -1085,16 +1246,21 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
         const bool has_ctx = i < n_ctx;
+        const std::string dn = "downs." + std::to_string(i);
         x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, true, nullptr, nullptr);
+        h->taps[dn + ".0"] = x;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
+        h->taps[dn + ".1"] = x;
         x = bd.attention(h->attns[ati++], x, sm, sr);
+        h->taps[dn + ".2"] = x;
         skips.push_back(x);
         if (i < n - 1) {
             const ConvW &dw = h->downs[i];
             Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2);
-            bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false,
-                    PC_DOWN);
+            Builder::ConvOpts od; od.emit_pf = true;
+            bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), od, false, PC_DOWN);
             x = y;
+            h->taps[dn + ".3"] = x;
         }
         if (bd.rc) return bd.rc;
     }
@@ -1102,8 +1268,11 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);          // mid_block1
+        h->taps["mid_block1"] = x;
         x = bd.attention(h->attns[ati++], x, sm, sr);                       // mid_attn
+        h->taps["mid_attn"] = x;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, nullptr, nullptr); // mid_block2
+        h->taps["mid_block2"] = x;
     }
     float *fsm = nullptr, *fsr = nullptr;       // LN statistics of the last Upsample output
     bool final_ln_done = false;                 // ... unless the Upsample epilogue already normalised it
@@ -1118,6 +1287,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         const ConvW &uw = h->ups[i];
         Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2);
         Builder::ConvOpts ou;
+        ou.emit_pf = i < n - 2;              // (the last Upsample feeds the final convolution only)
         bool done = false;
         if (i == n - 2) {
             // the final LayerNorm (unet.py:104) needs per-pixel statistics of this output: emit them
@@ -1145,6 +1315,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
             }
         }
         x = y;
+        if (!final_ln_done) h->taps["ups." + std::to_string(i)] = x;   // (the last one may hold LN(up(x)) instead)
         if (bd.rc) return bd.rc;
     }
     if (n == 1) {       // no Upsample stage: statistics of the last attention output
@@ -1187,7 +1358,8 @@ int build_encoder_program(cdc_handle *h, int B, int H, int W) {
         x = bd.resblock(h->rbs[i], x, nullptr, false, nullptr, nullptr);
         const ConvW &dw = h->downs[i];
         Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2);
-        bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false, PC_DOWN);
+        Builder::ConvOpts od; od.emit_pf = true;
+        bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), od, false, PC_DOWN);
         x = y;
         if (bd.rc) return bd.rc;
     }
@@ -1247,7 +1419,8 @@ int build_ctxdec_program(cdc_handle *h, int B, int hl, int wl) {
         x = bd.resblock(h->rbs[i], x, nullptr, false, nullptr, nullptr);
         const ConvW &uw = h->ups[i];
         Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2);
-        bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), Builder::ConvOpts(), false, PC_UP);
+        Builder::ConvOpts ouu; ouu.emit_pf = true;
+        bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ouu, false, PC_UP);
         x = y;
         h->dec_outs.push_back(y);
         if (bd.rc) return bd.rc;
@@ -1289,6 +1462,10 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
     }
     switch (op.kind) {
         case Op::CONV: HIP_TRY(h, conv_launch(op.conv, op.plan, B, op.nz, st)); break;
+        case Op::CONVPF: HIP_TRY(h, pf_launch(op.pf, op.pfplan, B, op.nz, st)); break;
+        case Op::PFPACK:
+            HIP_TRY(h, pf_pack_launch(op.pk.src, op.pk.src_bs, op.pk.dst, op.pk.dst_bs, op.pk.C, op.pk.H, op.pk.W, B, st));
+            break;
         case Op::LN: HIP_TRY(h, ln_launch(op.ln, B, st)); break;
         case Op::TEMB: HIP_TRY(h, temb_launch(op.temb, B, st)); break;
         case Op::KSTATS:
@@ -1464,6 +1641,8 @@ void cdc_destroy(cdc_handle *h) {
     free_program(h);
     free_pool(&h->weight_allocs);
     if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->d_time_steps) (void)hipFree(h->d_time_steps);
+    if (h->d_shift_tab) (void)hipFree(h->d_shift_tab);
     (void)resolve_pending(h);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if (h->gev_in) (void)hipEventDestroy(h->gev_in);
@@ -1780,7 +1959,8 @@ int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, c
     if (!q_hyper_latent || !q_latent || !mean || !scale || !bpp || B < 1 || hh < 1 || wh < 1 || H_img < 1 || W_img < 1)
         return fail(h, CDC_ERR_INVALID, "null/invalid argument");
     const int Ch = h->hyper_dims[0], Cl = h->hyper_dims.back() / 2;
-    const long long nh = (long long)Ch * hh * wh, nl = (long long)Cl * 16 * hh * wh;
+    const long long nh = (long long)Ch * hh * wh, up = 1LL << ((int)h->hyper_dims.size() - 2),
+                    nl = (long long)Cl * up * up * hh * wh;   // hyper_dec upsamples by 2 per layer but the last
     hipStream_t st = pick_stream(h, stream, mem);
     std::vector<void *> tmp;
     auto dev = [&](const float *p, long long n) -> const float * {
@@ -1928,6 +2108,21 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
     return copy_out(h, out, h->out_fx, (size_t)B * h->out_dim * H * W, mem, st);
 }
 
+int cdc_unet_tap(cdc_handle *h, const char *name, float *out, int64_t shape[4]) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!name || !shape) return fail(h, CDC_ERR_INVALID, "null argument");
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return fail(h, CDC_ERR_INVALID, "no tap named '%s' in the current program", name);
+    const Act &a = it->second;
+    shape[0] = h->pB; shape[1] = a.C; shape[2] = a.H; shape[3] = a.W;
+    if (out) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(out, a.p, (size_t)h->pB * a.bs() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return CDC_OK;
+}
+
 int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float *sqrt_recip,
                      const float *sqrt_recipm1, const float *sqrt_ac_prev,
                      const float *one_minus_ac_prev, const float *sigma) {
@@ -1937,16 +2132,26 @@ int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float
         return fail(h, CDC_ERR_INVALID, "null/invalid argument");
     int rc0 = ensure_device(h);
     if (rc0) return rc0;
-    HIP_TRY(h, hipDeviceSynchronize());
-    if (h->d_tab) { (void)hipFree(h->d_tab); h->d_tab = nullptr; }
     std::vector<float> tab((size_t)5 * steps);
     const float *srcs[5] = {sqrt_recip, sqrt_recipm1, sqrt_ac_prev, one_minus_ac_prev, sigma};
     for (int k = 0; k < 5; ++k) memcpy(&tab[(size_t)k * steps], srcs[k], sizeof(float) * steps);
-    HIP_TRY(h, hipMalloc((void **)&h->d_tab, tab.size() * sizeof(float)));
+    // compress() / decompress() set the schedule on every call: the same tables again change nothing
+    if (h->d_tab && h->steps == steps && tab == h->h_tab && (int)h->h_time_in.size() == steps &&
+        memcmp(h->h_time_in.data(), time_in, sizeof(float) * steps) == 0)
+        return CDC_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (tab.size() > h->tab_cap) {       // grow only; the buffer keeps its address otherwise
+        if (h->d_tab) { (void)hipFree(h->d_tab); h->d_tab = nullptr; }
+        HIP_TRY(h, hipMalloc((void **)&h->d_tab, tab.size() * sizeof(float)));
+        h->tab_cap = tab.size();
+    }
     HIP_TRY(h, hipMemcpy(h->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->h_tab.swap(tab);
     h->h_time_in.assign(time_in, time_in + steps);
     h->steps = steps;
-    h->time_steps_B = 0;     // forces re-upload of the per-step time rows
+    h->time_steps_B = 0;     // forces re-evaluation of the per-step time rows
+    ++h->sched_gen;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     return CDC_OK;
 }
 
@@ -1955,14 +2160,21 @@ int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float
 // launch (one workgroup per step) and broadcast row i at iteration i.
 static int ensure_time_rows(cdc_handle *h, int B) {
     if (h->d_shift_tab && h->time_steps_B == B) return CDC_OK;
-    void *p = nullptr, *q = nullptr;
-    HIP_TRY(h, hipMalloc(&p, (size_t)h->steps * sizeof(float)));
-    h->act_allocs.push_back(p);
-    HIP_TRY(h, hipMemcpy(p, h->h_time_in.data(), (size_t)h->steps * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMalloc(&q, (size_t)h->steps * h->shift_bs * sizeof(float)));
-    h->act_allocs.push_back(q);
-    h->d_time_steps = (float *)p;
-    h->d_shift_tab = (float *)q;
+    const size_t need = (size_t)h->steps * (h->shift_bs + 1);
+    if (need > h->trows_cap) {           // owned by the handle (not by the launch program): reused across schedules
+        if (h->d_time_steps) (void)hipFree(h->d_time_steps);
+        if (h->d_shift_tab) (void)hipFree(h->d_shift_tab);
+        h->d_time_steps = h->d_shift_tab = nullptr;
+        h->trows_cap = 0;
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // it baked the old addresses
+        void *p = nullptr, *q = nullptr;
+        HIP_TRY(h, hipMalloc(&p, (size_t)h->steps * sizeof(float)));
+        h->d_time_steps = (float *)p;
+        HIP_TRY(h, hipMalloc(&q, (size_t)h->steps * h->shift_bs * sizeof(float)));
+        h->d_shift_tab = (float *)q;
+        h->trows_cap = need;
+    }
+    HIP_TRY(h, hipMemcpy(h->d_time_steps, h->h_time_in.data(), (size_t)h->steps * sizeof(float), hipMemcpyHostToDevice));
     h->time_steps_B = B;
     TembArgs t;
     t.time = h->d_time_steps; t.w0 = h->tm_w0; t.b0 = h->tm_b0; t.w2 = h->tm_w2; t.b2 = h->tm_b2;
@@ -1984,7 +2196,8 @@ static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *
     Op op;
     op.kind = Op::DDIM; op.prof = PC_SMALL;
     op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i < 0 ? 0 : i,
-               i == -2 ? h->d_step : nullptr, pred_mode, clip, eta, (long long)n};
+               i == -2 ? h->d_step : nullptr, pred_mode, clip, eta, (long long)n,
+               (long long)(B / 2) * h->cfg.channels * H * W, h->d_fault};
     op.bytes = 16.0 * n;
     return run_op(h, op, B, st);
 }
@@ -2025,10 +2238,14 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     if (h->out_dim != h->cfg.channels)
         return fail(h, CDC_ERR_UNSUPPORTED, "sampler needs out_dim == channels");
     if (!out || !ctx) return fail(h, CDC_ERR_INVALID, "null argument");
+    if (pred_mode < 0 || pred_mode > 2 || clip < 0 || clip > 2)
+        return fail(h, CDC_ERR_INVALID, "pred_mode %d / clip %d out of range", pred_mode, clip);
     if ((rc = build_program(h, B, H, W))) return rc;
     if ((rc = ensure_time_rows(h, B))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
     const size_t n = (size_t)B * h->cfg.channels * H * W;
+    if (!h->d_fault) { void *p = nullptr; HIP_TRY(h, hipMalloc(&p, sizeof(int))); h->d_fault = (int *)p; h->weight_allocs.push_back(p); }
+    HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st));
     if (init) { if ((rc = copy_in(h, h->in_x, init, n, mem, st))) return rc; }
     else HIP_TRY(h, hipMemsetAsync(h->in_x, 0, n * sizeof(float), st));
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
@@ -2056,7 +2273,7 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
         // first iteration eagerly (kernel attributes, code pages), then capture the second and replay it
         if ((rc = ddim_on_device(h, h->in_x, i, nullptr, 0.f, h->in_x, B, H, W, pred_mode, clip, st))) return rc;
         --i;
-        const int key[4] = {h->steps, pred_mode, clip, 1};
+        const int key[4] = {h->steps, pred_mode, clip, h->sched_gen};
         if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key)) {
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
@@ -2087,6 +2304,20 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
             return rc;
     }
     h->prof_now = true;
+    // Range guard of the two-plane fp16 arithmetic: |activation| >= 65504 turns into inf / NaN, reaches the U-Net
+    // output and is flagged by the sampler kernel.  Such a decode is repeated once with the full-range three-plane
+    // bf16 arithmetic (the handle stays in that mode).  One 4-byte read-back per decode.
+    static const bool no_guard = getenv("CDC_NO_RANGE_GUARD") != nullptr;
+    if (h->arith == CDC_ARITH_F16X2 && !no_guard) {
+        int fault = 0;
+        HIP_TRY(h, hipMemcpyAsync(&fault, h->d_fault, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        if (fault) {
+            if ((rc = cdc_set_arith(h, CDC_ARITH_BF16X3))) return rc;
+            ++h->range_faults;
+            return cdc_decode(h, init, ctx, n_ctx, out, B, H, W, pred_mode, clip, mem, stream);
+        }
+    }
     return copy_out(h, out, h->in_x, n, mem, st);
 }
 
@@ -2188,6 +2419,8 @@ int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bi
     if (resid && (rc = sc.up(resid, (size_t)B * Cout * Ho * Wo, &dr))) return rc;
     h->shift_bs = Cout;
     float *dy = bd.dalloc((size_t)B * Cout * Ho * Wo);
+    bd.add_twin(dx, Cin, H, W);                  // qualifying shapes run on the pre-split operand kernel
+    bd.pack(dx, (long long)Cin * H * W);
     if (bd.rc) return bd.rc;
     Builder::ConvOpts o;
     o.ln_g = dg; o.ln_b = db; o.relu = relu; o.shift = ds;
@@ -2220,6 +2453,8 @@ int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const
     if ((rc = sc.up(x, (size_t)B * Cin * H * W, &dx))) return rc;
     const size_t ny = (size_t)B * Cout * 4 * H * W;
     float *dy = bd.dalloc(ny);
+    bd.add_twin(dx, Cin, H, W);
+    bd.pack(dx, (long long)Cin * H * W);
     if (bd.rc) return bd.rc;
     bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, (long long)Cout * 4 * H * W,
             Builder::ConvOpts(), false, PC_UP);

@@ -40,6 +40,17 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan);
 // Fills the tiling-dependent fields of `a` from the plan and launches (nz = gridDim.z).
 hipError_t conv_launch(ConvArgs a, const ConvPlan &plan, int B, int nz, hipStream_t st);
 
+// ---- pre-split fp16 operand convolution (conv_pf_kernel.h, conv_inst_p.hip) -------------------------------
+struct PfShape {
+    int Cin, Cout, C0 = 0, KH, KW, nz = 1, Ho, Wo, B;
+    bool need_all_cout = false;
+};
+struct PfPlan { int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; };
+bool pf_make_plan(const PfShape &s, PfPlan *plan);
+hipError_t pf_launch(PfArgs a, const PfPlan &plan, int B, int nz, hipStream_t st);
+hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long long dst_bs, int C, int H, int W, int B,
+                          hipStream_t st);
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
@@ -98,6 +109,9 @@ struct LnConvArgs {
     const float *bias;                  // [B][C]
     float *y; long long y_bs;
     int C, N, nsplit;
+    void *y_pf = nullptr;               // optional PF copy of y (conv_pf_kernel.h); image width W (W % 32 == 0)
+    long long pf_bs = 0, pf_ps = 0;
+    int W = 0;
 };
 hipError_t lnconv_launch(const LnConvArgs &a, int B, hipStream_t st);
 
@@ -127,9 +141,11 @@ struct DdimArgs {
                         //                          one_minus_ac_prev, sigma
     int steps, i;
     const int *step_ptr;   // non-null: the step index is read from device memory (hipGraph replay)
-    int pred_mode, clip;
+    int pred_mode, clip;   // pred_mode: 0 x-tree "x", 1 eps-tree "noise", 2 x-tree "noise"; clip: 0 none, 1 all, 2 first half
     float eta;
     long long n;
+    long long clip_half_n; // elements of the first B/2 images
+    int *fault;            // set to 1 when the U-Net output holds inf / NaN (may be null)
 };
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,

@@ -76,10 +76,57 @@ struct ConvArgs {
     int zfold;      // transposed conv: the 4 phases of a tile are consecutive-by-8 workgroup ids in gridDim.x, so
                     // they run on ONE XCD at about the same time and the L2 merges their interleaved stores
     long long out_ks;
+    // optional second copy of the result as a PF tensor (two fp16 planes in B-operand order, conv_pf_kernel.h):
+    // unit index b*pf_bs + ((co/8)*2 + plane)*pf_ps + oy*pf_ys + ox*pf_xs + pf_zoff[z]; needs Cout % 32 == 0
+    void *out_pf;
+    long long pf_bs, pf_ps;
+    int pf_ys, pf_xs, pf_zoff[4];
 #ifdef CDC_TIMELINE
     unsigned long long *tl;         // tools/build_variant.sh timeline -DCDC_TIMELINE: 64 cycle stamps per workgroup
 #endif
 };
+
+// Arguments of conv_pf_kernel (conv_pf_kernel.h): activations arrive as PF tensors (two fp16 planes, 16-byte units
+// of 8 channels, one-pixel zero halo).
+struct PfArgs {
+    const void *src0, *src1;        // PF sources (channel concatenation); src1 may be null
+    long long src0_bs, src1_bs;     // batch strides in units
+    int C0, Cin;                    // channels taken from src0; total (both multiples of 16)
+    int H, W;                       // input extent without the halo
+    const void *w;                  // fp16 planes {WH, WL, WH2}: [z][tap][Cin/16][3][2][COP] units
+    long long w_zs;
+    int KH, KW, nz;
+    int pad_y[4], pad_x[4];
+    int nchunk, COP, Cout;
+    float acc_scale;
+    int ring;                       // weight ring slots (3..6)
+    // fp32 NCHW output (may be null): b*out_bs + co*out_cs + oy*out_ys + ox*out_xs + out_zoff[z]
+    float *out;
+    long long out_bs, out_cs;
+    int out_ys, out_xs, out_zoff[4];
+    // PF output (may be null), unit index: b*pf_bs + ((co/8)*2 + plane)*pf_ps + oy*pf_ys + ox*pf_xs + pf_zoff[z]
+    // (pf_zoff includes the +1,+1 halo origin)
+    void *out_pf;
+    long long pf_bs, pf_ps;
+    int pf_ys, pf_xs, pf_zoff[4];
+    int Ho, Wo;
+    int lognbw, tiles_x, tiles_y, B;
+    int xcd_remap;
+    // epilogue (same meaning as ConvArgs)
+    const float *bias, *pre_add, *ep_g, *ep_b;
+    float eps;
+    int relu;
+    float relu_slope;
+    const float *shift;
+    int shift_bs;
+    const float *resid;
+    long long resid_bs, resid_cs;
+    float *stat_mean, *stat_rstd;
+    const float *res3_w, *res3_x;   // 3-channel res_conv in the epilogue (see ConvArgs)
+    long long res3_bs;
+};
+
+constexpr int kPfXS = 12;   // patch DMA instructions per chunk and patch wave (two patch waves: <= 24 per chunk)
 
 // Host-side launch plan for one convolution.
 struct ConvPlan {

@@ -1,0 +1,125 @@
+// conv_inst_p.hip -- instantiations, launch-plan chooser and launcher of conv_pf_kernel (pre-split fp16 operands
+// by LDS-DMA), plus the fp32 NCHW -> PF packing kernel for tensors whose producer does not emit planes.
+#include <algorithm>
+#include <stdlib.h>
+
+#include "cdc_internal.h"
+#include "conv_pf_kernel.h"
+
+namespace cdc {
+
+template <int KH, int KW>
+static pf_kernel_fn pf_lookup_k(int MB, int NPW, int WM, int WP) {
+    if (MB == 2 && NPW == 2 && WM == 1 && WP == 4) return conv_pf_kernel<2, 2, 1, 4, KH, KW>;
+    if (MB == 2 && NPW == 2 && WM == 2 && WP == 2) return conv_pf_kernel<2, 2, 2, 2, KH, KW>;
+    if (MB == 2 && NPW == 2 && WM == 2 && WP == 4) return conv_pf_kernel<2, 2, 2, 4, KH, KW>;
+    if (MB == 3 && NPW == 2 && WM == 2 && WP == 4) return conv_pf_kernel<3, 2, 2, 4, KH, KW>;
+    if (MB == 2 && NPW == 2 && WM == 4 && WP == 2) return conv_pf_kernel<2, 2, 4, 2, KH, KW>;
+    return nullptr;
+}
+static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW) {
+    if (KH == 3 && KW == 3) return pf_lookup_k<3, 3>(MB, NPW, WM, WP);
+    if (KH == 1 && KW == 1) return pf_lookup_k<1, 1>(MB, NPW, WM, WP);
+    if (KH == 2 && KW == 2) return pf_lookup_k<2, 2>(MB, NPW, WM, WP);
+    return nullptr;
+}
+
+// Candidate shapes, best first for a given channel-group width COPT = WM*MB*32.
+struct PfCand { int MB, NPW, WM, WP; };
+static const PfCand kCands[] = {
+    {2, 2, 4, 2},   // 256 channels, 8 waves, 4 rows
+    {3, 2, 2, 4},   // 192 channels, 8 waves, 8 rows
+    {2, 2, 2, 2},   // 128 channels, 4 waves, 4 rows
+    {2, 2, 2, 4},   // 128 channels, 8 waves, 8 rows
+    {2, 2, 1, 4},   //  64 channels, 4 waves, 8 rows
+};
+
+bool pf_make_plan(const PfShape &s, PfPlan *p) {
+    if (s.Cout % 32 || s.Cin % 16 || (s.C0 % 16)) return false;
+    if (s.Wo < 32) return false;                              // 32-pixel blocks are rows of the image (lognbw = 5)
+    static const char *force = getenv("CDC_PF_PLAN");         // tuning aid: "MB,NPW,WM,WP"
+    int f[4] = {0, 0, 0, 0};
+    if (force) sscanf(force, "%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3]);
+    double best = -1;
+    for (const PfCand &c : kCands) {
+        if (f[0] && (c.MB != f[0] || c.NPW != f[1] || c.WM != f[2] || c.WP != f[3])) continue;
+        const int COPT = c.WM * c.MB * 32, NW = c.WM * c.WP;
+        if (s.Cout % COPT) continue;
+        if (s.need_all_cout && COPT != s.Cout) continue;
+        if (!pf_lookup(c.MB, c.NPW, c.WM, c.WP, s.KH, s.KW)) continue;
+        const int TH = c.WP * c.NPW, PH = TH + s.KH - 1, PW = 32 + s.KW - 1;
+        const int xsw = (4 * PH * PW + 63) / 64;
+        if (xsw > 2 * kPfXS) continue;
+        const int taps = s.KH * s.KW, npb = taps == 1 ? 3 : 2;
+        const size_t patch = (size_t)npb * xsw * 64 * 16, wst = (size_t)6 * COPT * 16;
+        const size_t budget = NW == 8 ? 156 * 1024 : 80 * 1024;   // 4 waves: two workgroups per CU
+        int ring = 0;
+        for (int r : {5, 4, 3})
+            if (patch + r * wst <= budget) { ring = r; break; }
+        if (!ring) continue;
+        const int S = (s.Cin / 16) * taps;
+        ring = std::max(3, std::min(ring, S + 1));
+        const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * (s.Cout / COPT) * s.nz;
+        const double fill = std::min(1.0, wgs * NW / 2048.0);
+        const double reads = (3.0 * c.MB + 2.0 * c.NPW) / (3.0 * c.MB * c.NPW);   // ds_read_b128 per MFMA
+        const double score = fill * (1.0 - 0.35 * reads) * (s.Cout / COPT > 1 ? 0.9 : 1.0);
+        if (score > best) {
+            best = score;
+            p->MB = c.MB; p->NPW = c.NPW; p->WM = c.WM; p->WP = c.WP;
+            p->ring = ring;
+            p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + TH - 1) / TH;
+            p->groups = s.Cout / COPT;
+            p->lds_bytes = std::max(patch + ring * wst, sizeof(float) * (size_t)(4 * COPT + 2 * c.WM * c.WP * c.NPW * 32));
+        }
+    }
+    return best >= 0;
+}
+
+hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
+    pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW);
+    if (!fn) return hipErrorInvalidValue;
+    a.lognbw = 5;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
+    if (p.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
+    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
+    hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+// fp32 NCHW -> PF (interior only; the halo stays zero).  One thread = one unit pair (8 channels of a pixel).
+__global__ void __launch_bounds__(256) pf_pack_kernel(const float *src, long long src_bs, uint4 *dst, long long dst_bs,
+                                                      int C, int H, int W) {
+    const int b = blockIdx.y;
+    const long long n = (long long)(C / 8) * H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % W);
+    const long long t = i / W;
+    const int y = (int)(t % H), g = (int)(t / H);
+    const float *sp = src + (size_t)b * src_bs + ((size_t)g * 8 * H + y) * W + x;
+    f16x8 hv, lv;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        _Float16 h, l;
+        split2h(sp[(size_t)q * H * W], h, l);
+        hv[q] = h; lv[q] = l;
+    }
+    const long long ps = (long long)(H + 2) * (W + 2);
+    uint4 *dp = dst + (size_t)b * dst_bs + (long long)g * 2 * ps + (long long)(y + 1) * (W + 2) + x + 1;
+    dp[0] = __builtin_bit_cast(uint4, hv);
+    dp[ps] = __builtin_bit_cast(uint4, lv);
+}
+
+hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long long dst_bs, int C, int H, int W, int B,
+                          hipStream_t st) {
+    const long long n = (long long)(C / 8) * H * W;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(pf_pack_kernel, grid, dim3(256), 0, st, src, src_bs, reinterpret_cast<uint4 *>(dst), dst_bs, C, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace cdc

@@ -8,6 +8,30 @@
 namespace cdc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Two-plane fp16 split of an activation (see conv_split_kernel.h, AR = 1): a = h + l * 2^-11.
+__device__ __forceinline__ void split2h(float a, _Float16 &h, _Float16 &l) {
+    h = (_Float16)a;
+    l = (_Float16)((a - (float)h) * 2048.0f);
+}
+
+// Stores the 16 accumulator values of one 32x32 block (lane = pixel, r -> channel (r&3) + 8(r>>2) + 4*half)
+// as PF units (conv_pf_kernel.h): per 8-channel group the lane owns 4 consecutive channels = 8 bytes of each
+// plane's 16-byte unit; lanes l and l+32 complete the unit, a wave writes 512-byte runs.
+__device__ __forceinline__ void pf_store_block(uint4 *pf, long long unit0, long long pf_ps, int half, const f32x16 &v) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2h(v[g * 4 + i], h[i], l[i]);
+        f16x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+        uint2 *p = reinterpret_cast<uint2 *>(pf + unit0 + (long long)g * 2 * pf_ps) + half;
+        *p = __builtin_bit_cast(uint2, hv);
+        *(p + 2 * pf_ps) = __builtin_bit_cast(uint2, lv);
+    }
+}
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) {
     return magic ? __umulhi(n, magic) : n;
@@ -240,6 +264,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
                 for (int r = 0; r < 16; ++r) t += acc[m][n][r];
             if (valid) P.out[(size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs] = t;
             continue;
+        }
+        if (P.out_pf && valid) {           // (host: Cout % 32 == 0, no split-K slices)
+            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[z];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps,
+                               P.pf_ps, half, acc[m][n]);
         }
         float *op = P.out + g.out_off + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll

@@ -1,0 +1,448 @@
+// conv_pf_kernel.h -- stride-1 k x k / 1x1 / phase-decomposed transposed convolution whose activation operand
+// arrives PRE-SPLIT: the producer's epilogue stores every activation tensor a second time as two fp16 planes
+// (h, l' of split2h, conv_split_kernel.h) in MFMA B-operand order, so this kernel's main loop has no VALU work,
+// no staging registers and no ds_write at all -- both operands go HBM/L2 -> LDS by LDS-DMA and straight into
+// v_mfma_f32_32x32x16_f16 (three products per fp32 product, see conv_split_kernel.h AR = 1).
+//
+// "PF" tensor (planar fp16) of a [B][C][H][W] activation, C % 8 == 0:
+//      unit = 8 consecutive channels of ONE pixel of ONE plane = 16 bytes = one lane's B operand;
+//      layout [B][C/8][plane 0..1][H + 2][W + 2] units, i.e. a ONE-PIXEL ZERO HALO is stored with the tensor
+//      (written once when the program is built, never touched by a producer), so a 3x3 / pad-1 patch is a plain
+//      affine address pattern: no bounds logic, no masked lanes, no zero source.
+//      Same bytes per element as fp32 NCHW (2 x 2).
+//
+// Workgroup = WM x WP waves: wave (wm, wp) owns output channels [wm*MB*32, +MB*32) of the workgroup's cout group
+// and NPW 32-pixel blocks stacked vertically; WM > 1 shares one patch between the channel parts (a 256-channel
+// layer is ONE workgroup column: the fused channel-LayerNorm reduces across waves through LDS).
+//
+// Pipeline (one iteration = one tap of one 16-channel chunk):
+//   * weight stages [3 planes][2 k-halves][COPT] x 16 B stream through an R-slot LDS ring, issued R-2 taps ahead
+//     by the "weight waves" (all but the last two) and awaited with a COUNTED s_waitcnt vmcnt (never 0 in the
+//     steady state);
+//   * the patch [2 k-halves][2 planes][PH][PW] x 16 B of chunk c+1 is issued by the last two waves ("patch
+//     waves"), a slice per tap, while chunk c is being multiplied, into the other of two patch buffers; their VM
+//     queues hold nothing else, so their only wait is one vmcnt(0) per chunk, a whole chunk after the issue;
+//   * one s_barrier per tap publishes the landed stage; the operands of tap s+1 are read from LDS into a second
+//     register set while the MFMAs of tap s issue.
+#pragma once
+#include <type_traits>
+
+#include "conv_split_kernel.h"
+
+namespace cdc {
+
+
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS-DMA with the destination in M0 (declared clobbered: no save / restore around every piece) and a 64-bit
+// scalar base + 32-bit per-lane byte offset.  The s_nop is the wait state between the M0 write and the DMA.
+__device__ __forceinline__ void dma16(unsigned voff, const void *sbase, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte)
+                 : "memory");
+}
+
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// KH x KW are compile-time (3x3, 1x1, 2x2 phases): tap offsets become ds_read immediates, the tap loop and the
+// patch-issue schedule are unrolled, and the per-tap scalar work shrinks to the ring counters.
+template <int MB, int NPW, int WM, int WP, int KH, int KW>
+__global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) ? 2 : 1) conv_pf_kernel(const PfArgs P) {
+    constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
+    static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
+    constexpr int WI = 6 * COPT / 64;                   // DMA instructions per weight stage
+    constexpr int NWV = NW - 2;                         // weight waves 0 .. NW-3; patch waves NW-2, NW-1
+    constexpr int NWW = (WI + NWV - 1) / NWV;           // DMA instructions per stage and weight wave
+    constexpr int TAPS = KH * KW;
+    constexpr int NBW = 32, NBH = 1;                    // a 32-pixel block is a row segment (host: lognbw = 5)
+    constexpr int TH = WP * NPW * NBH;
+    constexpr int PH = TH + KH - 1, PW = NBW + KW - 1, PLANE = PH * PW;
+    constexpr int NX = 4 * PLANE;                       // units per chunk
+    constexpr int XSW = (NX + 63) / 64;                 // DMA instructions per chunk
+    constexpr int KX = (XSW + 1) / 2;                   // ... per patch wave (even / odd instructions)
+    constexpr int PST = XSW * 64;                       // units per patch buffer (tail lanes land in the slack)
+    // 1x1 layers have one tap per chunk: their patches run two chunks ahead through three buffers
+    constexpr int LA = TAPS == 1 ? 2 : 1, NPB = LA + 1;
+    constexpr int WST = 6 * COPT;                       // units per weight stage
+    static_assert(KX <= kPfXS, "patch too large for two patch waves");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WP, wp = wave % WP;
+    const bool patch_wave = wave >= NWV;
+    const int pwi = wave - NWV;                          // patch wave 0 / 1 issues the even / odd instructions
+    const int z = blockIdx.z, cog = blockIdx.y;
+    unsigned bid0 = blockIdx.x;
+    if (P.xcd_remap) bid0 = (bid0 & 7) * (gridDim.x >> 3) + (bid0 >> 3);
+    int bid = (int)bid0;
+    const int tx = bid % P.tiles_x;
+    bid /= P.tiles_x;
+    const int ty = bid % P.tiles_y;
+    const int b = bid / P.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * NBW;
+    const int S = P.nchunk * TAPS;
+    const int R = P.ring;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
+    const unsigned wl_lds = lds0 + (unsigned)(NPB * PST) * 16u;
+
+    // ---- patch waves: per-lane source offsets of their DMA instructions (constant over chunks) --------------
+    const int Hp = P.H + 2, Wp = P.W + 2;
+    const int iy0 = oy0 - P.pad_y[z] + 1, ix0 = ox0 - P.pad_x[z] + 1;      // +1: halo origin
+    unsigned xoff[KX];
+#pragma unroll
+    for (int i = 0; i < KX; ++i) {
+        int e = (2 * i + (pwi & 1)) * 64 + lane;
+        if (e >= NX) e = 0;
+        const int q = e / PLANE, rem = e - q * PLANE;    // q = k-half * 2 + plane: the order of the tensor
+        const int r = rem / PW, c = rem - r * PW;
+        const int iy = min(max(iy0 + r, 0), Hp - 1), ix = min(max(ix0 + c, 0), Wp - 1);
+        xoff[i] = (unsigned)((q * Hp + iy) * Wp + ix) * 16u;
+    }
+    const long long cg_bytes = (long long)4 * Hp * Wp * 16;               // bytes per 16-channel chunk of a PF tensor
+    const char *s0 = reinterpret_cast<const char *>(P.src0) + (size_t)b * P.src0_bs * 16;
+    const char *s1 = P.src1 ? reinterpret_cast<const char *>(P.src1) + (size_t)b * P.src1_bs * 16 : nullptr;
+    const int c0_chunks = P.C0 >> 4;
+    // patch instruction i of this wave is issued at tap `i / PER` of the previous chunk (PER per tap, early taps)
+    constexpr int ISSUE_TAPS = TAPS >= 9 ? 6 : (TAPS >= 4 ? 2 : 1);
+    constexpr int PER = (KX + ISSUE_TAPS - 1) / ISSUE_TAPS;
+    auto issue_patch = [&](int chunk, auto tc) {          // instructions scheduled at tap tc of the chunk before
+        constexpr int t = decltype(tc)::value;
+        const char *base = chunk < c0_chunks ? s0 + (long long)chunk * cg_bytes : s1 + (long long)(chunk - c0_chunks) * cg_bytes;
+        int pb = chunk;                                   // chunk % NPB
+        if constexpr (NPB == 2) pb &= 1; else pb %= 3;
+        const unsigned dst = lds0 + (unsigned)(pb * PST) * 16u + (unsigned)(pwi & 1) * 1024u;
+#pragma unroll
+        for (int i = 0; i < KX; ++i)
+            if (t < 0 || i / PER == t)
+                if (2 * i + (pwi & 1) < XSW) dma16(xoff[i], base, dst + (unsigned)(2 * i) * 1024u);
+    };
+    // ---- weight waves: instruction jj of a stage covers units [64jj, 64jj+64) = row pk = jj / (COPT/64) -------
+    const char *wsrc = reinterpret_cast<const char *>(P.w) + ((size_t)z * P.w_zs + (size_t)cog * COPT) * 16;
+    unsigned wvo[NWW], wdo[NWW];                          // per-lane source offset / LDS offset of instruction k
+#pragma unroll
+    for (int k = 0; k < NWW; ++k) {
+        const int jj = min(wave + k * NWV, WI - 1);       // clamped duplicates are harmless
+        const int row = jj / (COPT / 64), seg = jj - row * (COPT / 64);
+        wvo[k] = (unsigned)(row * P.COP + seg * 64 + lane) * 16u;
+        wdo[k] = __builtin_amdgcn_readfirstlane((unsigned)jj * 1024u);
+    }
+    const long long w_dt = (long long)P.nchunk * 6 * P.COP * 16;          // next tap, same chunk
+    const long long w_dc = (long long)6 * P.COP * 16 - (TAPS - 1) * w_dt;  // first tap of the next chunk
+    const char *wptr = wsrc;                              // stage to be issued next
+    int tw = 0, sw = 0;                                   // its tap and ring slot
+    auto issue_w = [&]() {
+        const unsigned dst = wl_lds + (unsigned)(sw * WST) * 16u;
+#pragma unroll
+        for (int k = 0; k < NWW; ++k) dma16(wvo[k], wptr, dst + wdo[k]);
+        if (++tw == TAPS) { tw = 0; wptr += w_dc; } else wptr += w_dt;
+        if (++sw == R) sw = 0;
+    };
+
+    f32x16 acc[MB][NPW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int half = lane >> 5, j = lane & 31;
+    const int pr = 0, pc = j;
+    // A: stage[(pl*2 + half)*COPT + wm*MB*32 + m*32 + j];  B: buf[(half*2 + pl)*PLANE + (row + ky)*PW + pc + kx]
+    const uint4 *a_base = smem_u + NPB * PST + half * COPT + wm * MB * 32 + j;
+    const uint4 *b_base = smem_u + (half * 2) * PLANE + (wp * NPW) * PW + j;
+
+    typedef f16x8 OpsA[3][MB];
+    typedef f16x8 OpsB[2][NPW];
+    // operands of tap t (compile-time: immediates) from patch buffer xb and ring slot wa
+    auto fetch = [&](auto tc, const uint4 *xb, const uint4 *wa, OpsA &A, OpsB &Bv) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int koff = (t / KW) * PW + (t % KW);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa[(pl * 2) * COPT + m * 32]);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) Bv[pl][n] = __builtin_bit_cast(f16x8, xb[pl * PLANE + n * PW + koff]);
+    };
+    auto mma = [&](const OpsA &A, const OpsB &Bv) {       // smallest terms first: WL.h, WH2.l', WH.h
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            constexpr int PA[3] = {1, 2, 0};
+            constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term]][m], Bv[PB[term]][n], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: patches of the first LA chunks, weight stages 0 .. R-2 -------------------------------------
+    if (patch_wave) {
+        for (int c = 0; c < LA && c < P.nchunk; ++c) issue_patch(c, std::integral_constant<int, -1>{});
+    } else {
+        for (int q = 0; q < R - 1 && q < S; ++q) issue_w();
+    }
+    dma_wait();
+    __builtin_amdgcn_s_barrier();
+    OpsA A0, A1;
+    OpsB B0, B1;
+    fetch(std::integral_constant<int, 0>{}, b_base, a_base, A0, B0);
+    int rem = S - 1;                                      // taps after the one being multiplied
+    int sn = 0;                                           // ring slot of the tap being fetched
+    // One tap.  TAIL = false: a tap of any chunk but the last -- every condition of the pipeline holds (the host
+    // guarantees TAPS >= ring - 1 or handles short tiles through the tail variant), so the body is straight-line
+    // code apart from the wave-role branch.  TAIL = true: the last chunk, with the end-of-tile conditions.
+    auto tap = [&](auto tc, auto tailc, int chunk, const uint4 *xb_cur, const uint4 *xb_nxt, OpsA &Ac, OpsB &Bc, OpsA &An,
+                   OpsB &Bn) {
+        constexpr int t = decltype(tc)::value;
+        constexpr bool TAIL = decltype(tailc)::value;
+        if (!(TAIL && t == TAPS - 1) || rem > 0) {        // (the very last tap has nothing left to fetch)
+            if (++sn == R) sn = 0;
+            // W(s+1) (and, at a chunk seam, the patch of the next chunk) must have landed before anyone reads it
+            if (patch_wave) {
+                if constexpr (t == TAPS - 1) dma_wait();
+            } else if (!TAIL || rem >= R - 2) {
+                // newer than W(s+1) in this wave's queue: W(s+2) .. W(s+R-2) = (R-3) stages
+                switch (R) {
+                    case 3: vm_wait<0>(); break;
+                    case 4: vm_wait<NWW>(); break;
+                    case 5: vm_wait<2 * NWW>(); break;
+                    default: vm_wait<3 * NWW>(); break;
+                }
+            } else {
+                dma_wait();                               // tail of the tile: everything in flight is needed next
+            }
+            __builtin_amdgcn_s_barrier();
+            const uint4 *wa = a_base + sn * WST;
+            if constexpr (t == TAPS - 1) fetch(std::integral_constant<int, 0>{}, xb_nxt, wa, An, Bn);
+            else fetch(std::integral_constant<int, t + 1>{}, xb_cur, wa, An, Bn);
+            if (patch_wave) {
+                if constexpr (t < ISSUE_TAPS)
+                    if (chunk + LA < P.nchunk) issue_patch(chunk + LA, tc);
+            } else if (!TAIL || rem >= R - 1) {
+                issue_w();                                // slot (s-1) % R: its readers passed the barrier above
+            }
+        }
+        --rem;
+        __builtin_amdgcn_s_setprio(2);
+        mma(Ac, Bc);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    int pbc = 0;                                          // patch buffer of the current chunk
+    auto chunk_body = [&](auto parc, auto tailc, int chunk) {   // parc: operand-set parity of this chunk's first tap
+        constexpr int par0 = decltype(parc)::value;
+        int pbn = pbc + 1;
+        if (pbn == NPB) pbn = 0;
+        const uint4 *xb_cur = b_base + pbc * PST, *xb_nxt = b_base + pbn * PST;
+        static_for<TAPS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (((par0 + t) & 1) == 0) tap(tc, tailc, chunk, xb_cur, xb_nxt, A0, B0, A1, B1);
+            else tap(tc, tailc, chunk, xb_cur, xb_nxt, A1, B1, A0, B0);
+        });
+        pbc = pbn;
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // chunks whose taps all satisfy rem >= ring - 1 run the straight-line variant
+    const int n_main = max(0, min(P.nchunk - 1, (S - R + 1) / TAPS));
+    if constexpr ((TAPS & 1) == 0) {
+        int chunk = 0;
+        for (; chunk < n_main; ++chunk) chunk_body(P0{}, std::false_type{}, chunk);
+        for (; chunk < P.nchunk; ++chunk) chunk_body(P0{}, std::true_type{}, chunk);
+    } else {
+        int chunk = 0;
+        for (; chunk + 1 < n_main; chunk += 2) {
+            chunk_body(P0{}, std::false_type{}, chunk);
+            chunk_body(P1{}, std::false_type{}, chunk + 1);
+        }
+        for (; chunk + 1 < P.nchunk; chunk += 2) {
+            chunk_body(P0{}, std::true_type{}, chunk);
+            chunk_body(P1{}, std::true_type{}, chunk + 1);
+        }
+        if (chunk < P.nchunk) chunk_body(P0{}, std::true_type{}, chunk);
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_barrier();                         // every wave is done with the operand buffers
+    float *ep = reinterpret_cast<float *>(smem_u);        // [4][COPT]: bias, ln g, ln b, shift   + reduction scratch
+    float *red = ep + 4 * COPT;                           // [2][WM][WP*NPW*32]
+    for (int i = tid; i < COPT; i += NT) {
+        const int co = cog * COPT + i;
+        const bool ok = co < P.Cout;
+        ep[i] = (ok && P.bias) ? P.bias[co] : 0.f;
+        ep[COPT + i] = (ok && P.ep_g) ? P.ep_g[co] : 0.f;
+        ep[2 * COPT + i] = (ok && P.ep_b) ? P.ep_b[co] : 0.f;
+        ep[3 * COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
+    }
+    __syncthreads();
+    const float inv_c = 1.0f / (float)P.Cout;
+    const int cobase = cog * COPT + wm * MB * 32;         // first channel of this wave
+    const float *epl = ep + wm * MB * 32 + 4 * half;
+    const bool ch_ok = cobase + MB * 32 <= P.Cout;        // host guarantees Cout % (MB*32) == 0 per wave part
+    float mean_v[NPW], rinv_v[NPW];
+    bool valid_v[NPW];
+    size_t pix_v[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+        valid_v[n] = (oy < P.Ho) && (ox < P.Wo) && ch_ok;
+        pix_v[n] = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[m][n][r] = acc[m][n][r] * P.acc_scale + epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+        if (P.pre_add && valid_v[n]) {
+            const float *pp = P.pre_add + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += pp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs];
+        }
+    }
+    // channel statistics of one pixel: in-lane sum over MB*16 values, lane^32, then across the WM channel parts
+    auto chan_stats = [&](float *mean_o, float *rinv_o) {
+        const int slot = (wp * NPW) * 32 + j;             // + n*32
+        float part[NPW];
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            float sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sm += acc[m][n][r];
+            sm += __shfl_xor(sm, 32);
+            part[n] = sm;
+        }
+        if constexpr (WM > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NPW; ++n)
+                if (half == 0) red[wm * (WP * NPW * 32) + slot + n * 32] = part[n];
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+                float sm = 0.f;
+#pragma unroll
+                for (int q = 0; q < WM; ++q) sm += red[q * (WP * NPW * 32) + slot + n * 32];
+                part[n] = sm;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            mean_o[n] = part[n] * inv_c;
+            float sq = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = acc[m][n][r] - mean_o[n]; sq += d * d; }
+            sq += __shfl_xor(sq, 32);
+            part[n] = sq;
+        }
+        if constexpr (WM > 1) {
+            float *red2 = red + WM * (WP * NPW * 32);
+#pragma unroll
+            for (int n = 0; n < NPW; ++n)
+                if (half == 0) red2[wm * (WP * NPW * 32) + slot + n * 32] = part[n];
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+                float sq = 0.f;
+#pragma unroll
+                for (int q = 0; q < WM; ++q) sq += red2[q * (WP * NPW * 32) + slot + n * 32];
+                part[n] = sq;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) rinv_o[n] = 1.0f / sqrtf(part[n] * inv_c + P.eps);
+    };
+    if (P.ep_g) {
+        chan_stats(mean_v, rinv_v);
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                    acc[m][n][r] = (acc[m][n][r] - mean_v[n]) * rinv_v[n] * epl[COPT + ci] + epl[2 * COPT + ci];
+                }
+    }
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        if (P.relu) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], P.relu_slope * acc[m][n][r]);
+        }
+        if (P.shift) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
+        }
+        if (P.resid && valid_v[n]) {
+            const float *rp = P.resid + (size_t)b * P.resid_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.resid_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += rp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.resid_cs];
+        }
+    }
+    if (P.res3_w) {        // res_conv over the 3 image channels of the first ResnetBlock: 3 FMAs per value
+        const size_t hw = (size_t)P.Ho * P.Wo;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+            const float *xp = P.res3_x + (size_t)b * P.res3_bs + (size_t)oy * P.Wo + ox;
+            const float x0 = valid_v[n] ? xp[0] : 0.f, x1 = valid_v[n] ? xp[hw] : 0.f, x2 = valid_v[n] ? xp[2 * hw] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cobase + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    acc[m][n][r] += P.res3_w[co] * x0 + P.res3_w[(size_t)P.COP + co] * x1 + P.res3_w[2 * (size_t)P.COP + co] * x2;
+                }
+        }
+    }
+    if (P.stat_mean) {
+        chan_stats(mean_v, rinv_v);
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+            if (valid_v[n] && half == 0 && wm == 0) {
+                P.stat_mean[(size_t)b * P.out_cs + pix_v[n]] = mean_v[n];
+                P.stat_rstd[(size_t)b * P.out_cs + pix_v[n]] = rinv_v[n];
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        if (!valid_v[n]) continue;
+        if (P.out) {
+            float *op = P.out + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
+        }
+        if (P.out_pf) {
+            const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[z];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps, P.pf_ps, half, acc[m][n]);
+        }
+    }
+}
+
+typedef void (*pf_kernel_fn)(const PfArgs);
+
+}  // namespace cdc

@@ -19,8 +19,6 @@
 namespace cdc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // ---- AR = 1: two-plane fp16 operands -----------------------------------------------------------------
 // a = h + l' * 2^-11 with h = fp16(a) (round to nearest) and l' = fp16((a - h) * 2^11): the residual is
@@ -33,10 +31,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // accumulator); the epilogue multiplies the accumulators by 2^-s (exact).  |a| >= 65504 becomes inf / NaN
 // and propagates to the output, where the sampler kernels flag it (the caller then re-runs the exact
 // three-plane bf16 arithmetic, AR = 0).
-__device__ __forceinline__ void split2h(float a, _Float16 &h, _Float16 &l) {
-    h = (_Float16)a;
-    l = (_Float16)((a - (float)h) * 2048.0f);
-}
+// (split2h lives in conv_kernel.h: the shared epilogue uses it to emit PF tensors)
 
 // a -> (hi, mid, lo) as fp32 bit patterns whose low 16 bits are zero; exact: a == hi + mid + lo
 __device__ __forceinline__ void split3(float a, unsigned &h, unsigned &m, unsigned &l) {

@@ -24,7 +24,8 @@ class _GaussianDiffusionBase:
     def _init_common(self, denoise_fn, context_fn, num_timesteps, pred_mode, var_schedule):
         assert pred_mode in ["noise", "x", "v"]
         if pred_mode == "v":
-            raise NotImplementedError('pred_mode "v" is not used by the reference test scripts')
+            raise NotImplementedError('pred_mode "v" (predict_start_from_v) is not implemented: neither reference '
+                                      "test script uses it")
         self.denoise_fn = denoise_fn
         self.context_fn = context_fn
         self.num_timesteps = int(num_timesteps)
@@ -58,8 +59,8 @@ class _GaussianDiffusionBase:
 
     # ---- schedule ---------------------------------------------------------------------------
     def set_sample_schedule(self, sample_steps, device=None):
-        s = SampleSchedule(self.num_timesteps, self.var_schedule,
-                           "x" if self.pred_mode == "x" else "eps", sample_steps)
+        # the schedule flavour (index / time rule, sigma formula) belongs to the TREE, not to pred_mode
+        s = SampleSchedule(self.num_timesteps, self.var_schedule, self._param, sample_steps)
         self.sample_steps = sample_steps
         self._sched = s
         self.index = s.index
@@ -74,10 +75,15 @@ class _GaussianDiffusionBase:
     # ---- sampler ----------------------------------------------------------------------------
     def _clip_flag(self, clip_denoised):
         if self._param == "x":
-            return 1 if clip_denoised else 0
-        if clip_denoised == "half":
-            raise NotImplementedError('clip_noise="half" is not used by the reference test script')
-        return 1 if clip_denoised == "full" else 0
+            return _lib.CDC_CLIP_ALL if clip_denoised else _lib.CDC_CLIP_NONE
+        if clip_denoised == "half":                       # eps :142-143: x_recon[: B // 2].clamp_(-1, 1)
+            return _lib.CDC_CLIP_HALF
+        return _lib.CDC_CLIP_ALL if clip_denoised == "full" else _lib.CDC_CLIP_NONE
+
+    def _pred_flag(self):
+        if self._param == "x":
+            return _lib.CDC_PRED_X if self.pred_mode == "x" else _lib.CDC_PRED_NOISE_XTREE
+        return _lib.CDC_PRED_NOISE
 
     def _loop(self, shape, context, clip_denoised, init, eta):
         L, un = _lib.lib(), self.denoise_fn
@@ -90,7 +96,7 @@ class _GaussianDiffusionBase:
         if any(c.mem != mem for c in actx):
             raise _lib.CdcError("context tensors must all be host or all be on the model's device")
         ptrs = (ctypes.c_void_p * len(actx))(*[c.ptr for c in actx])
-        pred = _lib.CDC_PRED_X if self.pred_mode == "x" else _lib.CDC_PRED_NOISE
+        pred = self._pred_flag()
         clip = self._clip_flag(clip_denoised)
         out, optr, omem = _result_like(proto, (B, C, H, W), dev)
         if omem != mem:

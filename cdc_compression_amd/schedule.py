@@ -36,7 +36,10 @@ def linspace_index(T, steps):
 class SampleSchedule:
     """Per-sample-step tables handed to cdc_set_schedule."""
 
-    def __init__(self, num_timesteps, var_schedule, pred_mode, sample_steps):
+    def __init__(self, num_timesteps, var_schedule, tree, sample_steps):
+        """tree: "x" (xparam/modules/denoising_diffusion.py) or "eps" (epsilonparam/...): the two trees differ in
+        the U-Net time input, the sample_steps == 1 special case and the order of operations of sigma."""
+        pred_mode = tree
         betas = cosine_beta_schedule(num_timesteps) if var_schedule == "cosine" \
             else linear_beta_schedule(num_timesteps)
         T = int(betas.shape[0])

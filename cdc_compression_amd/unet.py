@@ -86,6 +86,7 @@ class Unet:
         self._h = None
         self._sd = {}
         self._finalized = False
+        self._want_final = False     # load_state_dict() completed once: re-finalize after a device change
 
     # ---- handle management ----------------------------------------------------------------
     def _handle(self):
@@ -107,6 +108,10 @@ class Unet:
             self._h = h
             for k, v in self._sd.items():
                 self._load_one(k, v)
+            if self._sd and self._want_final:
+                # a handle re-created after .to(other device): the replayed parameters are final again
+                _lib.check(h, L.cdc_finalize_weights(h))
+                self._finalized = True
         return self._h
 
     def __del__(self):
@@ -166,6 +171,7 @@ class Unet:
                 self._load_one(n, self._sd[n])
         _lib.check(h, _lib.lib().cdc_finalize_weights(h))
         self._finalized = True
+        self._want_final = True
         return self
 
     def state_dict(self):
@@ -197,3 +203,14 @@ class Unet:
         return out
 
     __call__ = forward
+
+    def tap(self, name):
+        """Intermediate activation of the last forward / DDIM iteration by the reference's module path
+        ("downs.0.0", "downs.1.3", "mid_block1", "ups.0", ...): what a forward hook on that module records."""
+        import numpy as np
+        L, h = _lib.lib(), self._handle()
+        shape = (ctypes.c_int64 * 4)()
+        _lib.check(h, L.cdc_unet_tap(h, name.encode(), None, shape))
+        out = np.empty(tuple(shape), np.float32)
+        _lib.check(h, L.cdc_unet_tap(h, name.encode(), out.ctypes.data, shape))
+        return out

@@ -12,8 +12,11 @@
  *     cdc_last_error(h) returns a human-readable message for the last failure on that handle;
  *   - a handle is bound to one HIP device and is NOT thread-safe (one handle per GPU per thread);
  *   - pointers tagged `mem` are host pointers (CDC_MEM_HOST: the library stages them through
- *     its own device buffers) or device pointers on the handle's device (CDC_MEM_DEVICE: used in
- *     place, zero copy).  With device pointers the work is enqueued asynchronously on
+ *     its own device buffers) or device pointers on the handle's device (CDC_MEM_DEVICE: no host
+ *     round trip; outputs are written in place, the inputs x / init / context are copied once per
+ *     call, device to device on `stream`, into the buffers the launch program was built on --
+ *     2.1 GB for a batch-32 context pyramid at 256x256, < 1 ms against a 500-iteration decode).
+ *     With device pointers the work is enqueued asynchronously on
  *     `stream` (a hipStream_t passed as void*; NULL = the HIP null stream, i.e. torch's default
  *     stream); with host pointers `stream` is ignored, the library uses its own stream and the
  *     call is synchronous (result valid on return).
@@ -39,7 +42,14 @@ typedef enum {
 } cdc_status;
 
 enum { CDC_MEM_HOST = 0, CDC_MEM_DEVICE = 1 };
-enum { CDC_PRED_X = 0, CDC_PRED_NOISE = 1 };
+/* pred_mode of the sampler entry points: which tree's ddim() rules apply and what the U-Net predicts.
+ *   CDC_PRED_X            x-tree, pred_mode "x"     (xparam/modules/denoising_diffusion.py:157-158)
+ *   CDC_PRED_NOISE        eps-tree, pred_mode "noise" (epsilonparam/...:137-152: no clamp under the square root)
+ *   CDC_PRED_NOISE_XTREE  x-tree, pred_mode "noise" (xparam :155-156,165: x0 = predict_start_from_noise, .clamp(min=0))
+ * clip: CDC_CLIP_NONE, CDC_CLIP_ALL (x-tree clip_denoised=True; eps-tree clip_noise "full"),
+ *       CDC_CLIP_HALF (eps-tree clip_noise "half": only the first B/2 images, eps :142-143). */
+enum { CDC_PRED_X = 0, CDC_PRED_NOISE = 1, CDC_PRED_NOISE_XTREE = 2 };
+enum { CDC_CLIP_NONE = 0, CDC_CLIP_ALL = 1, CDC_CLIP_HALF = 2 };
 enum { CDC_MAX_LEVELS = 8 };
 
 /* Unet.__init__ arguments: xparam/modules/unet.py:19-29 (epsilonparam/modules/unet.py:18-27).
@@ -68,7 +78,9 @@ const char *cdc_version(void);
  * 16-bit matrix cores from split operands (no reference counterpart -- torch delegates to oneDNN / cuDNN fp32):
  *   CDC_ARITH_F16X2 (default)  a = h + l*2^-11 as two fp16 numbers, w*2^s as {WH, WL}: three
  *                              v_mfma_f32_32x32x16_f16 per product block, error <= 3 fp32 ulp per product,
- *                              activations must satisfy |a| < 65504 (else the result is NaN, never silently wrong);
+ *                              activations must satisfy |a| < 65504 -- beyond that the U-Net output is inf / NaN,
+ *                              cdc_decode notices (a flag written by the sampler kernel) and repeats the decode
+ *                              once in CDC_ARITH_BF16X3; cdc_unet_forward returns the non-finite values as they are;
  *   CDC_ARITH_BF16X3           a = a1 + a2 + a3 exactly as three bf16 numbers: six v_mfma_f32_32x32x16_bf16,
  *                              full fp32 range.
  * Changing the mode drops the handle's launch program (rebuilt on the next call).  New handles take
@@ -97,6 +109,13 @@ int cdc_finalize_weights(cdc_handle *h);
  * l < n_ctx (C_l = context_dims[l], unet.py:34,109); out [B,out_dim,H,W]. */
 int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const float *const *ctx,
                      int n_ctx, float *out, int B, int H, int W, int mem, void *stream);
+
+/* Intermediate activation of the LAST cdc_unet_forward / DDIM iteration, by the reference's module path: the output
+ * of "downs.<i>.<0|1|2|3>" (ResnetBlock, ResnetBlock, attention, Downsample: unet.py:110-116), "mid_block1",
+ * "mid_attn", "mid_block2", "ups.<i>" (output of the stage's Upsample, unet.py:125-128).  What a
+ * register_forward_hook on that module records in the reference; used by the per-stage parity tests.
+ * out may be NULL (shape query); host pointer, synchronous. */
+int cdc_unet_tap(cdc_handle *h, const char *name, float *out, int64_t shape[4]);
 
 /* ---- sampler: GaussianDiffusion.set_sample_schedule / ddim / p_sample_loop ------------------- */
 

@@ -275,9 +275,9 @@ class Schedule:
 
 
 def ddim_step(ops, cfg, sd, sched, x, i, context, num_timesteps_for_time, clip, eta=0.0,
-              noise=None):
-    """One DDIM update.  x-param: xparam/.../denoising_diffusion.py:152-174 (pred_mode "x",
-    embd_type "01"); eps-param: epsilonparam/.../denoising_diffusion.py:137-152."""
+              noise=None, pred_mode=None):
+    """One DDIM update.  x-param: xparam/.../denoising_diffusion.py:152-174 (pred_mode "x" or "noise",
+    embd_type "01"); eps-param: epsilonparam/.../denoising_diffusion.py:137-152 (clip "full" / "half")."""
     f = np.float32
     B = x.shape[0]
     if sched.param == "x":
@@ -289,7 +289,13 @@ def ddim_step(ops, cfg, sd, sched, x, i, context, num_timesteps_for_time, clip, 
     c_recip = sched.sqrt_recip_alphas_cumprod[i]
     c_recipm1 = sched.sqrt_recipm1_alphas_cumprod[i]
     sig = f(eta) * sched.sigma[i]
-    if sched.param == "x":
+    if sched.param == "x" and pred_mode == "noise":
+        x_recon = c_recip * x - c_recipm1 * fx                      # :155-156 predict_start_from_noise
+        if clip:
+            x_recon = np.clip(x_recon, -1.0, 1.0)
+        eps = fx                                                    # :165
+        var = np.maximum(sched.one_minus_alphas_cumprod_prev[i] - sig ** 2, f(0))   # .clamp(min=0)
+    elif sched.param == "x":
         x_recon = fx
         if clip:
             x_recon = np.clip(x_recon, -1.0, 1.0)
@@ -300,6 +306,9 @@ def ddim_step(ops, cfg, sd, sched, x, i, context, num_timesteps_for_time, clip, 
         x_recon = c_recip * x - c_recipm1 * eps                     # eps :99-103
         if clip == "full":
             x_recon = np.clip(x_recon, -1.0, 1.0)
+        elif clip == "half":                                        # eps :142-143
+            x_recon = x_recon.copy()
+            x_recon[: B // 2] = np.clip(x_recon[: B // 2], -1.0, 1.0)
         var = sched.one_minus_alphas_cumprod_prev[i] - sig ** 2
     x_next = sched.sqrt_alphas_cumprod_prev[i] * x_recon + np.sqrt(var).astype(f) * eps
     if eta != 0 and noise is not None:
@@ -307,12 +316,12 @@ def ddim_step(ops, cfg, sd, sched, x, i, context, num_timesteps_for_time, clip, 
     return x_next.astype(f)
 
 
-def p_sample_loop(ops, cfg, sd, sched, shape, context, clip, init=None, eta=0.0, noises=None):
+def p_sample_loop(ops, cfg, sd, sched, shape, context, clip, init=None, eta=0.0, noises=None, pred_mode=None):
     """x: :179-205 ; eps: :166-192.  for i in reversed(range(steps))."""
     img = np.zeros(shape, np.float32) if init is None else np.asarray(init, np.float32)
     for count, i in enumerate(reversed(range(sched.sample_steps))):
         nz = None if noises is None else noises[count]
-        img = ddim_step(ops, cfg, sd, sched, img, i, context, None, clip, eta, nz)
+        img = ddim_step(ops, cfg, sd, sched, img, i, context, None, clip, eta, nz, pred_mode)
     return img
 
 

@@ -192,6 +192,32 @@ def gen_decode(name, steps_list, eta_case=False):
     np.savez_compressed(os.path.join(HERE, f"decode_{name}.npz"), **out)
 
 
+def gen_decode_variants():
+    """The sampler branches the test scripts do not take: x-tree pred_mode="noise" (xparam :155-156,165; it is the
+    reference constructor's default) and eps-tree clip_noise="half" (epsilonparam :142-143, the constructor's default)."""
+    out = {}
+    for name, over in (("small_x", {"pred_mode": "noise"}), ("small_eps", {"clip_noise": "half"})):
+        tree, kw, ctxc, H, W, B = CONFIGS[name]
+        ref, net, _, _ = gen_unet(name, taps=False)
+        ctx = synth.context_pyramid(ctxc, B, H, W, seed=3)
+        tctx = [torch.from_numpy(c) for c in ctx]
+        args = dict(DIFF[tree]); args.update(over)
+        diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=FixedContext(tctx),
+                                        **({"ae_fn": None} if tree == "xparam" else {}), **args)
+        diff.eval()
+        init = synth.normal("init", (B, 3, H, W), seed=1, std=0.8)
+        images = np.zeros((B, 3, H, W), np.float32)
+        with torch.no_grad():
+            if tree == "xparam":
+                rec, _ = diff.compress(torch.from_numpy(images), sample_steps=3, init=torch.from_numpy(init.copy()))
+            else:
+                rec, _ = diff.compress(torch.from_numpy(images), sample_steps=3, sample_mode="ddim",
+                                       bpp_return_mean=False, init=torch.from_numpy(init.copy()))
+        out[name] = rec.numpy()
+        print("variant", name, over, float(rec.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "decode_variants.npz"), **out)
+
+
 def gen_schedules():
     out = {}
     for tree in ("xparam", "epsilonparam"):
@@ -245,6 +271,38 @@ def gen_full_res():
                 "dec4_sumsq": d["sumsq"]})
     np.savez_compressed(os.path.join(HERE, "full_res_x_256.npz"), **out)
     print("full res ok", d["sum"])
+
+
+def gen_full_res_other(name, cfg, H, W, steps=4):
+    """Digests of the real reference at the other BASELINE shapes: x-param 512x512 (configs[4]) and eps-param
+    256x256 (configs[2]), B=1: one U-Net forward + a `steps`-step decode."""
+    tree, kw, ctxc, _, _, _ = CONFIGS[cfg]
+    ref = import_reference(tree)
+    net = ref.unet.Unet(**kw)
+    load_synth(net, seed=0, final_gain=0.2 if tree == "epsilonparam" else 1.0)
+    B = 1
+    x = synth.normal("x", (B, 3, H, W), seed=1, std=0.8)
+    ctx = synth.context_pyramid(ctxc, B, H, W, seed=3)
+    tctx = [torch.from_numpy(c) for c in ctx]
+    time = np.full((B, 1), 0.37, np.float32)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x), torch.from_numpy(time), tctx).numpy()
+    d = digest(y)
+    out = {"time": time, "y_idx": d["idx"], "y_val": d["val"], "y_sum": d["sum"], "y_sumsq": d["sumsq"]}
+    extra = {"ae_fn": None} if tree == "xparam" else {}
+    diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=FixedContext(tctx), **extra, **DIFF[tree])
+    diff.eval()
+    init = synth.normal("init", (B, 3, H, W), seed=1, std=0.8)
+    with torch.no_grad():
+        if tree == "xparam":
+            rec, _ = diff.compress(torch.zeros(B, 3, H, W), sample_steps=steps, init=torch.from_numpy(init.copy()))
+        else:
+            rec, _ = diff.compress(torch.zeros(B, 3, H, W), sample_steps=steps, sample_mode="ddim",
+                                   init=torch.from_numpy(init.copy()))
+    d = digest(rec.numpy())
+    out.update({"dec_idx": d["idx"], "dec_val": d["val"], "dec_sum": d["sum"], "dec_sumsq": d["sumsq"], "steps": steps})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", d["sum"])
 
 
 CTXDEC = {
@@ -494,7 +552,10 @@ if __name__ == "__main__":
     gen_unet("odd_x")
     gen_decode("full_x", [3])
     gen_decode("full_eps", [3])
+    gen_decode_variants()
     gen_full_res()
+    gen_full_res_other("full_res_x_512", "full_x", 512, 512)
+    gen_full_res_other("full_res_eps_256", "full_eps", 256, 256)
     for n in CTXDEC:
         gen_ctxdec(n)
     for n in HYPERDEC:

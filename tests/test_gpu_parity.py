@@ -58,6 +58,18 @@ CONV_CASES = [
 ]
 
 
+PF_CASES = [
+    # pre-split operand kernel (conv_pf_kernel: W >= 32, Cin % 16 == 0, Cout % 32 == 0), one case per tile shape
+    (2, 128, 20, 64, 128, 3, 1, 1, True),   # 128 channels: two channel parts per workgroup, cross-wave LayerNorm
+    (1, 192, 36, 32, 192, 3, 1, 1, True),   # 192 channels, eight waves, ragged rows
+    (1, 256, 32, 32, 256, 3, 1, 1, True),   # 256 channels, four channel parts
+    (2, 384, 32, 32, 128, 1, 1, 0, False),  # 1x1 res_conv: one tap per chunk, three patch buffers
+    (1, 64, 33, 48, 64, 3, 1, 1, True),     # ragged in both directions
+    (1, 64, 40, 96, 96, 3, 1, 1, False),    # three channel blocks per wave
+    (1, 16, 32, 32, 32, 3, 1, 1, False),    # a single chunk: weight ring longer than the tile
+]
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_oracle(O, G, case):
     B, Ci, H, W, Co, k, s, p, fused = case
@@ -78,8 +90,40 @@ def test_conv2d_matches_oracle(O, G, case):
         assert relerr(g2, r2) < 5e-5, relerr(g2, r2)
 
 
+def _conv_check(O, G, case, tol_plain=2e-5, tol_fused=5e-5):
+    B, Ci, H, W, Co, k, s, p, fused = case
+    x = synth.normal("cx", (B, Ci, H, W), 21)
+    w = synth.normal("cw", (Co, Ci, k, k), 21, 1.0 / np.sqrt(Ci * k * k))
+    b = synth.normal("cb", (Co,), 21, 0.1)
+    ref = O.conv2d(x, w, b, s, p)
+    got = G.conv2d(x, w, b, s, p)
+    assert relerr(got, ref) < tol_plain, relerr(got, ref)
+    if fused:
+        g = synth.normal("cg", (Co,), 21, 0.2, 1.0)
+        bb = synth.normal("cbb", (Co,), 21, 0.2)
+        shift = synth.normal("cs", (B, Co), 21, 0.3)
+        resid = synth.normal("cr", ref.shape, 21)
+        r2 = np.maximum(O.chan_layernorm(ref, g, bb), 0) + shift[:, :, None, None] + resid
+        g2 = G.conv2d(x, w, b, s, p, ln_g=g, ln_b=bb, relu=True, shift=shift, resid=resid)
+        assert relerr(g2, r2) < tol_fused, relerr(g2, r2)
+
+
+@pytest.mark.parametrize("case", PF_CASES + CONV_CASES[4:6])
+def test_conv2d_pre_split_operand_kernel(O, case, monkeypatch):
+    """conv_pf_kernel (CDC_PF=1): activations arrive as two fp16 planes by LDS-DMA; every tile shape of its planner."""
+    monkeypatch.setenv("CDC_PF", "1")
+    _conv_check(O, Ops(0), case)
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[4], CONV_CASES[6], CONV_CASES[7], CONV_CASES[10], CONV_CASES[11]] + PF_CASES[:2])
+def test_conv2d_three_plane_bf16_arithmetic(O, case, monkeypatch):
+    """CDC_ARITH=0: the exact three-way bf16 split (six MFMA products) stays available as the full-range path."""
+    monkeypatch.setenv("CDC_ARITH", "0")
+    _conv_check(O, Ops(0), case)
+
+
 @pytest.mark.parametrize("case", [(2, 5, 6, 7, 4), (1, 64, 16, 16, 64), (1, 320, 8, 8, 320),
-                                  (1, 24, 12, 20, 24)])
+                                  (1, 24, 12, 20, 24), (2, 64, 24, 32, 64), (1, 192, 32, 32, 192), (1, 128, 33, 64, 128)])
 def test_conv_transpose2d_matches_oracle(O, G, case):
     B, Ci, H, W, Co = case
     x = synth.normal("tx", (B, Ci, H, W), 22)
@@ -126,6 +170,17 @@ def test_unet_forward_matches_reference_golden(name):
     un, kw, sd, x, time, ctx, g = make_unet(name)
     y = un(x, time, ctx)
     assert y.shape == g["y"].shape
+    assert relerr(y, g["y"]) < TOL, relerr(y, g["y"])
+
+
+@pytest.mark.parametrize("name,env", [("full_x", {"CDC_PF": "1"}), ("small_x", {"CDC_PF": "1"}), ("full_eps", {"CDC_PF": "1"}),
+                                      ("full_x", {"CDC_ARITH": "0"}), ("odd_x", {"CDC_ARITH": "0"})])
+def test_unet_forward_alternate_kernel_modes(name, env, monkeypatch):
+    """The same goldens through the opt-in pre-split operand kernel and through the bf16x3 arithmetic."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    un, kw, sd, x, time, ctx, g = make_unet(name)
+    y = un(x, time, ctx)
     assert relerr(y, g["y"]) < TOL, relerr(y, g["y"])
 
 
@@ -470,12 +525,12 @@ def test_kodak_crops_500_steps_match_reference():
     steps = int(g["steps"])
     rec = diff.decompress(comp.decode(g["q_latent"]), x.shape, sample_steps=steps, init=init)
     d = np.abs(rec.reshape(-1)[g["rec_idx"]] - g["rec_val"])
-    assert d.max() < 1e-4, float(d.max())
+    assert d.max() < 3e-5, float(d.max())          # measured 8.4e-6 (bf16x3) / ~1e-5 (fp16x2)
     assert abs(float(rec.astype(np.float64).sum()) - float(g["rec_sum"])) < 1e-5 * rec.size
     rec2, bpp = diff.compress(x, sample_steps=steps, bpp_return_mean=False, init=init)
     assert np.abs(bpp - g["bpp"]).max() <= 1e-5 * float(np.abs(g["bpp"]).max())
     flipped = int((np.abs(comp(x)["q_latent"] - g["q_latent"]) > 0.5).sum())
-    assert flipped <= 20, flipped
+    assert flipped <= 2, flipped          # measured: 1 of 196 608 (a latent within round-off of a rounding boundary)
     d2 = np.abs(rec2.reshape(-1)[g["rec_idx"]] - g["rec_val"])
     assert d2.mean() < (1e-5 if flipped == 0 else 5e-3), (flipped, float(d2.mean()))
 
@@ -501,10 +556,10 @@ def test_kodak_crops_eps_1000_steps_match_reference():
     rec = diff.decompress(comp.decode(g["q_latent"]), x.shape, sample_steps=steps, init=init)
     scale = max(1.0, float(np.abs(g["rec_val"]).max()))
     d = np.abs(rec.reshape(-1)[g["rec_idx"]] - g["rec_val"]) / scale
-    assert d.max() < 1e-3, float(d.max())
+    assert d.max() < 5e-5, float(d.max())          # relative to |x| ~ 480; measured 4.4e-6
     out = comp(x)
     assert np.abs(out["bpp"] - g["bpp"]).max() <= 1e-5 * float(np.abs(g["bpp"]).max())
-    assert int((np.abs(out["q_latent"] - g["q_latent"]) > 0.5).sum()) <= 20
+    assert int((np.abs(out["q_latent"] - g["q_latent"]) > 0.5).sum()) <= 2
 
 
 def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
@@ -522,3 +577,155 @@ def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
     monkeypatch.setenv("CDC_GRAPH", "0")
     np.testing.assert_array_equal(a, eager)
     np.testing.assert_array_equal(b, diff.decompress(ctx, shape, sample_steps=5, init=init))
+
+
+# ---- round 2: the remaining BASELINE shapes, per-stage taps, sampler variants ---------------------------------
+
+def _digest_check(a, g, key, tol=TOL):
+    flat = a.reshape(-1)
+    ref = g[key + "_val"]
+    assert float(np.abs(flat[g[key + "_idx"]] - ref).max()) <= tol * max(1.0, float(np.abs(ref).max()))
+    assert abs(float(a.astype(np.float64).sum()) - float(g[key + "_sum"])) <= tol * a.size * max(1.0, float(np.abs(ref).max()))
+
+
+def test_x_param_512_matches_reference_digest_and_batch16_rows():
+    """BASELINE configs[4] (x-param, batch 16, 512x512): the real reference's B=1 forward and 4-step decode as
+    digests (tests/golden/make_golden.py::gen_full_res_other), then every row of the batch-16 launch plans must
+    reproduce the B=1 result."""
+    g = np.load(os.path.join(GOLDEN, "full_res_x_512.npz"))
+    kw, man, sd, _, _, _, _ = load_case("full_x")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    H = W = 512
+    x = synth.normal("x", (1, 3, H, W), seed=1, std=0.8)
+    ctx = synth.context_pyramid([64, 64, 128, 192], 1, H, W, seed=3)
+    y1 = un(x, g["time"], ctx)
+    _digest_check(y1, g, "y")
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    init = synth.normal("init", (1, 3, H, W), seed=1, std=0.8)
+    steps = int(g["steps"])
+    rec1 = diff.decompress(ctx, (1, 3, H, W), sample_steps=steps, init=init)
+    _digest_check(rec1, g, "dec")
+    B = 16
+    rec16 = diff.decompress([np.repeat(c, B, 0) for c in ctx], (B, 3, H, W), sample_steps=steps, init=np.repeat(init, B, 0))
+    for k in (0, 7, 15):      # (different attention / split-K partitions: summation order differs; measured 1.1e-5)
+        assert relerr(rec16[k], rec1[0]) < 3e-5, (k, relerr(rec16[k], rec1[0]))
+    np.testing.assert_array_equal(rec16[3], rec16[12])
+
+
+def test_eps_param_256_matches_reference_digest_and_batch32_rows():
+    """BASELINE configs[2] (eps-param, batch 32, 256x256): reference digests at B=1 (forward + 4 DDIM steps, no
+    clipping), then the batch-32 launch plans row by row (the eps model's level 0 has 6 -> 64 channels and a
+    3-channel context: plans differ from the x-param ones)."""
+    g = np.load(os.path.join(GOLDEN, "full_res_eps_256.npz"))
+    kw, man, sd, _, _, _, _ = load_case("full_eps")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    H = W = 256
+    x = synth.normal("x", (1, 3, H, W), seed=1, std=0.8)
+    ctx = synth.context_pyramid([3, 64, 128, 192], 1, H, W, seed=3)
+    y1 = un(x, g["time"], ctx)
+    _digest_check(y1, g, "y")
+    diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=20000, clip_noise="none", pred_mode="noise", var_schedule="linear")
+    init = synth.normal("init", (1, 3, H, W), seed=1, std=0.8)
+    steps = int(g["steps"])
+    rec1 = diff.decompress(ctx, (1, 3, H, W), sample_steps=steps, init=init)
+    _digest_check(rec1, g, "dec")
+    B = 32
+    y32 = un(np.repeat(x, B, 0), np.repeat(g["time"], B, 0), [np.repeat(c, B, 0) for c in ctx])
+    for k in (0, 13, 31):
+        assert relerr(y32[k], y1[0]) < 1e-5, (k, relerr(y32[k], y1[0]))
+    rec32 = diff.decompress([np.repeat(c, B, 0) for c in ctx], (B, 3, H, W), sample_steps=steps, init=np.repeat(init, B, 0))
+    for k in (0, 19, 31):
+        assert relerr(rec32[k], rec1[0]) < 3e-5, (k, relerr(rec32[k], rec1[0]))
+
+
+TAPS = ["downs.0.0", "downs.0.2", "downs.1.3", "mid_block1", "ups.0"]
+
+
+@pytest.mark.parametrize("name", ["small_x", "small_eps", "odd_x", "full_x", "full_eps"])
+def test_unet_stage_taps_match_reference(name):
+    """Per-stage activations (forward hooks on the reference modules, stored by gen_unet as arrays for the small
+    configurations and as digests for the full-width ones) against cdc_unet_tap of the same forward: a wrong
+    ResnetBlock / attention / resampler shows up at its own stage, not only in the final output."""
+    un, kw, sd, x, time, ctx, g = make_unet(name)
+    un(x, time, ctx)
+    checked = 0
+    for k in TAPS:
+        key = k
+        if k == "downs.1.3" and f"tap_{k}" not in g.files and f"tap_{k}_val" not in g.files:
+            continue
+        if k == "downs.1.3" and len(kw["dim_mults"]) <= 2:
+            key = "downs.0.3"                                  # (make_golden hooks downs[0][3] for two-level nets)
+        if f"tap_{k}" in g.files:
+            ref = g[f"tap_{k}"]
+            got = un.tap(key)
+            assert got.shape == ref.shape, (k, got.shape, ref.shape)
+            assert relerr(got, ref) < TOL, (k, relerr(got, ref))
+            checked += 1
+        elif f"tap_{k}_val" in g.files:
+            got = un.tap(key)
+            ref = g[f"tap_{k}_val"]
+            err = float(np.abs(got.reshape(-1)[g[f"tap_{k}_idx"]] - ref).max()) / max(1.0, float(np.abs(ref).max()))
+            assert err < TOL, (k, err)
+            assert abs(float(got.astype(np.float64).sum()) - float(g[f"tap_{k}_sum"])) < TOL * got.size * max(1.0, float(np.abs(ref).max()))
+            checked += 1
+    assert checked >= 4, checked
+
+
+def test_sampler_variants_match_reference_golden():
+    """x-tree pred_mode="noise" (the reference constructor's default) and eps-tree clip_noise="half" (ditto)."""
+    g = np.load(os.path.join(GOLDEN, "decode_variants.npz"))
+    un, kw, sd, x, time, ctx, _ = make_unet("small_x")
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="noise", var_schedule="cosine")
+    rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
+    assert relerr(rec, g["small_x"]) < TOL, relerr(rec, g["small_x"])
+    un, kw, sd, x, time, ctx, _ = make_unet("small_eps")
+    diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=20000, clip_noise="half", pred_mode="noise", var_schedule="linear")
+    rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
+    assert relerr(rec, g["small_eps"]) < TOL, relerr(rec, g["small_eps"])
+    assert np.abs(rec[: x.shape[0] // 2]).max() <= np.abs(rec).max()
+
+
+def test_fp16_range_overflow_falls_back_to_bf16_planes():
+    """CDC_ARITH_F16X2 cannot represent |activation| >= 65504: the decode must notice (non-finite U-Net output flagged
+    by the sampler kernel) and repeat itself in the three-plane bf16 arithmetic instead of returning garbage."""
+    L = _lib.lib()
+    un, kw, sd, x, time, ctx, _ = make_unet("small_eps")
+    diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=20000, clip_noise="none", pred_mode="noise", var_schedule="linear")
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    big = [c * np.float32(3.0e5) for c in ctx]                  # context far outside the fp16 range
+    assert L.cdc_get_arith(un._handle()) == 1
+    rec = diff.decompress(big, x.shape, sample_steps=2, init=init)
+    assert np.isfinite(rec).all()
+    assert L.cdc_get_arith(un._handle()) == 0                   # the handle switched itself
+    un2, *_ = make_unet("small_eps")
+    _lib.check(un2._handle(), L.cdc_set_arith(un2._handle(), 0))
+    diff2 = cdc.GaussianDiffusionEps(un2, None, num_timesteps=20000, clip_noise="none", pred_mode="noise", var_schedule="linear")
+    ref = diff2.decompress(big, x.shape, sample_steps=2, init=init)
+    np.testing.assert_array_equal(rec, ref)
+
+
+def test_model_follows_device_change_after_load():
+    """load_state_dict() followed by .to(device) must leave a usable model (both reference test
+    scripts use that order): the handle is re-created, the parameters replayed AND finalized again."""
+    un, kw, sd, x, time, ctx, g = make_unet("small_x")
+    y0 = un(x, time, ctx)
+    un.to(0)                          # same device: nothing happens
+    un._h and _lib.lib().cdc_destroy(un._h)
+    un._h, un._finalized = None, False          # what .to(other device) does
+    y1 = un(x, time, ctx) if (un._handle() and un._finalized) else None
+    assert y1 is not None
+    np.testing.assert_array_equal(y0, y1)
+    meta = json.load(open(os.path.join(GOLDEN, "manifest_encoder_small_x.json")))
+    comp = cdc.ResnetCompressor(**meta["kwargs"])
+    csd = synth.unet_state_dict([(k, tuple(v)) for k, v in meta["manifest"]], seed=15)
+    comp.load_state_dict(csd)
+    img = synth.normal("img", (1, 3, 64, 64), seed=9, std=0.5)
+    a = comp(img)
+    comp.device_index = -1            # force the "device changed" branch of .to()
+    comp.to(0)
+    b = comp(img)
+    np.testing.assert_array_equal(a["q_latent"], b["q_latent"])
+    np.testing.assert_array_equal(a["bpp"], b["bpp"])

@@ -120,6 +120,20 @@ def test_decode_chain_matches_reference(O, name, param, T, vs, clip):
     assert np.abs(rec - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
+def test_sampler_variants_match_reference(O):
+    """Branches the test scripts do not take but the constructors default to: x-tree pred_mode="noise"
+    (xparam/modules/denoising_diffusion.py:155-156,165) and eps-tree clip_noise="half" (epsilonparam :142-143)."""
+    g = np.load(os.path.join(GOLDEN, "decode_variants.npz"))
+    for name, param, T, vs, clip, pm in (("small_x", "x", 8193, "cosine", True, "noise"),
+                                         ("small_eps", "eps", 20000, "linear", "half", None)):
+        kw, man, sd, x, time, ctx, _ = load_case(name)
+        init = synth.normal("init", x.shape, seed=1, std=0.8)
+        s = om.Schedule(T, vs, param).set_sample_schedule(3)
+        rec = om.p_sample_loop(O, oracle_cfg(kw), sd, s, x.shape, ctx, clip, init=init, pred_mode=pm)
+        ref = g[name]
+        assert np.abs(rec - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name
+
+
 def test_full_width_decode_matches_reference(O):
     for name, param, T, vs, clip in (("full_x", "x", 8193, "cosine", True),
                                      ("full_eps", "eps", 20000, "linear", "none")):
