@@ -2,17 +2,18 @@
 """bench.py -- decode throughput of the CDC hot path on MI355X.
 
 One "step" = one pass of the hot path over one batch: a full `sample_steps`-iteration DDIM decode
-(GaussianDiffusion.p_sample_loop) of `batch` synthetic 256x256 images per GPU, inputs (init noise +
-context pyramid) resident in HBM when the timed region starts.  Default workload = BASELINE.json
-configs[1]: x-param, batch 32, 256x256, 500 steps, 1 MI355X.  Multi-GPU: one process per GPU
-(torchrun), the image batch is sharded (weak scaling: 32 images per GPU), the only collective is
-the final all_gather of the decoded images over RCCL.
+(GaussianDiffusion.p_sample_loop) of `batch` synthetic images per GPU, inputs (init noise + context
+pyramid) resident in HBM when the timed region starts.  Default workload = BASELINE.json configs[1]:
+x-param, batch 32, 256x256, 500 steps, 1 MI355X.  Multi-GPU: one process per GPU (torchrun), the image
+batch is sharded (weak scaling: `batch` images per GPU) through cdc_compression_amd.parallel.sharded_decode;
+the only collective is its final all_gather of the decoded images over RCCL.
 
-    python bench.py                      # N=1, 1 timed decode (~1 min) + CPU baseline sample
+    python bench.py                      # N=1, 1 timed decode + verification + CPU baseline sample
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 1 --warmup 0
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -23,6 +24,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# canonical (reference op list, fused-minimum bytes) work per image and DDIM iteration at 256x256;
+# both scale with the pixel count.
 FULL = {
     "x": dict(kw=dict(dim=64, channels=3, context_channels=64, dim_mults=(1, 2, 3, 4, 5, 6),
                       context_dim_mults=(1, 2, 3, 4)), ctx=[64, 64, 128, 192], T=8193, vs="cosine",
@@ -32,11 +35,25 @@ FULL = {
                 gflop_per_image_step=103.39, gb_per_image_step=0.682),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak
-# The 3x3 Block convolutions run fp32-exact products on the bf16 matrix cores: every fp32 operand is the
-# exact sum of three bf16 numbers and six bf16 products reproduce the fp32 product (conv_split_kernel.h),
-# so the matrix-core ceiling for one ALGORITHMIC fp32 flop is the bf16 peak / 6.
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA peak
+# The split convolutions form every fp32 product on the 16-bit matrix cores: three fp16 MFMA products (two-plane
+# fp16 operands, CDC_ARITH_F16X2, default) or six bf16 products (exact three-plane bf16, CDC_ARITH_BF16X3) per
+# ALGORITHMIC fp32 product -- the matrix-core ceiling for algorithmic flops is the 16-bit peak / 3 resp. / 6.
+PRODUCTS = {1: 3, 0: 6}
+# the true reference (PyTorch 2.10 CPU, oneDNN) probed in the build container
+REFERENCE_PROBE = {"value": 0.003, "unit": "images/s", "cores": 8, "kind": "reference",
+                   "sample": "BASELINE.md section 2: reference compress(), B=2, 256x256, 4 of 500 steps on 8 container "
+                             "cores (0.7 s per image-step), extrapolated; NOT measured on the GPU box"}
+
+
+def workload_name(param, B, S, steps, world):
+    known = {("x", 32, 256, 500): "BASELINE configs[1]", ("eps", 32, 256, 1000): "BASELINE configs[2]",
+             ("x", 16, 512, 500): "BASELINE configs[4]"}
+    tag = known.get((param, B, S, steps))
+    if param == "x" and B == 32 and S == 256 and steps == 500 and world == 8:
+        tag = "BASELINE configs[3]"
+    return (f"{param}-param decode, batch={B}/GPU synthetic {S}x{S}, {steps} DDIM steps"
+            + (f" ({tag})" if tag else " (not a BASELINE configuration)"))
 
 
 def cpu_baseline(param, size, sample_steps, n_iter=2):
@@ -61,8 +78,9 @@ def cpu_baseline(param, size, sample_steps, n_iter=2):
     dt = (time.time() - t0) / n_iter
     return {"value": 1.0 / (dt * sample_steps), "unit": "images/s", "cores": os.cpu_count(),
             "kind": "port",
-            "sample": f"oracle/ (C+OpenMP restatement), 1 image x {n_iter} of {sample_steps} DDIM "
-                      f"iterations at {size}x{size}, {dt:.2f} s/iteration, extrapolated linearly"}
+            "sample": f"oracle/ (naive C+OpenMP restatement, slower than the oneDNN reference), 1 image x {n_iter} of "
+                      f"{sample_steps} DDIM iterations at {size}x{size}, {dt:.2f} s/iteration, extrapolated linearly",
+            "reference_probe": REFERENCE_PROBE}
 
 
 def main():
@@ -71,16 +89,19 @@ def main():
     ap.add_argument("--steps", type=int, default=1, help="timed batch decodes")
     ap.add_argument("--warmup", type=int, default=0, help="untimed batch decodes")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
-    ap.add_argument("--sample-steps", type=int, default=500)
+    ap.add_argument("--sample-steps", type=int, default=None, help="DDIM iterations (default 500 x-param, 1000 eps-param)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--param", choices=["x", "eps"], default="x")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the B=1 re-decode of two output rows")
     ap.add_argument("--prof-every", type=int, default=50)
     a = ap.parse_args()
+    if a.sample_steps is None:
+        a.sample_steps = 500 if a.param == "x" else 1000
 
     import torch
     import cdc_compression_amd as cdc
-    from cdc_compression_amd import _lib, synth
+    from cdc_compression_amd import _lib, parallel, synth
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -90,6 +111,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ       # under torchrun always (exercises the RCCL path at N=1 too)
+    dist = None
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
@@ -109,7 +131,9 @@ def main():
     init = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8          # gamma 0.8
     ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5
            for l, c in enumerate(cfgd["ctx"])]
-    shape = (B, 3, S, S)
+
+    def decode_fn(i, c, steps=None):
+        return diff.decompress(c, (c[0].shape[0], 3, S, S), sample_steps=steps or a.sample_steps, init=i)
 
     def barrier():
         torch.cuda.synchronize()
@@ -117,79 +141,147 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    diff.decompress(ctx, shape, sample_steps=2, init=init)      # builds the launch program, pages in code
+    decode_fn(init, ctx, steps=2)      # builds the launch program, pages in code
     for _ in range(a.warmup):
-        diff.decompress(ctx, shape, sample_steps=a.sample_steps, init=init)
+        decode_fn(init, ctx)
     L, h = _lib.lib(), un._handle()
     L.cdc_prof_reset(h)
     L.cdc_prof_enable(h, max(2, a.prof_every))
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        rec = diff.decompress(ctx, shape, sample_steps=a.sample_steps, init=init)
-        if use_dist:
-            gathered = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(gathered, rec)                      # the trivial result gather (RCCL)
+        # this rank's shard of the B*world-image job; the gather of the decoded images is the only collective
+        full = parallel.sharded_decode(decode_fn, init, ctx, world, rank, dist, global_batch=B * world)
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ok = bool(torch.isfinite(rec).all().item())
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+    lo, hi = parallel.shard_bounds(B * world, world, rank)
+    rec = full[lo:hi]
+    ok = bool(torch.isfinite(full).all().item()) and tuple(full.shape) == (B * world, 3, S, S)
+    arith = L.cdc_get_arith(h)
 
-    import ctypes
     classes = {}
     for c in range(L.cdc_prof_num_classes()):
         ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         L.cdc_prof_get(h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
         classes[L.cdc_prof_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value,
                                                    bytes=by.value)
+    ops = []
+    for i in range(L.cdc_prof_num_ops(h)):
+        lab, ms, n, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+        if n.value:
+            ops.append(dict(label=lab.value.decode(), ms=ms.value / n.value, n=n.value, flops=fl.value))
     L.cdc_prof_enable(h, 0)
 
     if rank == 0:
         images = B * world * a.steps
         value = images / dt
-        split = not os.environ.get("CDC_NO_SPLIT")
-        peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        dom = classes["conv3x3"]
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        products = PRODUCTS[arith]
+        peak = PEAK_16BIT_MFMA_TFLOPS / products
+        # dominant kernel = the launch shape with the largest total time among the matrix-core convolutions
+        conv_ops = [o for o in ops if o["label"].startswith("conv 3x3 s1") and o["flops"] > 0]
+        groups = {}
+        for o in conv_ops:
+            key = " ".join(o["label"].split()[:8])          # kind, stride, Cin->Cout, out HxW
+            g = groups.setdefault(key, dict(ms=0.0, n=0, flops=o["flops"], label=o["label"]))
+            g["ms"] += o["ms"]; g["n"] += 1
+        domk, dom = max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else ("", dict(ms=0, n=1, flops=0, label=""))
+        dom_ms = dom["ms"] / max(dom["n"], 1)
+        ach = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        cls3 = classes["conv3x3"]
+        cls_ach = cls3["flops"] / (cls3["ms"] * 1e-3) / 1e12 if cls3["ms"] > 0 else 0.0
         tot_ms = sum(c["ms"] for c in classes.values())
+        n_prof_iters = max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps)
+        scale = (S / 256.0) ** 2
+        canon_tf = cfgd["gflop_per_image_step"] * scale * 1e-3 * a.sample_steps * value
+        exec_gflop_iter = sum(c["flops"] for c in classes.values()) / n_prof_iters / 1e9     # per batch iteration
+        exec_tf = exec_gflop_iter * 1e-3 / B * a.sample_steps * value
+        # counter-based HBM traffic of the dominant launch shape, if a PMC pass of THIS build was committed
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_r02_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                want = f"B{B} " + " ".join(dom["label"].split()[:8])
+                if tj.get("launch") == want and tj.get("arith") == arith:
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("source")
+            except Exception:
+                pass
+        pixels_out = 0
+        try:
+            hw = dom["label"].split("out")[1].split()[0].split("x")
+            cio = dom["label"].split()[3].split("->")
+            pixels_out = int(hw[0]) * int(hw[1])
+            alg_bytes = 4.0 * B * pixels_out * (int(cio[0]) + int(dom["label"].split("->")[1].split()[0]))
+        except Exception:
+            alg_bytes = None
         out = {
             "metric": f"decoded images/sec at {S}x{S}, {a.sample_steps}-step {a.param}-param",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "float32 tensors and accumulation; k x k convolution products as exact 3-way bf16 splits",
-            "config": {"workload": f"{a.param}-param decode, batch={B}/GPU synthetic {S}x{S}, "
-                                   f"{a.sample_steps} DDIM steps (BASELINE configs[1] shape)",
-                       "batch_per_gpu": B, "global_batch": B * world, "sample_steps": a.sample_steps,
-                       "parallelism": f"batch-shard x{world}", "finite": ok},
+            "dtype_note": ("float32 tensors and accumulation; convolution products formed on the 16-bit matrix cores from "
+                           + ("two-plane fp16 split operands (3 MFMA products per fp32 product)" if arith == 1 else
+                              "exact three-plane bf16 split operands (6 MFMA products per fp32 product)")),
+            "config": {"workload": workload_name(a.param, B, S, a.sample_steps, world),
+                       "batch_per_gpu": B, "global_batch": B * world, "sample_steps": a.sample_steps, "size": S,
+                       "parallelism": f"batch-shard x{world}", "finite": ok, "rccl_ranks_seen": ranks_seen,
+                       "arith": "f16x2" if arith == 1 else "bf16x3"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": ("conv_split2_kernel / conv_split_kernel (3x3 Block convolutions, fused LN epilogue; "
-                           "3-way bf16 split operands, 6 bf16 MFMA products per fp32 product, f32 accumulate)"
-                           if split else "conv_mfma_kernel (3x3 Block convolutions, v_mfma_f32_32x32x2_f32)"),
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 products per algorithmic fp32 product"
-                               if split else "157.3 TFLOP/s dense f32-input MFMA"),
+                "kernel": dom["label"],
+                "kernel_note": "dominant launch shape (largest total time among the 3x3 Block convolutions, fused LN "
+                               "epilogue); achieved = its algorithmic flops / its hipEvent-timed average duration",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0,
+                "peak_basis": f"2500 TFLOP/s dense 16-bit MFMA / {products} products per algorithmic fp32 product",
+                "mfma_tflops_executed": ach * products,
                 "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
-                "traffic": None,
-                # PMC pass of the dominant launch shape, collected separately (rocprofv3 --pmc FETCH_SIZE /
-                # WRITE_SIZE, gfx950 x2 read correction): profiles/pmc_r01_v6_conv3x3_64_256_traffic.txt
-                "traffic_sample": {"launch": "conv_split2_kernel<2,2,0>, 64->64 3x3 @256x256, batch 32",
-                                   "hbm_bytes": 1.0998e9, "algorithmic_bytes": 1.0737e9},
-                "whole_path_tflops": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value,
-                # both whole-path terms on the canonical (fused-minimum) work
-                "whole_path_mfma_frac_of_split_peak": cfgd["gflop_per_image_step"] * 1e-3 * a.sample_steps * value / peak,
-                "whole_path_hbm_frac": ((cfgd["gb_per_image_step"] + 0.160 / B) * 1e9 * a.sample_steps * value) / 8e12,
+                "avg_launch_ms": dom_ms, "launches_per_iteration": dom["n"],
+                "flops_per_launch": dom["flops"], "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "class_conv3x3": {"achieved": cls_ach, "frac": cls_ach / peak if peak else 0,
+                                  "avg_launch_ms": cls3["ms"] / max(cls3["launches"], 1),
+                                  "flops_per_launch": cls3["flops"] / max(cls3["launches"], 1)},
+                # whole-path terms.  canonical = the reference's op list (what a user gets per image);
+                # executed = what the launch program really multiplies (context hoisting removes ~25 %)
+                "whole_path_tflops_canonical": canon_tf,
+                "whole_path_tflops_executed": exec_tf,
+                "whole_path_mfma_frac_canonical": canon_tf / peak, "whole_path_mfma_frac_executed": exec_tf / peak,
+                "whole_path_hbm_frac": ((cfgd["gb_per_image_step"] * scale + 0.160 / B) * 1e9 * a.sample_steps * value) / 8e12,
+                "whole_path_hbm_note": "north_star's >= 40 % of the HBM roofline is not reachable in fp32-class arithmetic "
+                                       "(AI ~180 flop/B vs a ridge of ~100-300): the path is matrix-bound (SURVEY section 7)",
                 "class_ms_share": {k: (v["ms"] / tot_ms if tot_ms else 0) for k, v in classes.items()},
                 "class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
                                  for k, v in classes.items()},
+                "class_ms_per_ddim_iter": {k: v["ms"] / n_prof_iters for k, v in classes.items()},
+                "ms_per_ddim_iter": dt / a.steps / a.sample_steps * 1e3,
             },
         }
+        if world == 1 and not a.no_verify:
+            # Verification + batch-1 latency (what test_xparam.py runs: one image per call): rows 0 and B-1 of the
+            # timed decode are decoded again on their own (different launch plans) and must agree.
+            rows, errs, t1 = (0, B - 1), [], 0.0
+            for k in rows:
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                r1 = decode_fn(init[k:k + 1], [c[k:k + 1] for c in ctx])
+                torch.cuda.synchronize()
+                t1 += time.perf_counter() - ta
+                den = max(1.0, float(rec[k].abs().max().item()))
+                errs.append(float((r1[0] - rec[k]).abs().max().item()) / den)
+            out["verify"] = {"rows": list(rows), "max_rel_err_vs_batch1_decode": max(errs), "tolerance": 1e-4,
+                             "ok": bool(max(errs) <= 1e-4)}
+            out["batch1"] = {"images_per_s": len(rows) / t1, "ms_per_ddim_iter": t1 / len(rows) / a.sample_steps * 1e3,
+                             "note": "one image per call, same model and step count (the reference test scripts' mode)"}
+            out["config"]["finite"] = ok and out["verify"]["ok"]
         if world == 1 and a.param == "x" and S % 64 == 0:
             # informational (outside the timed region): the compressor on the GPU -- Compressor.forward (analysis
             # transform, hyper encoder/decoder, quantisers, rate estimate, synthesis transform) and decode alone
@@ -227,7 +319,6 @@ def main():
                                                  "once per image, not in `value`"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
-        out["roofline"]["class_ms_per_ddim_iter"] = {k: v["ms"] / max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps) for k, v in classes.items()}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

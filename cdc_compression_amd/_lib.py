@@ -106,6 +106,9 @@ def lib():
                                ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
                                ctypes.POINTER(ctypes.c_double)]
     L.cdc_prof_reset.argtypes = [H]
+    L.cdc_prof_num_ops.argtypes = [H]
+    L.cdc_prof_op.argtypes = [H, _i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
+                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     L.cdc_op_conv2d.argtypes = [H, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp, _i, _vp, _vp]
     L.cdc_op_conv_transpose2d.argtypes = [H, _vp, _vp, _vp, _vp] + [_i] * 5
     L.cdc_op_chan_layernorm.argtypes = [H, _vp, _vp, _vp, _vp, _i, _i, _i]
@@ -121,7 +124,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_op_conv2d", "cdc_op_conv_transpose2d", "cdc_op_chan_layernorm",
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
-           "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap"]
+           "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap", "cdc_prof_num_ops", "cdc_prof_op"]
 
 
 def check(handle, rc):

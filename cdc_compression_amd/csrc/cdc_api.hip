@@ -658,13 +658,17 @@ struct Builder {
                     long long ps() const { return (long long)(H + 2) * (W + 2); }
                     long long bs() const { return (long long)(C / 8) * 2 * ps(); } };
     std::map<const float *, PfTwin> pfmap;
-    // Opt-in (CDC_PF=1): the kernel's main loop is ~20 % faster than the register-staged split kernel, but every
-    // tensor that is also needed in fp32 (residual stream, attention input) is then written twice, and at batch 32
-    // the extra HBM writes cost slightly more than the main loop gains (3.64 vs 3.75 images/s, round 2).
+    // Opt-in (CDC_PF=1).  The kernel's main loop is 20-30 % faster than the register-staged split kernel (more on
+    // long-K layers: 256->64 @128^2 0.56 -> 0.42 ms, 1x1 384->128 @64^2 0.131 -> 0.078 ms), but every tensor that is also
+    // needed in fp32 (residual stream, attention input, stride-2 / transposed convolutions) is then written twice, and
+    // at batch 32 those extra HBM writes in the producers cost as much as the consumers gain (round 2: 3.64 images/s
+    // with planes everywhere, 3.68 with planes up to 128 x 128 (CDC_PF_MAXPIX), 3.75 without).  It pays once the
+    // remaining fp32 consumers read planes too.
     bool pf_on() const { const char *e = getenv("CDC_PF"); return h->arith == 1 && e && atoi(e); }
+    static long long pf_maxpix() { const char *e = getenv("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
     PfTwin *twin(const float *p) { auto it = pfmap.find(p); return it == pfmap.end() ? nullptr : &it->second; }
     void add_twin(const float *p, int C, int H, int W) {
-        if (rc || !p || !pf_on() || (C % 16) || W < 32 || H < 2) return;
+        if (rc || !p || !pf_on() || (C % 16) || W < 32 || H < 2 || (long long)H * W > pf_maxpix()) return;
         PfTwin t; t.C = C; t.H = H; t.W = W;
         const size_t bytes = (size_t)B * t.bs() * 16;
         void *q = nullptr;
@@ -2345,6 +2349,17 @@ int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *
     if (launches) *launches = h->prof_launches[cls];
     if (flops) *flops = h->prof_flops[cls];
     if (bytes) *bytes = h->prof_bytes[cls];
+    return CDC_OK;
+}
+int cdc_prof_num_ops(cdc_handle *h) { return h ? (int)h->op_ms.size() : CDC_ERR_INVALID; }
+int cdc_prof_op(cdc_handle *h, int idx, const char **label, double *ms, int64_t *launches, double *flops) {
+    if (!h || idx < 0 || idx >= (int)h->op_ms.size()) return CDC_ERR_INVALID;
+    int rc = resolve_pending(h);
+    if (rc) return rc;
+    if (label) *label = h->op_label[idx].c_str();
+    if (ms) *ms = h->op_ms[idx];
+    if (launches) *launches = h->op_n[idx];
+    if (flops) *flops = h->op_flops[idx];
     return CDC_OK;
 }
 int cdc_prof_reset(cdc_handle *h) {

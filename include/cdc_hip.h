@@ -239,6 +239,10 @@ const char *cdc_prof_name(int cls);
 int cdc_prof_get(cdc_handle *h, int cls, double *ms, int64_t *launches, double *flops,
                  double *bytes);
 int cdc_prof_reset(cdc_handle *h);
+/* Per-launch view of the same events: one entry per kernel launch of the current program (label = kernel kind,
+ * shape and launch plan; ms = accumulated GPU time over `launches` instrumented executions; flops per execution). */
+int cdc_prof_num_ops(cdc_handle *h);
+int cdc_prof_op(cdc_handle *h, int idx, const char **label, double *ms, int64_t *launches, double *flops);
 
 /* ---- single operators (used by the parity tests; same kernels the U-Net graph launches) ------ */
 
