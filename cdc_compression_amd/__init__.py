@@ -4,3 +4,4 @@ C-ABI (include/cdc_hip.h), with host-side mirrors of the reference's Unet / Gaus
 from .unet import Unet  # noqa: F401
 from .diffusion import GaussianDiffusionEps, GaussianDiffusionX  # noqa: F401
 from .compressor import BigCompressor, ResnetCompressor  # noqa: F401
+from . import epsilonparam, xparam  # noqa: F401,E402  (drop-in names of the reference trees)

@@ -751,3 +751,47 @@ def test_bench_under_torchrun_one_rank_nccl(tmp_path):
     assert d["n_gpus"] == 1 and d["config"]["rccl_ranks_seen"] == 1
     assert d["config"]["global_batch"] == 3 and d["config"]["finite"] is True
     assert d["value"] > 0 and d["roofline"]["achieved"] >= 0
+
+
+def test_inference_script_counterpart_on_kodak_crops(tmp_path):
+    """examples/test_xparam.py = the reference's test_xparam.py on this path: argument set, EMA checkpoint layout
+    ("ema_model." prefix, wrapper entries ignored), uint8/255*2-1 scaling, printed bpp.  Driven on two of the Kodak
+    crops with the fixture's parameters stored as a checkpoint file; the printed bpp must be the reference's."""
+    import subprocess
+    import sys
+    import torch
+    from PIL import Image
+    g = np.load(os.path.join(GOLDEN, "kodak_x_500.npz"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kw, man, usd, _, _, _, _ = load_case("full_x")
+    meta = json.load(open(os.path.join(GOLDEN, "manifest_encoder_full_x.json")))
+    csd = synth.unet_state_dict([(k, tuple(v)) for k, v in meta["manifest"]], seed=15)
+    ema = {"initted": torch.tensor(True), "step": torch.tensor(12345)}
+    for k, v in usd.items():
+        ema["ema_model.denoise_fn." + k] = torch.from_numpy(np.asarray(v))
+        ema["online_model.denoise_fn." + k] = torch.zeros(1)                 # wrapper entries: must be ignored
+    for k, v in csd.items():
+        ema["ema_model.context_fn." + k] = torch.from_numpy(np.asarray(v))
+    ema["ema_model.train_betas"] = torch.zeros(8193)                          # derived buffers: ignored
+    ckpt = tmp_path / "ckpt.pt"
+    torch.save({"step": 1, "ema": ema}, ckpt)
+    imgs, outs = tmp_path / "imgs", tmp_path / "out"
+    imgs.mkdir()
+    for i in range(2):
+        Image.fromarray(g["crops"][i]).save(imgs / f"{i}.png")
+    cmd = [sys.executable, os.path.join(root, "examples", "test_xparam.py"), "--ckpt", str(ckpt), "--lpips_weight", "0.0",
+           "--n_denoise_step", "6", "--img_dir", str(imgs), "--out_dir", str(outs), "--seed", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bpps = [float(l.split("bpp:")[1].strip().strip("tensor()").split(",")[0].strip("[]() "))
+            for l in r.stdout.splitlines() if l.startswith("bpp:")]
+    assert len(bpps) == 2
+    for i in range(2):
+        assert abs(bpps[i] - float(g["bpp"][i])) <= 1e-5 * float(g["bpp"][i]), (i, bpps[i], float(g["bpp"][i]))
+        out = np.asarray(Image.open(outs / f"{i}.png"))
+        assert out.shape == (256, 256, 3) and out.dtype == np.uint8
+    r2 = subprocess.run([sys.executable, os.path.join(root, "examples", "test_epsilonparam.py"), "--ckpt", "synthetic",
+                         "--lpips_weight", "0.0", "--n_denoise_step", "4", "--img_dir", str(imgs), "--out_dir",
+                         str(tmp_path / "out_eps"), "--seed", "3"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert len([l for l in r2.stdout.splitlines() if l.startswith("bpp:")]) == 2
