@@ -378,6 +378,64 @@ class _ContextDecoder:
                      "latent_distribution": NormalDistribution(mean, scale)}
         return q_latent, q_hyper_latent, state4bpp
 
+    # ---- entropy coder (no reference counterpart) ---------------------
+    def _median_vector(self):
+        C = self.reversed_hyper_dims[0]
+        med = self._medians.reshape(-1) if self._medians is not None else np.zeros(C, np.float32)
+        return np.ascontiguousarray(med, dtype=np.float32)
+
+    def compress_to_bytes(self, images):
+        """images [B, 3, H, W] -> list of B bitstreams (bytes): analysis transform + hyper encoder on the GPU, then the
+        range-ANS coder of include/cdc_hip.h (cdc_entropy_encode) over exactly the symbols `bpp()` prices."""
+        L, h = _lib.lib(), self._hyper_handle()
+        if not (self._hyper_finalized and self._prior_loaded):
+            raise _lib.CdcError("the prior.* tensors have not been loaded (load_state_dict with the full state_dict)")
+        latent, hyper = self.analysis(images)
+        al, ah = _Arg(latent, self.device_index), _Arg(hyper, self.device_index)
+        B, _, hh, wh = ah.shape
+        nsym = int(np.prod(al.shape[1:])) + int(np.prod(ah.shape[1:]))
+        cap = B * (64 + 4 * nsym)
+        buf = (ctypes.c_ubyte * cap)()
+        offs = (ctypes.c_size_t * (B + 1))()
+        med = self._median_vector()
+        _lib.check(h, L.cdc_entropy_encode(h, al.ptr, ah.ptr, med.ctypes.data, B, hh, wh, buf, cap, offs, al.mem,
+                                           _current_stream(al.mem)))
+        raw = bytes(buf[: offs[B]])
+        return [raw[offs[b]: offs[b + 1]] for b in range(B)]
+
+    def decompress_from_bytes(self, streams, like=None, return_hyper=False):
+        """list of B bitstreams -> q_latent [B, C, h, w] exactly as the encoder dequantised it (numpy, or a tensor on
+        `like`'s device); all streams must have the same latent size."""
+        L, h = _lib.lib(), self._hyper_handle()
+        if not (self._hyper_finalized and self._prior_loaded):
+            raise _lib.CdcError("the prior.* tensors have not been loaded (load_state_dict with the full state_dict)")
+        streams = [bytes(s) for s in streams]
+        B = len(streams)
+        hh, wh, ar = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        dims = set()
+        for s in streams:
+            if L.cdc_entropy_peek(s, len(s), ctypes.byref(hh), ctypes.byref(wh), ctypes.byref(ar)) != 0:
+                raise _lib.CdcError("not a CDC bitstream")
+            dims.add((hh.value, wh.value))
+        if len(dims) != 1:
+            raise _lib.CdcError("the streams of one call must share the latent size")
+        hh, wh = dims.pop()
+        up = 2 ** (len(self.reversed_hyper_dims) - 2)
+        C = self.reversed_hyper_dims[-1] // 2
+        proto = like if like is not None else np.empty(0, np.float32)
+        q, pq, mem = _result_like(proto, (B, C, hh * up, wh * up), self.device_index)
+        qh, ph, _ = _result_like(proto, (B, self.reversed_hyper_dims[0], hh, wh), self.device_index)
+        blob = b"".join(streams)
+        offs = (ctypes.c_size_t * (B + 1))()
+        pos = 0
+        for b, s in enumerate(streams):
+            offs[b] = pos
+            pos += len(s)
+        offs[B] = pos
+        med = self._median_vector()
+        _lib.check(h, L.cdc_entropy_decode(h, blob, offs, med.ctypes.data, B, pq, ph, mem, _current_stream(mem)))
+        return (q, qh) if return_hyper else q
+
     def forward(self, input, cond=None):
         """Compressor.forward (compress_modules.py:92-103)."""
         q_latent, q_hyper_latent, state4bpp = self.encode(input, cond)

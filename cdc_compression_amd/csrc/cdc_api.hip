@@ -15,6 +15,7 @@
 
 #include "../../include/cdc_hip.h"
 #include "cdc_internal.h"
+#include "entropy.h"
 
 using namespace cdc;
 
@@ -104,6 +105,8 @@ struct cdc_handle {
     std::vector<int> hyper_dims;  // kind 2: reversed_hyper_dims
     std::vector<ConvW> hconvs;    // kind 2: packed layers
     float *d_prior = nullptr;     // kind 2: FlexiblePrior per channel, 44 floats (softplus / tanh applied), or null
+    std::vector<double> h_prior;  // kind 2: the same in float64 (probability tables of the entropy coder)
+    std::unique_ptr<cdc::EntropyModel> ent;   // kind 2: entropy coder tables (built on first use)
     std::vector<int> rev_dims;    // kind 1: [dim*m for m in rev_mults] + [out_channels]
     int up_index = 1;
     std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
@@ -1759,10 +1762,14 @@ int cdc_finalize_weights(cdc_handle *h) {
             // tanh(a2)[3] | softplus(W3)[3] b3[1] | pad  = 44 floats  (PriorFunction.forward, FlexiblePrior.cdf)
             const int pc = h->hyper_dims[0];
             std::vector<float> pk((size_t)pc * 44, 0.f);
+            h->h_prior.assign((size_t)pc * 44, 0.0);
+            h->ent.reset();
             auto sp = [](float v) { return v > 20.f ? v : (float)log1p(exp((double)v)); };      // F.softplus (threshold 20)
+            auto spd = [](float v) { return v > 20.f ? (double)v : log1p(exp((double)v)); };
             const int pd[5] = {1, 3, 3, 3, 1};
             for (int c = 0; c < pc; ++c) {
                 float *o = &pk[(size_t)c * 44];
+                double *od = &h->h_prior[(size_t)c * 44];
                 for (int i = 0; i < 4; ++i) {
                     const std::string pi = "prior.affine." + std::to_string(i);
                     for (const char *suf : {".weight", ".bias"})
@@ -1770,13 +1777,13 @@ int cdc_finalize_weights(cdc_handle *h) {
                     const auto &w = hostp(h, pi + ".weight");
                     const auto &bb = hostp(h, pi + ".bias");
                     const int nin = pd[i], nout = pd[i + 1];
-                    for (int k = 0; k < nin * nout; ++k) *o++ = sp(w[(size_t)c * nin * nout + k]);
-                    for (int k = 0; k < nout; ++k) *o++ = bb[(size_t)c * nout + k];
+                    for (int k = 0; k < nin * nout; ++k) { *o++ = sp(w[(size_t)c * nin * nout + k]); *od++ = spd(w[(size_t)c * nin * nout + k]); }
+                    for (int k = 0; k < nout; ++k) { *o++ = bb[(size_t)c * nout + k]; *od++ = (double)bb[(size_t)c * nout + k]; }
                     if (i < 3) {
                         const std::string ai = "prior.a." + std::to_string(i);
                         if (!h->params[h->pindex.at(ai)].loaded) return fail(h, CDC_ERR_STATE, "missing key \"%s\"", ai.c_str());
                         const auto &a = hostp(h, ai);
-                        for (int k = 0; k < nout; ++k) *o++ = (float)tanh((double)a[(size_t)c * nout + k]);
+                        for (int k = 0; k < nout; ++k) { *o++ = (float)tanh((double)a[(size_t)c * nout + k]); *od++ = tanh((double)a[(size_t)c * nout + k]); }
                     }
                 }
             }
@@ -2016,6 +2023,182 @@ int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean,
         if ((rc = copy_out(h, mean + (size_t)b * half, o.p + (size_t)b * o.bs(), (size_t)half, mem, st))) return rc;
         if ((rc = copy_out(h, scale + (size_t)b * half, o.p + (size_t)b * o.bs() + half, (size_t)half, mem, st))) return rc;
     }
+    return CDC_OK;
+}
+
+// ---- entropy coder (entropy.hip) ---------------------------------------------------------
+namespace {
+constexpr int kStreamHeader = 18;     // 'C' 'D' 'C' 1 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32
+
+int ensure_entropy(cdc_handle *h, const float *medians) {
+    if (h->kind != 2) return fail(h, CDC_ERR_STATE, "handle is not a hyper decoder");
+    if (h->h_prior.empty()) return fail(h, CDC_ERR_STATE, "the prior.* tensors were not loaded");
+    const int C = h->hyper_dims[0];
+    if (!h->ent) h->ent.reset(new cdc::EntropyModel);
+    cdc::entropy_init(h->ent.get());
+    if ((int)h->ent->medians.size() != C || memcmp(h->ent->medians.data(), medians, sizeof(float) * C) != 0)
+        cdc::entropy_build_hyper(h->ent.get(), h->h_prior.data(), medians, C);
+    if (!h->ent->d_edges) {
+        int rc = upload(h, h->ent->edges, cdc::kEntropyBins, &h->ent->d_edges, &h->weight_allocs);
+        if (rc) return rc;
+    }
+    return CDC_OK;
+}
+
+// hyper_dec on ONE image (the batch-1 launch program, see the contract in entropy.hip): q_hyper (host) -> device mean / scale
+int hyperdec_one(cdc_handle *h, const float *qh_host, int hh, int wh, hipStream_t st, const float **mean, const float **scale,
+                 long long *nl) {
+    int rc = build_hyperdec_program(h, 1, hh, wh);
+    if (rc) return rc;
+    const size_t nh = (size_t)h->hyper_dims[0] * hh * wh;
+    HIP_TRY(h, hipMemcpyAsync(h->in_x, qh_host, nh * sizeof(float), hipMemcpyHostToDevice, st));
+    h->prof_now = false;
+    for (const Op &op : h->ops)
+        if ((rc = run_op(h, op, 1, st))) return rc;
+    const Act &o = h->dec_outs[0];
+    const long long half = (long long)(o.C / 2) * o.H * o.W;
+    HIP_TRY(h, clamp_min_launch(o.p + half, o.bs(), half, 0.1f, 1, st));       // scale.clamp(min=0.1), compress_modules.py:59
+    *mean = o.p; *scale = o.p + half; *nl = half;
+    return CDC_OK;
+}
+}  // namespace
+
+int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
+                       int hh, int wh, unsigned char *out, size_t cap, size_t *offsets, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!latent || !hyper_latent || !medians || !out || !offsets || B < 1 || hh < 1 || wh < 1 || hh > 65535 || wh > 65535)
+        return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    if ((rc = ensure_entropy(h, medians))) return rc;
+    hipStream_t st = h->own_stream;                       // synchronous entry point: the coder runs on the host
+    if (mem == CDC_MEM_DEVICE) HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    const int Ch = h->hyper_dims[0];
+    const size_t nh = (size_t)Ch * hh * wh;
+    std::vector<float> hl(nh), qh(nh);
+    std::vector<int32_t> sh(nh), sl;
+    std::vector<uint8_t> bins, bytes_h, bytes_l;
+    std::vector<const cdc::EntropyTable *> tabs;
+    void *d_sym = nullptr, *d_bin = nullptr, *d_lat = nullptr;
+    size_t pos = 0;
+    offsets[0] = 0;
+    auto cleanup = [&]() { if (d_sym) (void)hipFree(d_sym); if (d_bin) (void)hipFree(d_bin); if (d_lat) (void)hipFree(d_lat); };
+    for (int b = 0; b < B; ++b) {
+        if (mem == CDC_MEM_DEVICE) { HIP_TRY(h, hipMemcpy(hl.data(), hyper_latent + (size_t)b * nh, nh * sizeof(float), hipMemcpyDeviceToHost)); }
+        else memcpy(hl.data(), hyper_latent + (size_t)b * nh, nh * sizeof(float));
+        for (int c = 0; c < Ch; ++c)
+            for (int i = 0; i < hh * wh; ++i) {
+                const size_t k = (size_t)c * hh * wh + i;
+                const float r = rintf(hl[k] - medians[c]);          // quantize(x, "dequantize", medians) (utils.py:72-85)
+                sh[k] = (int32_t)r;
+                qh[k] = r + medians[c];
+            }
+        const float *dmean, *dscale;
+        long long nl;
+        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl))) { cleanup(); return rc; }
+        if (!d_sym) {
+            HIP_TRY(h, hipMalloc(&d_sym, nl * sizeof(int32_t)));
+            HIP_TRY(h, hipMalloc(&d_bin, nl));
+            if (mem == CDC_MEM_HOST) HIP_TRY(h, hipMalloc(&d_lat, nl * sizeof(float)));
+        }
+        const float *dl = latent + (size_t)b * nl;
+        if (mem == CDC_MEM_HOST) {
+            HIP_TRY(h, hipMemcpyAsync(d_lat, dl, nl * sizeof(float), hipMemcpyHostToDevice, st));
+            dl = (const float *)d_lat;
+        }
+        HIP_TRY(h, cdc::latent_symbols_launch(dl, dmean, dscale, h->ent->d_edges, nl, (int32_t *)d_sym, (uint8_t *)d_bin, st));
+        sl.resize(nl); bins.resize(nl);
+        HIP_TRY(h, hipMemcpyAsync(sl.data(), d_sym, nl * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(bins.data(), d_bin, nl, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        tabs.resize(nh);
+        for (int c = 0; c < Ch; ++c)
+            for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
+        cdc::entropy_encode_symbols(sh.data(), nh, tabs, &bytes_h);
+        tabs.resize(nl);
+        for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
+        cdc::entropy_encode_symbols(sl.data(), (size_t)nl, tabs, &bytes_l);
+        const size_t need = kStreamHeader + bytes_h.size() + bytes_l.size();
+        if (pos + need > cap) { cleanup(); return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: image %d needs %zu bytes at offset %zu of %zu", b, need, pos, cap); }
+        unsigned char *o = out + pos;
+        o[0] = 'C'; o[1] = 'D'; o[2] = 'C'; o[3] = 1; o[4] = (unsigned char)h->arith; o[5] = 0;
+        o[6] = (unsigned char)(hh & 255); o[7] = (unsigned char)(hh >> 8); o[8] = (unsigned char)(wh & 255); o[9] = (unsigned char)(wh >> 8);
+        const uint32_t a = (uint32_t)bytes_h.size(), bl = (uint32_t)bytes_l.size();
+        for (int i = 0; i < 4; ++i) { o[10 + i] = (unsigned char)(a >> (8 * i)); o[14 + i] = (unsigned char)(bl >> (8 * i)); }
+        memcpy(o + kStreamHeader, bytes_h.data(), bytes_h.size());
+        memcpy(o + kStreamHeader + bytes_h.size(), bytes_l.data(), bytes_l.size());
+        pos += need;
+        offsets[b + 1] = pos;
+    }
+    cleanup();
+    return CDC_OK;
+}
+
+int cdc_entropy_peek(const unsigned char *in, size_t n, int *hh, int *wh, int *arith) {
+    if (!in || n < (size_t)kStreamHeader || in[0] != 'C' || in[1] != 'D' || in[2] != 'C' || in[3] != 1) return CDC_ERR_INVALID;
+    if (arith) *arith = in[4];
+    if (hh) *hh = in[6] | (in[7] << 8);
+    if (wh) *wh = in[8] | (in[9] << 8);
+    return CDC_OK;
+}
+
+int cdc_entropy_decode(cdc_handle *h, const unsigned char *in, const size_t *offsets, const float *medians, int B,
+                       float *q_latent, float *q_hyper_latent, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!in || !offsets || !medians || !q_latent || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    if ((rc = ensure_entropy(h, medians))) return rc;
+    hipStream_t st = h->own_stream;
+    const int Ch = h->hyper_dims[0];
+    std::vector<int32_t> sh, sl;
+    std::vector<float> qh;
+    std::vector<uint8_t> bins;
+    std::vector<const cdc::EntropyTable *> tabs;
+    void *d_sym = nullptr, *d_bin = nullptr, *d_q = nullptr;
+    auto cleanup = [&]() { if (d_sym) (void)hipFree(d_sym); if (d_bin) (void)hipFree(d_bin); if (d_q) (void)hipFree(d_q); };
+    for (int b = 0; b < B; ++b) {
+        const unsigned char *s = in + offsets[b];
+        const size_t n = offsets[b + 1] - offsets[b];
+        int hh, wh, ar;
+        if (cdc_entropy_peek(s, n, &hh, &wh, &ar)) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: not a CDC bitstream", b); }
+        if (ar != h->arith) {
+            // the decoder must run hyper_dec in the encoder's arithmetic (see the contract in entropy.hip)
+            if ((rc = cdc_set_arith(h, ar))) { cleanup(); return rc; }
+        }
+        uint32_t nbh = 0, nbl = 0;
+        for (int i = 0; i < 4; ++i) { nbh |= (uint32_t)s[10 + i] << (8 * i); nbl |= (uint32_t)s[14 + i] << (8 * i); }
+        if ((size_t)kStreamHeader + nbh + nbl != n) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: truncated bitstream", b); }
+        const size_t nh = (size_t)Ch * hh * wh;
+        sh.resize(nh); qh.resize(nh); tabs.resize(nh);
+        for (int c = 0; c < Ch; ++c)
+            for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
+        if (!cdc::entropy_decode_symbols(s + kStreamHeader, nbh, nh, tabs, sh.data())) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: corrupt hyper stream", b); }
+        for (int c = 0; c < Ch; ++c)
+            for (int i = 0; i < hh * wh; ++i) { const size_t k = (size_t)c * hh * wh + i; qh[k] = (float)sh[k] + medians[c]; }
+        const float *dmean, *dscale;
+        long long nl;
+        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl))) { cleanup(); return rc; }
+        if (!d_sym) {
+            HIP_TRY(h, hipMalloc(&d_sym, nl * sizeof(int32_t)));
+            HIP_TRY(h, hipMalloc(&d_bin, nl));
+            HIP_TRY(h, hipMalloc(&d_q, nl * sizeof(float)));
+        }
+        HIP_TRY(h, cdc::latent_symbols_launch(nullptr, dmean, dscale, h->ent->d_edges, nl, nullptr, (uint8_t *)d_bin, st));
+        bins.resize(nl); sl.resize(nl); tabs.resize(nl);
+        HIP_TRY(h, hipMemcpyAsync(bins.data(), d_bin, nl, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
+        if (!cdc::entropy_decode_symbols(s + kStreamHeader + nbh, nbl, (size_t)nl, tabs, sl.data())) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: corrupt latent stream", b); }
+        HIP_TRY(h, hipMemcpyAsync(d_sym, sl.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, cdc::symbols_to_latent_launch((const int32_t *)d_sym, dmean, nl, (float *)d_q, st));
+        HIP_TRY(h, hipMemcpyAsync(q_latent + (size_t)b * nl, d_q, nl * sizeof(float),
+                                  mem == CDC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        if (q_hyper_latent)
+            HIP_TRY(h, hipMemcpyAsync(q_hyper_latent + (size_t)b * nh, qh.data(), nh * sizeof(float),
+                                      mem == CDC_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    cleanup();
+    (void)stream;
     return CDC_OK;
 }
 

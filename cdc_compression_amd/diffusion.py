@@ -137,6 +137,11 @@ class _GaussianDiffusionBase:
         """Decode half of compress(): context pyramid (= context_fn(...)["output"]) -> image.  `context`
         may also be the transmitted q_latent tensor [B, C, H/16, W/16]: it then goes through
         `context_fn.decode` first (compress_modules.py:68-74; cdc_compression_amd.compressor on the GPU)."""
+        if isinstance(context, (bytes, bytearray)):
+            context = [context]
+        if isinstance(context, (list, tuple)) and context and isinstance(context[0], (bytes, bytearray)):
+            # entropy-coded bitstreams (compress_to_bytes): range-ANS decode -> q_latent
+            context = self.context_fn.decompress_from_bytes(context, like=init)
         if not isinstance(context, (list, tuple)):
             if self.context_fn is None or not hasattr(self.context_fn, "decode"):
                 raise RuntimeError("decompress(q_latent, ...) needs a context_fn with decode()")
@@ -145,6 +150,12 @@ class _GaussianDiffusionBase:
         if clip_denoised is None:
             clip_denoised = True if self._param == "x" else getattr(self, "clip_noise", "none")
         return self._loop(tuple(shape), context, clip_denoised, init, eta)
+
+
+    def compress_to_bytes(self, images):
+        """The transmitted half of compress(): images -> one entropy-coded bitstream per image.
+        `decompress(streams, shape, sample_steps, init)` reconstructs from them."""
+        return self.context_fn.compress_to_bytes(images)
 
 
 class GaussianDiffusionX(_GaussianDiffusionBase):

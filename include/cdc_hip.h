@@ -24,6 +24,7 @@
 #ifndef CDC_HIP_H
 #define CDC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -222,6 +223,25 @@ int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean,
 int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, const float *mean,
             const float *scale, float *bpp, int B, int h_hyper, int w_hyper, int H_img, int W_img, int mem_kind,
             void *stream);
+
+/* ---- entropy coder -- no reference counterpart: the reference only estimates the rate ------
+ * Codes exactly the symbols Compressor.bpp prices (compress_modules.py:76-90) with exactly its two models:
+ *   q_hyper_latent - medians   under FlexiblePrior.likelihood (network_components.py:372-378), one table per channel;
+ *   q_latent - mean            under NormalDistribution(mean, scale).likelihood (utils.py:147-159), tables by scale,
+ * byte-wise range-ANS, 16-bit probabilities (table specification: csrc/entropy.hip; restated in oracle/entropy_oracle.c,
+ * streams agree byte for byte).  Entry points of a hyper-decoder handle (cdc_hyperdec_create) that has the prior.* tensors.
+ * latent / hyper_latent are the UNquantised encoder outputs (cdc_encoder_encode); medians [dims[0]] is a host array.
+ * out receives B concatenated streams, image b at [offsets[b], offsets[b+1]) (offsets has B+1 entries).  Each stream:
+ *   'C' 'D' 'C' 1 | arith u8 | 0 | h_hyper u16 | w_hyper u16 | n_hyper u32 | n_latent u32 | hyper bytes | latent bytes.
+ * Encoder and decoder run hyper_dec one image at a time (batch-1 launch plan) in the arithmetic the header records, so
+ * that the decoder reproduces the encoder's (mean, scale) bit for bit -- the contract every learned codec has.
+ * Synchronous; latent / hyper_latent / q_latent / q_hyper_latent follow `mem`, in / out / offsets / medians are host. */
+int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
+                       int h_hyper, int w_hyper, unsigned char *out, size_t cap, size_t *offsets, int mem_kind, void *stream);
+int cdc_entropy_peek(const unsigned char *in, size_t n, int *h_hyper, int *w_hyper, int *arith);
+/* -> q_latent [B][dims[n]/2][up*h][up*w] (exactly the encoder's dequantised latent) and, optionally, q_hyper_latent. */
+int cdc_entropy_decode(cdc_handle *h, const unsigned char *in, const size_t *offsets, const float *medians, int B,
+                       float *q_latent, float *q_hyper_latent, int mem_kind, void *stream);
 
 /* quantize(x, "dequantize", offset) = round(x - offset) + offset, round = half-to-even (utils.py:72-85). */
 int cdc_dequantize(cdc_handle *h, const float *x, const float *offset, float *out, long long n, int mem_kind,

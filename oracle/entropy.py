@@ -1,0 +1,105 @@
+"""ctypes front-end of oracle/entropy_oracle.c (TEST INFRASTRUCTURE ONLY): the independent CPU restatement of the
+entropy coder.  "Parity unpinned": the reference has no entropy coder; the probability
+models are the reference's (FlexiblePrior.likelihood, NormalDistribution.likelihood) and are pinned through bpp()."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import ops as _ops
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _ops.build()
+        L = ctypes.CDLL(os.path.join(_HERE, "libcdc_entropy_oracle.so"))
+        vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        L.orc_entropy_edges.argtypes = [vp]
+        L.orc_entropy_encode_hyper.argtypes = [vp, i, i, vp, vp, vp, sz]
+        L.orc_entropy_encode_hyper.restype = sz
+        L.orc_entropy_decode_hyper.argtypes = [vp, sz, i, i, vp, vp, vp]
+        L.orc_entropy_encode_latent.argtypes = [vp, vp, ctypes.c_longlong, vp, sz]
+        L.orc_entropy_encode_latent.restype = sz
+        L.orc_entropy_decode_latent.argtypes = [vp, sz, vp, ctypes.c_longlong, vp]
+        L.orc_entropy_ideal_bits_latent.argtypes = [vp, vp, ctypes.c_longlong]
+        L.orc_entropy_ideal_bits_latent.restype = ctypes.c_double
+        _lib = L
+    return _lib
+
+
+def raw_prior(state_dict, C):
+    """Reference FlexiblePrior parameters -> [C, 44] float32: W0[3] b0[3] a0[3] | W1[9] b1[3] a1[3] | W2[9] b2[3] a2[3] | W3[3] b3."""
+    out = np.zeros((C, 44), np.float32)
+    pos = 0
+    for i in range(4):
+        w = np.asarray(state_dict[f"prior.affine.{i}.weight"], np.float32).reshape(C, -1)
+        b = np.asarray(state_dict[f"prior.affine.{i}.bias"], np.float32).reshape(C, -1)
+        out[:, pos:pos + w.shape[1]] = w; pos += w.shape[1]
+        out[:, pos:pos + b.shape[1]] = b; pos += b.shape[1]
+        if i < 3:
+            a = np.asarray(state_dict[f"prior.a.{i}"], np.float32).reshape(C, -1)
+            out[:, pos:pos + a.shape[1]] = a; pos += a.shape[1]
+    assert pos == 43
+    return out
+
+
+def edges():
+    e = np.zeros(128, np.float32)
+    lib().orc_entropy_edges(e.ctypes.data)
+    return e
+
+
+def encode_hyper(sym, prior44, medians):
+    """sym [C, h, w] int32 -> bytes."""
+    sym = np.ascontiguousarray(sym, np.int32)
+    C, per = sym.shape[0], int(np.prod(sym.shape[1:]))
+    cap = 64 + 8 * sym.size
+    out = np.zeros(cap, np.uint8)
+    p, m = np.ascontiguousarray(prior44, np.float32), np.ascontiguousarray(medians, np.float32).reshape(-1)
+    n = lib().orc_entropy_encode_hyper(sym.ctypes.data, C, per, p.ctypes.data, m.ctypes.data, out.ctypes.data, cap)
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def decode_hyper(data, C, per, prior44, medians):
+    buf = np.frombuffer(data, np.uint8).copy()
+    sym = np.zeros(C * per, np.int32)
+    p, m = np.ascontiguousarray(prior44, np.float32), np.ascontiguousarray(medians, np.float32).reshape(-1)
+    bad = lib().orc_entropy_decode_hyper(buf.ctypes.data, buf.size, C, per, p.ctypes.data, m.ctypes.data, sym.ctypes.data)
+    assert not bad
+    return sym
+
+
+def encode_latent(sym, scale):
+    sym = np.ascontiguousarray(sym, np.int32).reshape(-1)
+    scale = np.ascontiguousarray(scale, np.float32).reshape(-1)
+    cap = 64 + 8 * sym.size
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_entropy_encode_latent(sym.ctypes.data, scale.ctypes.data, sym.size, out.ctypes.data, cap)
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def decode_latent(data, scale):
+    buf = np.frombuffer(data, np.uint8).copy()
+    scale = np.ascontiguousarray(scale, np.float32).reshape(-1)
+    sym = np.zeros(scale.size, np.int32)
+    bad = lib().orc_entropy_decode_latent(buf.ctypes.data, buf.size, scale.ctypes.data, scale.size, sym.ctypes.data)
+    assert not bad
+    return sym
+
+
+def ideal_bits_latent(sym, scale):
+    sym = np.ascontiguousarray(sym, np.int32).reshape(-1)
+    scale = np.ascontiguousarray(scale, np.float32).reshape(-1)
+    return float(lib().orc_entropy_ideal_bits_latent(sym.ctypes.data, scale.ctypes.data, sym.size))
+
+
+def stream(arith, hh, wh, hyper_bytes, latent_bytes):
+    """The container of include/cdc_hip.h: 'CDC' 1 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 | payloads."""
+    import struct
+    return b"CDC\x01" + struct.pack("<BBHHII", arith, 0, hh, wh, len(hyper_bytes), len(latent_bytes)) + hyper_bytes + latent_bytes

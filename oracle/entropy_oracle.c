@@ -1,0 +1,235 @@
+/* entropy_oracle.c -- TEST INFRASTRUCTURE: independent CPU restatement of the entropy coder of SURVEY section 8f row 4.
+ *
+ * "Parity unpinned": the reference has no entropy coder (it only estimates the rate, xparam/modules/compress_modules.py:
+ * 76-90), so there is nothing of its own to pin this against.  What IS pinned: the probability models are the
+ * reference's -- FlexiblePrior.likelihood (xparam/modules/network_components.py:285-378: softplus weights, tanh gates,
+ * sigmoid difference with the sign trick) and NormalDistribution.likelihood (xparam/modules/utils.py:147-159) -- and
+ * tests/test_entropy.py checks the ideal code length of these tables against the reference's own bpp() on the golden
+ * fixtures.  The table construction and the range-ANS byte format follow the specification in
+ * cdc_compression_amd/csrc/entropy.hip; product and oracle streams must agree byte for byte.
+ * Only tests/ may load this file.  Compile with -ffp-contract=off (the tables are float64 + libm, no fused operations). */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PREC 16
+#define TOT 65536u
+#define RANS_L (1u << 23)
+#define NBINS 128
+
+typedef struct { int K, n; uint32_t *f, *c; } table_t;      /* n = 2K+2 entries; c has n+1 cumulative starts */
+
+static void table_from_p(const double *p, int n, int K, table_t *t) {
+    t->K = K; t->n = n;
+    t->f = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    t->c = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint32_t sum = 0; int best = 0;
+    for (int j = 0; j < n; ++j) {
+        double v = p[j] > 0 ? p[j] : 0.0;
+        t->f[j] = 1u + (uint32_t)floor(v * (double)(TOT - (uint32_t)n));
+        sum += t->f[j];
+        if (p[j] > p[best]) best = j;
+    }
+    t->f[best] += TOT - sum;
+    t->c[0] = 0;
+    for (int j = 0; j < n; ++j) t->c[j + 1] = t->c[j] + t->f[j];
+}
+static void table_free(table_t *t) { free(t->f); free(t->c); }
+
+static float g_edges[NBINS];
+static table_t g_gauss[NBINS];
+static int g_gauss_ready = 0;
+
+static void gauss_tables(void) {
+    if (g_gauss_ready) return;
+    const double lo = log(0.1), hi = log(2048.0);
+    for (int i = 0; i < NBINS; ++i) g_edges[i] = (float)exp(lo + (double)i * (hi - lo) / (double)(NBINS - 1));
+    for (int i = 0; i < NBINS; ++i) {
+        const double s = (double)g_edges[i];
+        int K = (int)ceil(8.0 * s) + 1;
+        if (K > 1023) K = 1023;
+        const int n = 2 * K + 2;
+        double *p = (double *)malloc(sizeof(double) * n), tot = 0;
+        const double cst = -sqrt(0.5);                 /* std_cdf(t) = 0.5 erfc(-2^-0.5 t), utils.py:147-150 */
+        for (int k = -K; k <= K; ++k) {
+            const double x = fabs((double)k);          /* likelihood(): x = |x - loc| (utils.py:155-159) */
+            const double upper = 0.5 * erfc(cst * ((0.5 - x) / s));
+            const double lower = 0.5 * erfc(cst * ((-0.5 - x) / s));
+            p[k + K] = upper - lower;
+            tot += p[k + K];
+        }
+        p[n - 1] = 1.0 - tot > 0 ? 1.0 - tot : 0.0;
+        table_from_p(p, n, K, &g_gauss[i]);
+        free(p);
+    }
+    g_gauss_ready = 1;
+}
+
+static int scale_bin(float s) {                        /* smallest i with s <= e_i, else the last */
+    for (int i = 0; i < NBINS; ++i) if (s <= g_edges[i]) return i;
+    return NBINS - 1;
+}
+
+/* raw: per channel W0[3] b0[3] a0[3] | W1[9] b1[3] a1[3] | W2[9] b2[3] a2[3] | W3[3] b3[1] (reference parameter values) */
+static double softplus_d(float v) { return v > 20.f ? (double)v : log1p(exp((double)v)); }   /* F.softplus, threshold 20 */
+
+static double prior_logits(const float *raw, double x) {
+    /* FlexiblePrior.cdf(..., logits=True): x -> affine(softplus W, b) -> x + tanh(a) tanh(x) -> ... (network_components.py:342-358) */
+    double v[3] = {x, 0, 0}, w[3];
+    int nin = 1;
+    const float *q = raw;
+    for (int layer = 0; layer < 4; ++layer) {
+        const int nout = layer == 3 ? 1 : 3;
+        for (int j = 0; j < nout; ++j) {
+            double acc = 0;
+            for (int i = 0; i < nin; ++i) acc = acc + v[i] * softplus_d(q[i * nout + j]);
+            w[j] = acc + (double)q[nin * nout + j];
+        }
+        q += nin * nout + nout;
+        if (layer < 3) {
+            for (int j = 0; j < nout; ++j) w[j] = w[j] + tanh((double)q[j]) * tanh(w[j]);
+            q += nout;
+        }
+        for (int j = 0; j < nout; ++j) v[j] = w[j];
+        nin = nout;
+    }
+    return v[0];
+}
+
+static double prior_p(const float *raw, double med, int k) {     /* FlexiblePrior.likelihood (network_components.py:372-378) */
+    const double lower = prior_logits(raw, med + k - 0.5), upper = prior_logits(raw, med + k + 0.5);
+    const double sum = lower + upper;
+    const double sign = sum > 0 ? -1.0 : (sum < 0 ? 1.0 : 0.0);
+    const double u = 1.0 / (1.0 + exp(-(upper * sign))), l = 1.0 / (1.0 + exp(-(lower * sign)));
+    return fabs(u - l);
+}
+
+static void hyper_table(const float *raw, float median, table_t *t) {
+    const double med = (double)median;
+    int K = 8;
+    for (;; K *= 2) {
+        double tot = 0;
+        for (int k = -K; k <= K; ++k) tot += prior_p(raw, med, k);
+        if (tot > 1.0 - ldexp(1.0, -20) || K >= 1024) break;
+    }
+    const int n = 2 * K + 2;
+    double *p = (double *)malloc(sizeof(double) * n), tot = 0;
+    for (int k = -K; k <= K; ++k) { p[k + K] = prior_p(raw, med, k); tot += p[k + K]; }
+    p[n - 1] = 1.0 - tot > 0 ? 1.0 - tot : 0.0;
+    table_from_p(p, n, K, t);
+    free(p);
+}
+
+/* ---- range-ANS, encoder writing backwards ---------------------------------------------------------------------- */
+typedef struct { uint8_t *buf; size_t cap, pos; uint32_t x; int overflow; } enc_t;
+static void enc_byte(enc_t *e, uint8_t b) { if (e->pos == 0) { e->overflow = 1; return; } e->buf[--e->pos] = b; }
+static void enc_put(enc_t *e, uint32_t start, uint32_t freq) {
+    const uint32_t xmax = ((RANS_L >> PREC) << 8) * freq;
+    while (e->x >= xmax) { enc_byte(e, (uint8_t)(e->x & 0xff)); e->x >>= 8; }
+    e->x = ((e->x / freq) << PREC) + (e->x % freq) + start;
+}
+static void enc_symbol(enc_t *e, const table_t *t, int k) {
+    const int K = t->K;
+    if (k >= -K && k <= K) { enc_put(e, t->c[k + K], t->f[k + K]); return; }
+    uint32_t w = ((uint32_t)((k < 0 ? -k : k) - K - 1) << 1) | (k < 0 ? 1u : 0u), dig[4];
+    int nd = 0;
+    do { dig[nd++] = w & 4095u; w >>= 12; } while (w);
+    for (int d = nd - 1; d >= 0; --d) {                 /* reverse order: the decoder reads digit 0 first */
+        const uint32_t v = dig[d] | (d < nd - 1 ? 4096u : 0u);
+        enc_put(e, v << (PREC - 13), 1u << (PREC - 13));
+    }
+    enc_put(e, t->c[2 * K + 1], t->f[2 * K + 1]);
+}
+static size_t enc_finish(enc_t *e, uint8_t *out) {      /* final state, most significant byte first */
+    for (int i = 0; i < 4; ++i) { enc_byte(e, (uint8_t)(e->x & 0xff)); e->x >>= 8; }
+    const size_t n = e->cap - e->pos;
+    memcpy(out, e->buf + e->pos, n);
+    return n;
+}
+
+typedef struct { const uint8_t *p, *end; uint32_t x; int bad; } dec_t;
+static uint32_t dec_next(dec_t *d) { if (d->p < d->end) return *d->p++; d->bad = 1; return 0; }
+static void dec_init(dec_t *d, const uint8_t *in, size_t n) {
+    d->p = in; d->end = in + n; d->x = 0; d->bad = 0;
+    for (int i = 0; i < 4; ++i) d->x = (d->x << 8) | dec_next(d);
+}
+static void dec_advance(dec_t *d, uint32_t start, uint32_t freq) {
+    d->x = freq * (d->x >> PREC) + (d->x & (TOT - 1)) - start;
+    while (d->x < RANS_L) d->x = (d->x << 8) | dec_next(d);
+}
+static int dec_symbol(dec_t *d, const table_t *t) {
+    const uint32_t slot = d->x & (TOT - 1);
+    int lo = 0, hi = t->n - 1;                          /* largest j with c[j] <= slot */
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t->c[mid] <= slot) lo = mid; else hi = mid - 1; }
+    dec_advance(d, t->c[lo], t->f[lo]);
+    if (lo <= 2 * t->K) return lo - t->K;
+    uint32_t w = 0;
+    for (int sh = 0; sh < 48; sh += 12) {
+        const uint32_t v = (d->x & (TOT - 1)) >> (PREC - 13);
+        dec_advance(d, v << (PREC - 13), 1u << (PREC - 13));
+        w |= (v & 4095u) << sh;
+        if (!(v & 4096u)) break;
+    }
+    const int mag = (int)(w >> 1) + t->K + 1;
+    return (w & 1u) ? -mag : mag;
+}
+
+/* ---- entry points (ctypes) ------------------------------------------------------------------------------------------- */
+void orc_entropy_edges(float *edges) { gauss_tables(); memcpy(edges, g_edges, sizeof g_edges); }
+
+/* hyper symbols [C][per] with per-channel tables -> bytes; returns the byte count (0 on overflow) */
+size_t orc_entropy_encode_hyper(const int32_t *sym, int C, int per, const float *raw_prior, const float *medians,
+                                uint8_t *out, size_t cap) {
+    table_t *tabs = (table_t *)malloc(sizeof(table_t) * C);
+    for (int c = 0; c < C; ++c) hyper_table(raw_prior + (size_t)c * 44, medians[c], &tabs[c]);
+    enc_t e = {(uint8_t *)malloc(cap), cap, cap, RANS_L, 0};
+    for (long long i = (long long)C * per - 1; i >= 0; --i) enc_symbol(&e, &tabs[i / per], sym[i]);
+    size_t n = enc_finish(&e, out);
+    if (e.overflow) n = 0;
+    free(e.buf);
+    for (int c = 0; c < C; ++c) table_free(&tabs[c]);
+    free(tabs);
+    return n;
+}
+int orc_entropy_decode_hyper(const uint8_t *in, size_t n, int C, int per, const float *raw_prior, const float *medians, int32_t *sym) {
+    table_t *tabs = (table_t *)malloc(sizeof(table_t) * C);
+    for (int c = 0; c < C; ++c) hyper_table(raw_prior + (size_t)c * 44, medians[c], &tabs[c]);
+    dec_t d; dec_init(&d, in, n);
+    for (long long i = 0; i < (long long)C * per; ++i) sym[i] = dec_symbol(&d, &tabs[i / per]);
+    for (int c = 0; c < C; ++c) table_free(&tabs[c]);
+    free(tabs);
+    return d.bad;
+}
+/* latent symbols with per-element scale -> bytes */
+size_t orc_entropy_encode_latent(const int32_t *sym, const float *scale, long long n, uint8_t *out, size_t cap) {
+    gauss_tables();
+    enc_t e = {(uint8_t *)malloc(cap), cap, cap, RANS_L, 0};
+    for (long long i = n - 1; i >= 0; --i) enc_symbol(&e, &g_gauss[scale_bin(scale[i])], sym[i]);
+    size_t nb = enc_finish(&e, out);
+    if (e.overflow) nb = 0;
+    free(e.buf);
+    return nb;
+}
+int orc_entropy_decode_latent(const uint8_t *in, size_t nbytes, const float *scale, long long n, int32_t *sym) {
+    gauss_tables();
+    dec_t d; dec_init(&d, in, nbytes);
+    for (long long i = 0; i < n; ++i) sym[i] = dec_symbol(&d, &g_gauss[scale_bin(scale[i])]);
+    return d.bad;
+}
+/* ideal code length (bits) of the same symbols under the integer tables: sum -log2(f / 65536) (+ escape payloads) */
+double orc_entropy_ideal_bits_latent(const int32_t *sym, const float *scale, long long n) {
+    gauss_tables();
+    double bits = 0;
+    for (long long i = 0; i < n; ++i) {
+        const table_t *t = &g_gauss[scale_bin(scale[i])];
+        const int k = sym[i];
+        if (k >= -t->K && k <= t->K) bits += 16.0 - log2((double)t->f[k + t->K]);
+        else {
+            uint32_t w = ((uint32_t)((k < 0 ? -k : k) - t->K - 1) << 1);
+            int nd = 0; do { ++nd; w >>= 12; } while (w);
+            bits += 16.0 - log2((double)t->f[2 * t->K + 1]) + 13.0 * nd;
+        }
+    }
+    return bits;
+}

@@ -19,7 +19,7 @@ _i = ctypes.c_int
 
 def build(force=False):
     """Compile the C oracle with gcc (oracle/Makefile). Building the checker is not using it."""
-    libs = [os.path.join(_HERE, n) for n in ("libcdc_oracle.so", "libcdc_oracle64.so")]
+    libs = [os.path.join(_HERE, n) for n in ("libcdc_oracle.so", "libcdc_oracle64.so", "libcdc_entropy_oracle.so")]
     if force or not all(os.path.exists(p) for p in libs):
         subprocess.check_call(["make", "-C", _HERE, "-B"] if force else ["make", "-C", _HERE],
                               stdout=subprocess.DEVNULL)
