@@ -7,12 +7,12 @@
 //     hyper symbols  k = q_hyper_latent - medians    per-channel tables  p_c(k) = likelihood(medians_c + k)
 //     latent symbols k = q_latent - mean             tables by scale:     p(k)  = Phi((k+.5)/s) - Phi((k-.5)/s)
 // with a byte-wise range-ANS coder (32-bit state, 16-bit probabilities).  The specification of the integer tables
-// (below) is restated independently in oracle/entropy_oracle.c; streams must agree byte for byte.
+// (below) is restated independently by the CPU checker of the test tree; streams must agree byte for byte.
 //
 // Division of labour: everything per-element and data-parallel runs on the GPU (quantisation against the mean, scale ->
 // table index, symbols -> dequantised latent, and of course hyper_dec itself); the probability tables are a few
 // thousand doubles evaluated once per model on the host in float64 with libm (so that encoder and decoder, product
-// and oracle, all hold the SAME integers -- device transcendentals are not bit-reproducible across toolchains); the
+// and the CPU checker, all hold the SAME integers -- device transcendentals are not bit-reproducible across toolchains); the
 // coder proper is inherently sequential and runs on the host over ~70 k symbols per 256x256 image (< 1 ms).
 //
 // CONTRACT (the one real hazard of learned codecs): the decoder must reproduce the encoder's `scale` bit for bit or
