@@ -667,7 +667,11 @@ struct Builder {
     // at batch 32 those extra HBM writes in the producers cost as much as the consumers gain (round 2: 3.64 images/s
     // with planes everywhere, 3.68 with planes up to 128 x 128 (CDC_PF_MAXPIX), 3.75 without).  It pays once the
     // remaining fp32 consumers read planes too.
-    bool pf_on() const { const char *e = getenv("CDC_PF"); return h->arith == 1 && e && atoi(e); }
+    // CDC_PF: 0 off; 1 planes for every activation (opt-in, see above); default 2: planes ONLY on the block1 -> block2
+    // edge of a ResnetBlock -- h1 has a single consumer, so it is written as planes INSTEAD of fp32 (same bytes) and
+    // block2, half of all 3x3 convolutions, runs on the DMA-fed kernel at no extra traffic.
+    int pf_mode() const { const char *e = getenv("CDC_PF"); return h->arith != 1 ? 0 : (e ? atoi(e) : 2); }
+    bool pf_on() const { return pf_mode() != 0; }
     static long long pf_maxpix() { const char *e = getenv("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
     PfTwin *twin(const float *p) { auto it = pfmap.find(p); return it == pfmap.end() ? nullptr : &it->second; }
     void add_twin(const float *p, int C, int H, int W) {
@@ -696,7 +700,7 @@ struct Builder {
     Act new_act(int C, int H, int W, bool want_twin = true) {
         Act a; a.C = C; a.H = H; a.W = W;
         a.p = dalloc((size_t)B * C * H * W);
-        if (want_twin) add_twin(a.p, C, H, W);
+        if (want_twin && pf_mode() == 1) add_twin(a.p, C, H, W);
         return a;
     }
 
@@ -921,6 +925,7 @@ struct Builder {
                     } else {
                         a.pf_ys = Wt + 2; a.pf_xs = 1; a.pf_zoff[0] = (Wt + 2) + 1;
                     }
+                    a.pf_only = o.no_f32 ? 1 : 0;
                     to->valid = true;
                 }
             }
@@ -1033,6 +1038,7 @@ struct Builder {
         const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
         const float *shift = rb.has_mlp ? h->shift + rb.shift_off : nullptr;   // Compressor blocks: no time embedding
         Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W);
+        if (pf_mode() == 2 && pf_would_plan(rb.c2, H, W)) add_twin(h1.p, rb.cout, H, W);
         // h1 feeds block2 only: when block2 runs on the pre-split operand kernel the fp32 copy is never read
         static const bool keep_h1 = getenv("CDC_PF_KEEP_H1") != nullptr;
         const bool h1_pf_only = !keep_h1 && twin(h1.p) && pf_would_plan(rb.c2, H, W);
@@ -2617,8 +2623,10 @@ int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bi
     if (resid && (rc = sc.up(resid, (size_t)B * Cout * Ho * Wo, &dr))) return rc;
     h->shift_bs = Cout;
     float *dy = bd.dalloc((size_t)B * Cout * Ho * Wo);
-    bd.add_twin(dx, Cin, H, W);                  // qualifying shapes run on the pre-split operand kernel
-    bd.pack(dx, (long long)Cin * H * W);
+    if (bd.pf_mode() == 1) {                     // CDC_PF=1: qualifying shapes run on the pre-split operand kernel
+        bd.add_twin(dx, Cin, H, W);
+        bd.pack(dx, (long long)Cin * H * W);
+    }
     if (bd.rc) return bd.rc;
     Builder::ConvOpts o;
     o.ln_g = dg; o.ln_b = db; o.relu = relu; o.shift = ds;
@@ -2651,8 +2659,10 @@ int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const
     if ((rc = sc.up(x, (size_t)B * Cin * H * W, &dx))) return rc;
     const size_t ny = (size_t)B * Cout * 4 * H * W;
     float *dy = bd.dalloc(ny);
-    bd.add_twin(dx, Cin, H, W);
-    bd.pack(dx, (long long)Cin * H * W);
+    if (bd.pf_mode() == 1) {
+        bd.add_twin(dx, Cin, H, W);
+        bd.pack(dx, (long long)Cin * H * W);
+    }
     if (bd.rc) return bd.rc;
     bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, (long long)Cout * 4 * H * W,
             Builder::ConvOpts(), false, PC_UP);

@@ -81,6 +81,7 @@ struct ConvArgs {
     void *out_pf;
     long long pf_bs, pf_ps;
     int pf_ys, pf_xs, pf_zoff[4];
+    int pf_only;    // the planes are the ONLY copy of the result (its single consumer reads planes): skip the fp32 store
 #ifdef CDC_TIMELINE
     unsigned long long *tl;         // tools/build_variant.sh timeline -DCDC_TIMELINE: 64 cycle stamps per workgroup
 #endif

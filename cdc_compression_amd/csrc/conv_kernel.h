@@ -272,6 +272,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
                 pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps,
                                P.pf_ps, half, acc[m][n]);
         }
+        if (P.pf_only) continue;
         float *op = P.out + g.out_off + (size_t)b * P.out_bs + pix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {

@@ -154,7 +154,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // patch units per thread: stride 2 always runs the two-unit / parity-plane variant
     const int xu = s.stride == 2 ? 2 : 1;
     const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && lookup2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
-                    (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && getenv("CDC_XU2_SMALL"))) && !getenv("CDC_NO_XU2"))) && !getenv("CDC_NO_SPLIT2");
+                    (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && !getenv("CDC_NO_XU2_SMALL"))) && !getenv("CDC_NO_XU2"))) && !getenv("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
     if (!v2 && ar) { ConvShape s0 = s; s0.arith = 0; return try_plan_split(s0, MB, NPW, lognbw, p, allow_ipw); }
     if (!v2 && (s.lnmode != 0 || !conv_lookup_split(MB, NPW) || 4 * plane > kXS * nthr)) return false;
