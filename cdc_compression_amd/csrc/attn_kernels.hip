@@ -33,13 +33,19 @@ __device__ __forceinline__ void split3(float a, unsigned &h, unsigned &m, unsign
     l = __float_as_uint(r - __uint_as_float(m));
 }
 
-template <int CB, int NW>      // C = 32 * CB channels, NW waves per workgroup
+// F16 = true (CDC_ARITH_F16X2): both contractions on the fp16 matrix cores with two-plane operands (three products):
+//   projection:  W' 2^s as {WH, WL, WH2} (static planes), x - mean as (h, l') -- as in conv_split_kernel.h AR = 1;
+//   sum_n p v:   p = exp(k - max) in (0, 1] as {PH, PL = fp16(p - PH), PH2 = PH 2^-11} (absolute error <= 3e-8, i.e. fp32
+//                resolution of the largest weight p = 1), v as (h, l'); K = 16 pixels per instruction: 6 fp16 MFMAs per
+//                32-pixel tile and S block instead of 16 v_mfma_f32_32x32x2_f32 (32 vs 64 cycles each).
+template <int CB, int NW, bool F16 = false>      // C = 32 * CB channels, NW waves per workgroup
 __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const KvCtxArgs a) {
     constexpr int C = 32 * CB, NBLK = 2 * CB;        // kv row blocks of 32 channels
     constexpr int BPW = NBLK / NW;                    // row blocks per wave in phase 1
     constexpr int SPW = CB * CB / NW;                 // S blocks per wave in phase 2
     constexpr int WPD = NW / CB;                      // waves sharing one d block (each takes SPW e blocks)
-    constexpr int LDK = 33;                           // padded pixel stride of the LDS tile
+    constexpr int LDK = F16 ? 36 : 33;                // pixel stride of the LDS tile (F16: 16-byte aligned rows, conflict-free b128)
+    static_assert(!F16 || BPW == 1, "the fp16 projection keeps one row block of split weights per wave");
     static_assert(NBLK % NW == 0 && (CB * CB) % NW == 0 && NW % CB == 0, "the waves share the blocks evenly");
     __shared__ float kvbuf[2][2 * C * LDK];         // double-buffered tile: one barrier per tile
     __shared__ __attribute__((aligned(16))) float fac[NW][32];
@@ -108,7 +114,22 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
         for (int q = 0; q < BPW; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-        if constexpr (kSplitP1) {
+        if constexpr (F16) {
+#pragma unroll
+            for (int c = 0; c < C / 16; ++c) {
+                f16x8 xh, xl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    _Float16 hq, lq;
+                    split2h(xn[8 * c + i] - mu, hq, lq);
+                    xh[i] = hq; xl[i] = lq;
+                }
+                // planes {WH, WL, WH2} sit where the bf16 planes {w1, w2, w3} sit; smallest terms first
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ws[0][c][1]), xh, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ws[0][c][2]), xl, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ws[0][c][0]), xh, acc[0], 0, 0, 0);
+            }
+        } else if constexpr (kSplitP1) {
 #pragma unroll
             for (int c = 0; c < C / 16; ++c) {
                 unsigned hh[8], mm[8], ll[8];
@@ -155,16 +176,28 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                kv[row * LDK + j] = acc[q][r] * rs + bias[q][r];
+                kv[row * LDK + j] = acc[q][r] * (F16 ? rs * a.wscale_inv : rs) + bias[q][r];
             }
         }
         __syncthreads();
         // ---- phase 2 -------------------------------------------------------------------------------
-        const float *krow = kv + (db * 32 + j) * LDK + kh;      // k[d][2s + kh]
+        // f32 MFMA: register s <-> pixel 2s + kh;  fp16 MFMA: register s <-> pixel 16(s/8) + 8kh + s%8
+        const float *krow = kv + (db * 32 + j) * LDK + (F16 ? 8 * kh : kh);
         float kk[16];
         float tmax = -INFINITY;
+        if constexpr (F16) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { kk[s] = krow[2 * s]; tmax = fmaxf(tmax, kk[s]); }
+            for (int st = 0; st < 2; ++st) {
+                const float4 k0 = *reinterpret_cast<const float4 *>(krow + 16 * st), k1 = *reinterpret_cast<const float4 *>(krow + 16 * st + 4);
+                kk[8 * st + 0] = k0.x; kk[8 * st + 1] = k0.y; kk[8 * st + 2] = k0.z; kk[8 * st + 3] = k0.w;
+                kk[8 * st + 4] = k1.x; kk[8 * st + 5] = k1.y; kk[8 * st + 6] = k1.z; kk[8 * st + 7] = k1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) tmax = fmaxf(tmax, kk[s]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { kk[s] = krow[2 * s]; tmax = fmaxf(tmax, kk[s]); }
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         if (__any(tmax > m_run)) {                   // a new row maximum somewhere in the block: rescale
             const float mn = fmaxf(m_run, tmax);
@@ -187,12 +220,45 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
         float pv[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) { pv[s] = expf(kk[s] - m_run); zsum += pv[s]; }
+        if constexpr (F16) {
+            f16x8 ph[2], pl[2], ph2[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p = pv[8 * st + i];
+                    const _Float16 h = (_Float16)p;
+                    ph[st][i] = h;
+                    pl[st][i] = (_Float16)(p - (float)h);
+                    ph2[st][i] = (_Float16)((float)h * (1.0f / 2048.0f));
+                }
+#pragma unroll
+            for (int q = 0; q < SPW; ++q) {
+                const float *vrow = kv + (C + (eb0 + q) * 32 + j) * LDK + 8 * kh;   // v[e][16 st + 8kh + i]
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(vrow + 16 * st), v1 = *reinterpret_cast<const float4 *>(vrow + 16 * st + 4);
+                    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    f16x8 vh, vl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        _Float16 hq, lq;
+                        split2h(vv[i], hq, lq);
+                        vh[i] = hq; vl[i] = lq;
+                    }
+                    S[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[st], vh, S[q], 0, 0, 0);
+                    S[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph2[st], vl, S[q], 0, 0, 0);
+                    S[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st], vh, S[q], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < SPW; ++q) {
             const float *vrow = kv + (C + (eb0 + q) * 32 + j) * LDK + kh;   // v[e][2s + kh]
 #pragma unroll
             for (int s = 0; s < 16; ++s)
                 S[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[s], vrow[2 * s], S[q], 0, 0, 0);
+        }
         }
     }
     // ---- partial results of this split ---------------------------------------------------------------
@@ -215,7 +281,9 @@ hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
     if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
     dim3 grid((unsigned)a.nsplit, (unsigned)B);
     static const bool w4 = getenv("CDC_KVCTX_W4") != nullptr;      // C = 128: 4 waves with the f32-MFMA projection
-    if (a.C == 64) hipLaunchKernelGGL((kvctx_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    if (a.C == 64 && a.f16) hipLaunchKernelGGL((kvctx_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
+    else if (a.C == 128 && a.f16) hipLaunchKernelGGL((kvctx_kernel<4, 8, true>), grid, dim3(512), 0, st, a);
+    else if (a.C == 64) hipLaunchKernelGGL((kvctx_kernel<2, 4>), grid, dim3(256), 0, st, a);
     else if (a.C == 128 && w4) hipLaunchKernelGGL((kvctx_kernel<4, 4>), grid, dim3(256), 0, st, a);
     else if (a.C == 128) hipLaunchKernelGGL((kvctx_kernel<4, 8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidValue;

@@ -61,7 +61,8 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
                ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr;
-               float *kvWt = nullptr, *kvb = nullptr; unsigned short *kvWs = nullptr; };   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
+               float *kvWt = nullptr, *kvb = nullptr; unsigned short *kvWs = nullptr;
+               unsigned short *kvWh = nullptr; float kv_scale_inv = 1.f; };   // fp16 planes {WH, WL, WH2} of W' 2^s   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
     enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV, CONVPF, PFPACK } kind;
@@ -589,6 +590,28 @@ int pack_attn(cdc_handle *h, const std::string &p, int c) {
             if ((rc = upload(h, reinterpret_cast<const float *>(sp.data()), (sp.size() + 1) / 2, &dsp, &h->weight_allocs)))
                 return rc;
             a.kvWs = reinterpret_cast<unsigned short *>(dsp);
+            // the same in two-plane fp16 arithmetic: {WH, WL, WH2 = WH 2^-11} of W' 2^s (see conv_split_kernel.h AR = 1)
+            float wmax = 0.f;
+            for (float v : wt) wmax = std::max(wmax, fabsf(v));
+            int sexp = 0;
+            if (wmax > 0.f && std::isfinite(wmax)) { int e; frexpf(wmax, &e); sexp = 14 - e; }
+            sexp = std::max(-100, std::min(100, sexp));
+            const float scl = ldexpf(1.f, sexp);
+            auto f16bits = [](float f) { const _Float16 hf = (_Float16)f; unsigned short u; memcpy(&u, &hf, 2); return u; };
+            std::vector<unsigned short> sh(sp.size(), 0);
+            for (int co = 0; co < 2 * c; ++co)
+                for (int ci = 0; ci < c; ++ci) {
+                    const float v = wt[(size_t)ci * 2 * c + co] * scl;
+                    const _Float16 wh = (_Float16)v;
+                    const unsigned short parts[3] = {f16bits((float)wh), f16bits(v - (float)wh), f16bits((float)wh * (1.0f / 2048.0f))};
+                    const int q = ci >> 4, kh = (ci >> 3) & 1, i = ci & 7;
+                    for (int pl = 0; pl < 3; ++pl) sh[((size_t)((q * 3 + pl) * 2 + kh) * 2 * c + co) * 8 + i] = parts[pl];
+                }
+            float *dsh = nullptr;
+            if ((rc = upload(h, reinterpret_cast<const float *>(sh.data()), (sh.size() + 1) / 2, &dsh, &h->weight_allocs)))
+                return rc;
+            a.kvWh = reinterpret_cast<unsigned short *>(dsh);
+            a.kv_scale_inv = ldexpf(1.f, -sexp);
         }
         if ((rc = upload(h, kb.data(), kb.size(), &a.kvb, &h->weight_allocs))) return rc;
     }
@@ -1154,6 +1177,7 @@ struct Builder {
         if (fused) {
             Op f; f.kind = Op::KVCTX; f.prof = PC_ATTN_CTX;
             f.kvc = {x.p, x.bs(), sm, sr, at.kvWt, at.kvb, at.kvWs, C, N, nsplit, S, ksum, kmaxs};
+            if (h->arith == 1 && at.kvWh && !getenv("CDC_KVCTX_BF16")) { f.kvc.Ws = at.kvWh; f.kvc.f16 = 1; f.kvc.wscale_inv = at.kv_scale_inv; }
             f.flops = 6.0 * B * (double)C * C * N; f.bytes = 4.0 * B * C * N;
             emit(f);
         } else {

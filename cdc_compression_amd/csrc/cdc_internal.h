@@ -98,6 +98,8 @@ struct KvCtxArgs {
     const unsigned short *Ws;           // [C/16][3 planes][2 k-halves][2C][8] bf16: exact 3-way split of Wt (C = 64)
     int C, N, nsplit;
     float *S, *Z, *M;                   // [B][nsplit][C][C], [B][nsplit][C], [B][nsplit][C]
+    int f16 = 0;                        // 1: Ws holds the fp16 planes {WH, WL, WH2} of Wt 2^s, wscale_inv = 2^-s
+    float wscale_inv = 1.f;
 };
 hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st);
 
