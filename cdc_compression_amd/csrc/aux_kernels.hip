@@ -535,9 +535,12 @@ __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, c
     }
 }
 
+// ws_f16: 0 three bf16 planes (exact split); 1 fp16 planes {WH, WL, WH2} of M' * 2^8 (conv_split_kernel.h AR = 1; the
+// consumer multiplies its accumulators by 2^-8.  |M'| >= 255 overflows to inf -> NaN -> the decode's range guard).
+constexpr float kFoldPlaneScale = 256.0f;
 __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const float *WqT, int C,
                                                      float scale, const float *ln_g, float *Mt,
-                                                     int Cin_pad, int COP, unsigned short *Ws) {
+                                                     int Cin_pad, int COP, unsigned short *Ws, int ws_f16) {
     extern __shared__ __attribute__((aligned(16))) float rows[];   // [C][kFoldRows]: WqT rows ci0..ci0+7, d-major
     const int ci0 = blockIdx.x * kFoldRows, b = blockIdx.y;
     for (int idx = threadIdx.x; idx < kFoldRows * C; idx += blockDim.x) {
@@ -565,7 +568,23 @@ __global__ void __launch_bounds__(256) ctx_r2_kernel(const float *T1, const floa
             acc[r] = acc[r] * scale * (ci0 + r < C ? ln_g[ci0 + r] : 0.f);   // PreNorm gain folded in (LNMODE 2)
             if (ci0 + r < Cin_pad) Mt[((size_t)b * Cin_pad + ci0 + r) * COP + c] = acc[r];
         }
-        if (Ws && c < C) {
+        if (Ws && c < C && ws_f16) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 wh, wl, wh2;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = acc[r] * kFoldPlaneScale;
+                const _Float16 hq = (_Float16)v;
+                wh[r] = hq;
+                wl[r] = (_Float16)(v - (float)hq);
+                wh2[r] = (_Float16)((float)hq * (1.0f / 2048.0f));
+            }
+            const int q = ci0 >> 4, kh = (ci0 >> 3) & 1;
+            uint4 *dst = reinterpret_cast<uint4 *>(Ws) + (size_t)b * (C / 16) * 6 * C;
+            dst[(size_t)((q * 3 + 0) * 2 + kh) * C + c] = __builtin_bit_cast(uint4, wh);
+            dst[(size_t)((q * 3 + 1) * 2 + kh) * C + c] = __builtin_bit_cast(uint4, wl);
+            dst[(size_t)((q * 3 + 2) * 2 + kh) * C + c] = __builtin_bit_cast(uint4, wh2);
+        } else if (Ws && c < C) {
             // the same 8 input channels x this output channel as three bf16 planes in the A-operand order of
             // lnconv_kernel: [ci/16][plane][(ci/8)&1][co][8] -- the 8 rows of this workgroup are one 16-byte unit
             unsigned hh[8], mm[8], ll[8];
@@ -606,14 +625,14 @@ __global__ void __launch_bounds__(256) ctx_r3_kernel(const float *T1, const floa
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
-                           float *biasB, int B, hipStream_t st, const float *M, unsigned short *Ws) {
+                           float *biasB, int B, hipStream_t st, const float *M, unsigned short *Ws, int ws_f16) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     // Mt doubles as scratch for the normalised context (C*C <= Cin_pad*COP) until R2 overwrites it
     hipLaunchKernelGGL(ctx_r0_kernel, dim3(ceil_div(C * C, 256), B), dim3(256), 0, st, S, ksum, C, nsplit, Mt, M);
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
                        sizeof(float) * kFoldRows * C, st, Mt, C, WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),
-                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, ln_g, Mt, Cin_pad, COP, Ws);
+                       sizeof(float) * kFoldRows * C, st, T1, WqT, C, scale, ln_g, Mt, Cin_pad, COP, Ws, ws_f16);
     hipLaunchKernelGGL(ctx_r3_kernel, dim3(ceil_div(C, 64), B), dim3(64), 0, st, T1, u, b_out, scale, biasB, C);
     return hipGetLastError();
 }

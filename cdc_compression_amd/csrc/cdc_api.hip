@@ -84,6 +84,7 @@ struct Op {
     const int *cp_step = nullptr; long long cp_step_stride = 0;   // COPY: source row selected by a device step index
     KvCtxArgs kvc;
     LnConvArgs lnc;
+    int at_ws_f16 = 0;                 // CTXF: the planes are fp16 {WH, WL, WH2} of M' 2^8 (split convolution) instead of bf16
     unsigned short *at_Ws = nullptr;   // CTXF: also emit M' as bf16 planes for lnconv_kernel
     const float *at_M = nullptr;  // CTXF after KVCTX: per-split row maxima   // COPY: dst = sum of cp_parts planes of src
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
@@ -739,6 +740,7 @@ struct Builder {
         int pre_mode = 1;                              // 1 in-LDS LN, 2 folded (1x1, weights carry g / W.b)
         int shift_bs = -1;                             // row stride of `shift` (-1: the U-Net's table)
         long long w_bs = 0;
+        long long wsp_bs = 0;                          // per-image split planes (elements of 16 bits)
         bool no_bias = false;
         const float *res3_w = nullptr, *res3_x = nullptr; long long res3_bs = 0;   // 3-channel res_conv in the epilogue
         int max_ksplit = 1;                            // > 1: `out` has room for that many partial-sum planes
@@ -764,7 +766,7 @@ struct Builder {
     // k x k / 1x1 / phase-decomposed transposed convolution with "same" geometry.
     bool try_pf(const ConvW &w, const float *s0, int C0, const float *s1, int H, int W, float *out, long long out_bs,
                 const ConvOpts &o, bool need_all, int prof, const ConvShape &s) {
-        if (!pf_on() || !w.wsh || w.stride != 1 || o.pre_mean || o.w_bs || o.max_ksplit > 1) return false;
+        if (!pf_on() || !w.wsh || w.stride != 1 || o.pre_mean || o.w_bs || o.wsp_bs || o.max_ksplit > 1) return false;
         PfTwin *t0 = twin(s0), *t1 = s1 ? twin(s1) : nullptr;
         if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
         if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
@@ -852,6 +854,7 @@ struct Builder {
         s.Win = W; s.nz = w.nz;
         s.allow_split = w.wsp != nullptr;
         s.arith = (h->arith == 1 && w.wsh) ? 1 : 0;
+        s.per_image_w = o.wsp_bs != 0;
         for (int z = 0; z < 4; ++z) s.pad_x[z] = w.transposed ? (w.tk == 5 ? 1 : 1 - (z & 1)) : pad_x;
         if (w.transposed) { s.Ho = H; s.Wo = W; }
         else {
@@ -911,7 +914,7 @@ struct Builder {
         a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
         a.ln_mean = o.pre_mean; a.ln_rstd = o.pre_rstd; a.ln_g = o.pre_g; a.ln_b = o.pre_b;
         a.wp = w.wp; a.w_bs = o.w_bs; a.w_zs = w.w_zs;
-        a.wsp = w.wsp; a.wsp_zs = w.wsp_zs;
+        a.wsp = w.wsp; a.wsp_zs = w.wsp_zs; a.wsp_bs = o.wsp_bs;
         a.acc_scale = 1.f;
         if (plan.split == 2 && plan.arith == 1) { a.wsp = w.wsh; a.acc_scale = w.wscale_inv; }
         a.KH = w.KH; a.KW = w.KW; a.stride = w.stride;
@@ -1189,9 +1192,16 @@ struct Builder {
         // folded output as one streaming pass (lnconv_kernel) where the level is wide enough to be bandwidth-bound
         const bool stream_out = fold && (C == 64 || C == 192 || (C == 128 && getenv("CDC_LNCONV128"))) && N >= 4096 && N % 1024 == 0 &&
                                 !getenv("CDC_NO_LNCONV");
-        unsigned short *Ws = stream_out ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
+        // folded output as a 1x1 split convolution with per-image planes (C % 16 == 0, planes layout = the A-operand
+        // layout of conv_split2_kernel with COP == C): replaces the f32-MFMA kernel and, where faster, lnconv_kernel
+        static const bool no_pic = getenv("CDC_NO_PERIMAGE_SPLIT") != nullptr;
+        // (measured, batch 32: 0.41 -> 0.31 ms at C = 64 / 256^2, 0.30 -> 0.20 at C = 128 / 128^2, 0.18 -> 0.10 at C = 192 / 64^2:
+        //  faster than the streaming lnconv_kernel everywhere, which stays as the CDC_NO_PERIMAGE_SPLIT fallback)
+        const bool split_out = fold && !no_pic && (C % 32) == 0 && (W & 3) == 0;
+        const bool planes_f16 = split_out && h->arith == 1;
+        unsigned short *Ws = (stream_out || split_out) ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
-        r.at_M = kmaxs; r.at_Ws = Ws;
+        r.at_M = kmaxs; r.at_Ws = Ws; r.at_ws_f16 = planes_f16 ? 1 : 0;
         r.bytes = 4.0 * B * nsplit * C * C;
         r.flops = fold ? 4.0 * B * (double)C * C * C : 0.0;
         emit(r);
@@ -1202,7 +1212,11 @@ struct Builder {
         if (!fused)
         dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
-        if (stream_out) {
+        if (split_out) {
+            cw.wsp = Ws;                                   // (bf16 planes unless planes_f16)
+            if (planes_f16) { cw.wsh = Ws; cw.wscale_inv = 1.0f / 256.0f; }
+        }
+        if (stream_out && !split_out) {
             Op f; f.kind = Op::LNCONV; f.prof = PC_CONV1;
             int ns = std::max(1, ceil_div(2048, B));
             while (ns > 1 && N % (32 * ns)) --ns;
@@ -1218,6 +1232,7 @@ struct Builder {
             ConvOpts oy;
             oy.pre_mean = sm; oy.pre_rstd = sr; oy.pre_mode = 2;
             oy.w_bs = (long long)Cin_pad * COP;
+            if (split_out) oy.wsp_bs = (long long)(C / 16) * 6 * C * 8;
             oy.shift = biasB; oy.shift_bs = C;
             oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
             oy.emit_pf = true;
@@ -1521,7 +1536,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
         case Op::CTXF:
             HIP_TRY(h, ctx_fold_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale, op.at.WoT,
                                        op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, op.at.ln_g,
-                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M, op.at_Ws));
+                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M, op.at_Ws, op.at_ws_f16));
             break;
         case Op::COMBINE:
             HIP_TRY(h, fold_combine_launch(op.cb.P, op.cb.bias, op.cb.out, op.cb.Cout, op.cb.KH, op.cb.pad,

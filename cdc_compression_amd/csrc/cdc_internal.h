@@ -29,6 +29,7 @@ struct ConvShape {
     int nz = 1, pad_x[4] = {0, 0, 0, 0};
     bool allow_split = false;   // split-bf16 weights exist for this layer
     int arith = 0;              // 1: the layer's split weights are the fp16 planes (conv_split2_kernel AR = 1 only)
+    bool per_image_w = false;   // split weights differ per image: one image per workgroup, arithmetic not negotiable
     int Ho, Wo;          // output extent (per phase for ConvTranspose)
     int B;
     bool need_all_cout;  // fused LayerNorm / statistics: one workgroup must own every channel
@@ -132,7 +133,7 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
                            float *biasB, int B, hipStream_t st, const float *M = nullptr,
-                           unsigned short *Ws = nullptr);
+                           unsigned short *Ws = nullptr, int ws_f16 = 0);
 hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
                                int pad, int H, int W, int B, hipStream_t st);
 

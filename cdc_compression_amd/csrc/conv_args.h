@@ -32,6 +32,7 @@ struct ConvArgs {
     // split-bf16 form (conv_split_kernel.h): [z][tap][Cin_pad/16][plane 3][k-half 2][COP][8] bf16
     const unsigned short *wsp;
     long long wsp_zs;
+    long long wsp_bs;               // per-image split weights (folded attention output): stride per image, 0 = shared
     // arith 1 (conv_split2_kernel AR = 1): wsp holds the fp16 planes {WH, WL, WH2} of w * 2^s in the same
     // layout and the epilogue multiplies the accumulators by acc_scale = 2^-s (1 otherwise)
     float acc_scale;

@@ -118,7 +118,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // small feature maps (one or two 32-pixel row blocks per wave cover the image): pack several images
     // into the workgroup so the weight stages are still shared by four waves
     int ipw = 1;
-    if (allow_ipw && s.Wo <= NBW && WN <= 2 && s.B >= 2 && !getenv("CDC_NO_IPW")) { ipw = 4 / WN; WN = 4; }
+    if (allow_ipw && !s.per_image_w && s.Wo <= NBW && WN <= 2 && s.B >= 2 && !getenv("CDC_NO_IPW")) { ipw = 4 / WN; WN = 4; }
     const int wpi = WN / ipw;
     const int nthr = 64 * WN;
     const int TH = wpi * NPW * NBH;
@@ -156,6 +156,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && lookup2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
                     (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && !getenv("CDC_NO_XU2_SMALL"))) && !getenv("CDC_NO_XU2"))) && !getenv("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
+    if (!v2 && s.per_image_w) return false;          // only the register-staged variant takes per-image planes
     if (!v2 && ar) { ConvShape s0 = s; s0.arith = 0; return try_plan_split(s0, MB, NPW, lognbw, p, allow_ipw); }
     if (!v2 && (s.lnmode != 0 || !conv_lookup_split(MB, NPW) || 4 * plane > kXS * nthr)) return false;
     const size_t lds = v2 ? lds2 : sizeof(float) * ((size_t)40 * plane + (size_t)2 * s.KW * 24 * COPT);

@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
     };
     const int n_w = TG * 6 * COPT;
     const int wsl = (n_w + nthr - 1) / nthr;
-    const unsigned short *wsrc = P.wsp + (size_t)(NZ == 4 ? 0 : z) * P.wsp_zs + (size_t)cog * COPT * 8;
+    const unsigned short *wsrc = P.wsp + (size_t)(NZ == 4 ? 0 : z) * P.wsp_zs + (size_t)cog * COPT * 8 + (size_t)b * P.wsp_bs;
     // Per-thread byte offsets of its units inside one (group, chunk) weight stage: they do not depend on
     // the group or the chunk (those move the scalar base), so the in-loop DMA issue is address-free.
     // A stage has TG*6*COPT units = a whole number of waves, so the tail test is wave-uniform.
