@@ -998,7 +998,9 @@ struct Builder {
         if (w.Cout % 32 || w.Cout > 384) return false;
         // the split-bf16 kernels hold at most 6 channel blocks per workgroup: wider layers run them over
         // channel groups (2x the matrix rate) and normalise in a separate pass
-        if (w.wsp && w.Cout > 192 && (W & 3) == 0 && !getenv("CDC_NO_SPLIT")) return false;
+        // (round 2: eight blocks = 256 channels with NPW = 1, two workgroups per CU)
+        static const bool no_mb8 = getenv("CDC_NO_MB8") != nullptr;
+        if (w.wsp && w.Cout > (no_mb8 ? 192 : 256) && (W & 3) == 0 && !getenv("CDC_NO_SPLIT")) return false;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.Ho = H; s.Wo = W; s.B = B; s.lnmode = 0;

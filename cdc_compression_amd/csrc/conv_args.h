@@ -126,6 +126,8 @@ struct PfArgs {
     float *stat_mean, *stat_rstd;
     const float *res3_w, *res3_x;   // 3-channel res_conv in the epilogue (see ConvArgs)
     long long res3_bs;
+    int dbg;                        // CDC_PF_DBG (timing experiments, wrong results): 1 no weight DMA in the loop, 2 no patch
+                                    // DMA in the loop, 4 no barrier in the loop, 8 no DMA waits, 16 no epilogue stores
 };
 
 constexpr int kPfXS = 12;   // patch DMA instructions per chunk and patch wave (two patch waves: <= 24 per chunk)

@@ -79,6 +79,7 @@ hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW);
     if (!fn) return hipErrorInvalidValue;
     a.lognbw = 5;
+    { static const char *e = getenv("CDC_PF_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);

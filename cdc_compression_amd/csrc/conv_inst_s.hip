@@ -35,6 +35,7 @@ conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu) {
         if (MB == 3 && NPW == 2) return conv_split2_kernel<3, 2>;
         if (MB == 5 && NPW == 1) return conv_split2_kernel<5, 1>;
         if (MB == 6 && NPW == 1) return conv_split2_kernel<6, 1>;
+        if (MB == 8 && NPW == 1) return conv_split2_kernel<8, 1>;
     } else if (lnmode == 1) {
         if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1, 1>;
         if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2, 1>;

@@ -231,7 +231,7 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
         for (int MB : mbs) {
             if (f_mb && !s.need_all_cout && MB != f_mb) continue;
             for (int NPW : {4, 2, 1}) {
-                if (MB * NPW > 8 || MB > 6) continue;
+                if (MB * NPW > 8 || MB > 8) continue;
                 if (NPW > 1 && NPW > nb_rows) continue;
                 if (f_npw && NPW != f_npw) continue;
                 if (s.KH == 7 && s.KW == 1 && getenv("CDC_71_NPW") && NPW != atoi(getenv("CDC_71_NPW"))) continue;

@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
         if (!(TAIL && t == TAPS - 1) || rem > 0) {        // (the very last tap has nothing left to fetch)
             if (++sn == R) sn = 0;
             // W(s+1) (and, at a chunk seam, the patch of the next chunk) must have landed before anyone reads it
-            if (patch_wave) {
+            if (P.dbg & 8) {
+            } else if (patch_wave) {
                 if constexpr (t == TAPS - 1) dma_wait();
             } else if (!TAIL || rem >= R - 2) {
                 // newer than W(s+1) in this wave's queue: W(s+2) .. W(s+R-2) = (R-3) stages
@@ -220,14 +221,14 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
             } else {
                 dma_wait();                               // tail of the tile: everything in flight is needed next
             }
-            __builtin_amdgcn_s_barrier();
+            if (!(P.dbg & 4)) __builtin_amdgcn_s_barrier();
             const uint4 *wa = a_base + sn * WST;
             if constexpr (t == TAPS - 1) fetch(std::integral_constant<int, 0>{}, xb_nxt, wa, An, Bn);
             else fetch(std::integral_constant<int, t + 1>{}, xb_cur, wa, An, Bn);
             if (patch_wave) {
                 if constexpr (t < ISSUE_TAPS)
-                    if (chunk + LA < P.nchunk) issue_patch(chunk + LA, tc);
-            } else if (!TAIL || rem >= R - 1) {
+                    if (chunk + LA < P.nchunk && !(P.dbg & 2)) issue_patch(chunk + LA, tc);
+            } else if ((!TAIL || rem >= R - 1) && !(P.dbg & 1)) {
                 issue_w();                                // slot (s-1) % R: its readers passed the barrier above
             }
         }
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     }
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
-        if (!valid_v[n]) continue;
+        if (!valid_v[n] || (P.dbg & 16)) continue;
         if (P.out) {
             float *op = P.out + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll

@@ -55,6 +55,8 @@ CONV_CASES = [
     (1, 64, 36, 20, 192, 1, 1, 0, False),
     (1, 64, 48, 48, 3, 7, 1, 3, False),
     (1, 24, 24, 40, 24, 3, 1, 1, True),     # Cout % 32 != 0 -> unfused LN path
+    (2, 256, 32, 32, 256, 3, 1, 1, True),   # 256 channels: eight channel blocks per wave, fused LayerNorm
+    (1, 192, 16, 32, 256, 3, 1, 1, True),
     (2, 320, 16, 16, 320, 3, 2, 1, False),  # stride 2 down to 8x8: two-unit patches + split-K
     (1, 256, 32, 32, 256, 3, 2, 1, False),
 ]
