@@ -52,13 +52,10 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         if (xsw > 2 * kPfXS) continue;
         const int taps = s.KH * s.KW, npb = taps == 1 ? 3 : 2;
         const size_t patch = (size_t)npb * xsw * 64 * 16, wst = (size_t)6 * COPT * 16;
-        const size_t budget = NW == 8 ? 156 * 1024 : 80 * 1024;   // 4 waves: two workgroups per CU
-        int ring = 0;
-        for (int r : {5, 4, 3})
-            if (patch + r * wst <= budget) { ring = r; break; }
+        const int ring = pf_ring(c.MB, c.NPW, c.WM, c.WP, s.KH, s.KW);    // compile-time in the kernel
         if (!ring) continue;
         const int S = (s.Cin / 16) * taps;
-        ring = std::max(3, std::min(ring, S + 1));
+        if (S < ring - 1) continue;                               // the prologue fills ring - 1 slots
         const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * (s.Cout / COPT) * s.nz;
         const double fill = std::min(1.0, wgs * NW / 2048.0);
         const double reads = (3.0 * c.MB + 2.0 * c.NPW) / (3.0 * c.MB * c.NPW);   // ds_read_b128 per MFMA

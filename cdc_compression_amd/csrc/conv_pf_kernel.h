@@ -48,6 +48,22 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
+// Weight ring depth of a kernel shape: what fits next to the patch buffers in the LDS budget (two 4-wave workgroups
+// or one 8-wave workgroup per CU).  Compile-time in the kernel (the counted waits become immediates, the ring
+// arithmetic folds), shared with the host planner.
+__host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW) {
+    return ((4 * (WP * NPW + KH - 1) * (32 + KW - 1) + 63) / 64) * 64;
+}
+__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW) {
+    const size_t budget = WM * WP == 8 ? 156 * 1024 : 80 * 1024;
+    const size_t patch = (size_t)(KH * KW == 1 ? 3 : 2) * pf_patch_units(NPW, WP, KH, KW) * 16;
+    const size_t wst = (size_t)6 * WM * MB * 32 * 16;
+    return patch + 5 * wst <= budget ? 5 : (patch + 4 * wst <= budget ? 4 : (patch + 3 * wst <= budget ? 3 : 0));
+}
+#ifndef CDC_PF_ABLATE
+#define CDC_PF_ABLATE 0      // 1: honour PfArgs::dbg (timing experiments with wrong results)
+#endif
+
 // KH x KW are compile-time (3x3, 1x1, 2x2 phases): tap offsets become ds_read immediates, the tap loop and the
 // patch-issue schedule are unrolled, and the per-tap scalar work shrinks to the ring counters.
 template <int MB, int NPW, int WM, int WP, int KH, int KW>
@@ -85,7 +101,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     const int b = bid / P.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * NBW;
     const int S = P.nchunk * TAPS;
-    const int R = P.ring;
+    constexpr int R = pf_ring(MB, NPW, WM, WP, KH, KW);   // weight ring slots (host: S >= R - 1)
+    static_assert(R >= 3, "no room for a weight ring");
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
     const unsigned wl_lds = lds0 + (unsigned)(NPB * PST) * 16u;
 
@@ -207,28 +224,23 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
         if (!(TAIL && t == TAPS - 1) || rem > 0) {        // (the very last tap has nothing left to fetch)
             if (++sn == R) sn = 0;
             // W(s+1) (and, at a chunk seam, the patch of the next chunk) must have landed before anyone reads it
-            if (P.dbg & 8) {
+            if (CDC_PF_ABLATE && (P.dbg & 8)) {
             } else if (patch_wave) {
                 if constexpr (t == TAPS - 1) dma_wait();
             } else if (!TAIL || rem >= R - 2) {
                 // newer than W(s+1) in this wave's queue: W(s+2) .. W(s+R-2) = (R-3) stages
-                switch (R) {
-                    case 3: vm_wait<0>(); break;
-                    case 4: vm_wait<NWW>(); break;
-                    case 5: vm_wait<2 * NWW>(); break;
-                    default: vm_wait<3 * NWW>(); break;
-                }
+                vm_wait<(R - 3) * NWW>();
             } else {
                 dma_wait();                               // tail of the tile: everything in flight is needed next
             }
-            if (!(P.dbg & 4)) __builtin_amdgcn_s_barrier();
+            if (!(CDC_PF_ABLATE && (P.dbg & 4))) __builtin_amdgcn_s_barrier();
             const uint4 *wa = a_base + sn * WST;
             if constexpr (t == TAPS - 1) fetch(std::integral_constant<int, 0>{}, xb_nxt, wa, An, Bn);
             else fetch(std::integral_constant<int, t + 1>{}, xb_cur, wa, An, Bn);
             if (patch_wave) {
                 if constexpr (t < ISSUE_TAPS)
-                    if (chunk + LA < P.nchunk && !(P.dbg & 2)) issue_patch(chunk + LA, tc);
-            } else if ((!TAIL || rem >= R - 1) && !(P.dbg & 1)) {
+                    if (chunk + LA < P.nchunk && !(CDC_PF_ABLATE && (P.dbg & 2))) issue_patch(chunk + LA, tc);
+            } else if ((!TAIL || rem >= R - 1) && !(CDC_PF_ABLATE && (P.dbg & 1))) {
                 issue_w();                                // slot (s-1) % R: its readers passed the barrier above
             }
         }
@@ -426,7 +438,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     }
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
-        if (!valid_v[n] || (P.dbg & 16)) continue;
+        if (!valid_v[n] || (CDC_PF_ABLATE && (P.dbg & 16))) continue;
         if (P.out) {
             float *op = P.out + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll

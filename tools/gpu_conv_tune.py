@@ -18,6 +18,8 @@ def child(args):
     kw = {}
     if ln:
         kw = dict(ln_g=np.ones(Co, np.float32), ln_b=np.zeros(Co, np.float32), relu=True)
+    if os.environ.get("TUNE_RESID"):
+        kw["resid"] = rng.standard_normal((B, Co, H // s, W // s)).astype(np.float32)
     G.conv2d(x, w, b, s, k // 2, **kw)
     ts = []
     for _ in range(5):
