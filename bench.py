@@ -192,8 +192,12 @@ def main():
         # dominant kernel = the launch shape with the largest total time among the matrix-core convolutions
         conv_ops = [o for o in ops if o["label"].startswith("conv 3x3 s1") and o["flops"] > 0]
         groups = {}
+        def launch_key(label):                              # shape + tile shape + which kernel + residual input
+            t = label.split()
+            kern = "PF" if "PF" in t else ("SPLIT2H" if "SPLIT2H" in t else ("SPLIT2" if "SPLIT2" in t else "CONV"))
+            return " ".join(t[:8]) + " " + kern + (" +res" if "+res" in t else "")
         for o in conv_ops:
-            key = " ".join(o["label"].split()[:8])          # kind, stride, Cin->Cout, out HxW
+            key = launch_key(o["label"])
             g = groups.setdefault(key, dict(ms=0.0, n=0, flops=o["flops"], label=o["label"]))
             g["ms"] += o["ms"]; g["n"] += 1
         domk, dom = max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else ("", dict(ms=0, n=1, flops=0, label=""))
@@ -213,7 +217,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                want = f"B{B} " + " ".join(dom["label"].split()[:8])
+                want = f"B{B} " + domk
                 if tj.get("launch") == want and tj.get("arith") == arith:
                     traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("source")
             except Exception:
@@ -223,7 +227,10 @@ def main():
             hw = dom["label"].split("out")[1].split()[0].split("x")
             cio = dom["label"].split()[3].split("->")
             pixels_out = int(hw[0]) * int(hw[1])
-            alg_bytes = 4.0 * B * pixels_out * (int(cio[0]) + int(dom["label"].split("->")[1].split()[0]))
+            cout = int(dom["label"].split("->")[1].split()[0])
+            # input once + output once, 4 bytes per element (+ the residual operand where the launch
+            # has one: it is an input of the fused epilogue)
+            alg_bytes = 4.0 * B * pixels_out * (int(cio[0]) + cout + (cout if "+res" in dom["label"].split() else 0))
         except Exception:
             alg_bytes = None
         out = {
@@ -240,7 +247,7 @@ def main():
                        "arith": "f16x2" if arith == 1 else "bf16x3"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": dom["label"],
+                "kernel": dom["label"], "launch_key": domk,
                 "kernel_note": "dominant launch shape (largest total time among the 3x3 Block convolutions, fused LN "
                                "epilogue); achieved = its algorithmic flops / its hipEvent-timed average duration",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0,

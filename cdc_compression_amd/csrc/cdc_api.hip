@@ -643,15 +643,16 @@ struct Builder {
         char buf[160];
         const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack"};
         if (op.kind == Op::CONV)
-            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s", op.conv.KH,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
                      op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? " SPLIT2H" : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
-                     op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "");
+                     op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)
-            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d PF%s%s%s", op.pf.KH, op.pf.KW,
+            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d PF%s%s%s%s", op.pf.KH, op.pf.KW,
                      op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
-                     op.pfplan.groups, op.pfplan.ring, op.pf.ep_g ? " LN" : "", op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "");
+                     op.pfplan.groups, op.pfplan.ring, op.pf.ep_g ? " LN" : "", op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
+                     op.pf.resid ? " +res" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)

@@ -24,11 +24,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for kname, v in acc.items():
         vals.setdefault(kname, {})[c] = sum(v) / len(v)
 Ho, Wo = H // s, W // s
-alg = 4.0 * (B * Ci * H * W + B * Co * Ho * Wo)
+import os
+res = bool(os.environ.get("TUNE_RESID"))
+alg = 4.0 * (B * Ci * H * W + B * Co * Ho * Wo * (2 if res else 1))
 for kname, v in vals.items():
     fetch = v.get("FETCH_SIZE", 0) * 1024 * 2
     write = v.get("WRITE_SIZE", 0) * 1024
     print(f"{kname}: FETCH_SIZE(KB)={v.get('FETCH_SIZE',0):.0f} WRITE_SIZE(KB)={v.get('WRITE_SIZE',0):.0f} "
           f"-> hbm read {fetch/1e6:.1f} MB (x2 corrected) + write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB per launch; "
-          f"algorithmic {alg/1e6:.1f} MB (input once + output once)")
+          f"algorithmic {alg/1e6:.1f} MB (input once + output once" + (" + residual once" if res else "") + ")")
 PY
