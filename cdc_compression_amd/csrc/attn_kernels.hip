@@ -277,11 +277,234 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? 3 : 1) kvctx_kernel(const K
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// kvctx16_kernel: the CDC_ARITH_F16X2 form of the kernel above, organised around its real bound -- the VALU, not
+// the matrix cores (per 32-pixel tile and wave the three-product contractions are 18 MFMAs, while splitting the
+// operands and the exponentials were ~600 VALU instructions):
+//   * the tile of x is split into fp16 planes ONCE per workgroup: wave w converts channel chunk w (16 channels x
+//     32 pixels = 8 values per lane) and publishes the two planes in B-operand order in LDS; every wave then reads
+//     the C/16 chunks as ds_read_b128 (was: every wave loaded and split the whole tile, NW-fold redundant);
+//   * VP: the v rows of the projection leave phase 1 already split (h, l' as fp16 [row][pixel] arrays): split once by
+//     the wave that produced them instead of once per S block that consumes them;
+//   * exp(k - max) and the rescale factor use v_exp_f32 (exp2(x log2 e)): <= 2 ulp of relative error on a weight in
+//     (0, 1], against the ~10-instruction expf.
+// One barrier per tile as before: x planes of tile t+1, k/v of tile t are written before barrier t (double buffers).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+template <int CB, int NW, bool VP>
+__global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_kernel(const KvCtxArgs a) {
+    constexpr int C = 32 * CB, NBLK = 2 * CB;
+    static_assert(NBLK == NW && C / 16 == NW, "one projection row block and one channel chunk per wave");
+    constexpr int SPW = CB * CB / NW;                 // S blocks per wave in phase 2
+    constexpr int WPD = NW / CB;                      // waves sharing one d block (each takes SPW e blocks)
+    constexpr int LDK = 36;                           // fp32 pixel stride of a k (v) row: 16-byte rows, conflict-free b128
+    constexpr int LDH = 40;                           // fp16 pixel stride of a v plane row
+    constexpr int KROWS = VP ? C : 2 * C;
+    __shared__ __attribute__((aligned(16))) float kbuf[2][KROWS * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 vbuf[2][2][VP ? C * LDH : 8];
+    __shared__ __attribute__((aligned(16))) uint4 xp[2][NW][2][64];       // [buffer][chunk][plane h / l'][lane]
+    __shared__ __attribute__((aligned(16))) float fac[NW][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int N = a.N;
+    const int per = N / a.nsplit;                     // pixels of this split (multiple of 32, host-enforced)
+    const int p0 = sp * per;
+    const float *mean = a.mean + (size_t)b * N, *rstd = a.rstd + (size_t)b * N;
+
+    // the wave's row block of W' 2^s as fp16 planes {WH, WL, WH2}: lane (i = j, kh) holds W'[row i][16c + 8kh .. +7]
+    f16x8 ws[C / 16][3];
+    float bias[16];
+    {
+        const uint4 *wp = reinterpret_cast<const uint4 *>(a.Ws);
+#pragma unroll
+        for (int c = 0; c < C / 16; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                ws[c][pl] = __builtin_bit_cast(f16x8, wp[(size_t)((c * 3 + pl) * 2 + kh) * (2 * C) + wave * 32 + j]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = a.bias[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+    }
+    const int db = wave / WPD;
+    const int eb0 = (wave % WPD) * SPW;
+    f32x16 S[SPW];
+#pragma unroll
+    for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[q][r] = 0.f;
+    float m_run = -INFINITY, zsum = 0.f;             // row d = db*32 + j (both halves of the wave hold it)
+
+    // this wave's chunk of the x tile: channels 16 wave + 8 kh + i at pixel j (wave-uniform base + lane offset)
+    const char *xb = reinterpret_cast<const char *>(a.x + (size_t)b * a.x_bs + (size_t)(16 * wave) * N);
+    float xr[8], mu_r, rs_r;                          // raw values / statistics of the tile loaded last
+    auto load_x = [&](int t0) {
+        const int px = p0 + t0 + j;
+        mu_r = mean[px]; rs_r = rstd[px];
+        const unsigned voff = (unsigned)(8 * kh * N + px) * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float *>(xb + (size_t)i * N * 4 + voff);
+    };
+    auto publish_x = [&](int buf) {                   // split (x - mean) and store the two planes of this chunk
+        f16x8 xh, xl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            _Float16 hq, lq;
+            split2h(xr[i] - mu_r, hq, lq);
+            xh[i] = hq; xl[i] = lq;
+        }
+        xp[buf][wave][0][lane] = __builtin_bit_cast(uint4, xh);
+        xp[buf][wave][1][lane] = __builtin_bit_cast(uint4, xl);
+    };
+    load_x(0);
+    publish_x(0);
+    float rs = rs_r;                                  // rstd of the tile in phase 1
+    if (32 < per) load_x(32);
+    __syncthreads();
+    for (int t0 = 0; t0 < per; t0 += 32) {
+        const int buf = (t0 >> 5) & 1;
+        // ---- phase 1: kv rows of this wave = W' planes x (x - mean) planes, three products ----------------------
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C / 16; ++c) {
+            const f16x8 xh = __builtin_bit_cast(f16x8, xp[buf][c][0][lane]), xl = __builtin_bit_cast(f16x8, xp[buf][c][1][lane]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws[c][1], xh, acc, 0, 0, 0);        // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws[c][2], xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws[c][0], xh, acc, 0, 0, 0);
+        }
+        // the next tile's planes (its values arrived during the previous tile), then the loads of the one after
+        const float rs_cur = rs;
+        if (t0 + 32 < per) {
+            publish_x(buf ^ 1);
+            rs = rs_r;
+            if (t0 + 64 < per) load_x(t0 + 64);
+        }
+        // k rows as fp32 [row][pixel]; v rows as fp32 or (VP) as the planes phase 2 multiplies with
+        {
+            const float sc = rs_cur * a.wscale_inv;
+            if (!VP || wave < CB) {
+                float *kv = kbuf[buf];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    kv[row * LDK + j] = acc[r] * sc + bias[r];
+                }
+            } else {
+                _Float16 *vh = vbuf[buf][0], *vl = vbuf[buf][1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave - CB) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    _Float16 hq, lq;
+                    split2h(acc[r] * sc + bias[r], hq, lq);
+                    vh[row * LDH + j] = hq;
+                    vl[row * LDH + j] = lq;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: S[d][e] += sum_n exp(k[d][n] - m[d]) v[e][n]; register s <-> pixel 16(s/8) + 8kh + s%8 -------
+        const float *krow = kbuf[buf] + (db * 32 + j) * LDK + 8 * kh;
+        float kk[16];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const float4 k0 = *reinterpret_cast<const float4 *>(krow + 16 * st), k1 = *reinterpret_cast<const float4 *>(krow + 16 * st + 4);
+            kk[8 * st + 0] = k0.x; kk[8 * st + 1] = k0.y; kk[8 * st + 2] = k0.z; kk[8 * st + 3] = k0.w;
+            kk[8 * st + 4] = k1.x; kk[8 * st + 5] = k1.y; kk[8 * st + 6] = k1.z; kk[8 * st + 7] = k1.w;
+        }
+        float tmax = kk[0];
+#pragma unroll
+        for (int s = 1; s < 16; ++s) tmax = fmaxf(tmax, kk[s]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        if (__any(tmax > m_run)) {                   // a new row maximum somewhere in the block: rescale
+            const float mn = fmaxf(m_run, tmax);
+            const float f = fast_exp(m_run - mn);     // exp2(-inf) = 0 on the first tile
+            m_run = mn;
+            zsum *= f;
+            if (kh == 0) fac[wave][j] = f;
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the wave's own LDS writes are visible
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 f4 = *reinterpret_cast<const float4 *>(&fac[wave][8 * r4 + 4 * kh]);
+#pragma unroll
+                for (int q = 0; q < SPW; ++q) {
+                    S[q][4 * r4 + 0] *= f4.x; S[q][4 * r4 + 1] *= f4.y;
+                    S[q][4 * r4 + 2] *= f4.z; S[q][4 * r4 + 3] *= f4.w;
+                }
+            }
+        }
+        // p in (0, 1] as {PH, PL = fp16(p - PH), PH2 = PH 2^-11} (absolute error <= 3e-8)
+        f16x8 ph[2], pl[2], ph2[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p = fast_exp(kk[8 * st + i] - m_run);
+                zsum += p;
+                const _Float16 h = (_Float16)p;
+                ph[st][i] = h;
+                pl[st][i] = (_Float16)(p - (float)h);
+                ph2[st][i] = (_Float16)((float)h * (1.0f / 2048.0f));
+            }
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f16x8 vh, vl;
+                if constexpr (VP) {
+                    const int o = ((eb0 + q) * 32 + j) * LDH + 16 * st + 8 * kh;     // v[e][16 st + 8kh + i]
+                    vh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(&vbuf[buf][0][o]));
+                    vl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(&vbuf[buf][1][o]));
+                } else {
+                    const float *vrow = kbuf[buf] + (C + (eb0 + q) * 32 + j) * LDK + 8 * kh + 16 * st;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(vrow), v1 = *reinterpret_cast<const float4 *>(vrow + 4);
+                    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        _Float16 hq, lq;
+                        split2h(vv[i], hq, lq);
+                        vh[i] = hq; vl[i] = lq;
+                    }
+                }
+                S[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[st], vh, S[q], 0, 0, 0);
+                S[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph2[st], vl, S[q], 0, 0, 0);
+                S[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[st], vh, S[q], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial results of this split ---------------------------------------------------------------
+    const size_t slot = (size_t)b * a.nsplit + sp;
+#pragma unroll
+    for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            a.S[(slot * C + d) * C + (eb0 + q) * 32 + j] = S[q][r];
+        }
+    zsum += __shfl_xor(zsum, 32);
+    if (kh == 0 && eb0 == 0) {
+        a.Z[slot * C + db * 32 + j] = zsum;
+        a.M[slot * C + db * 32 + j] = m_run;
+    }
+}
+
 hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
     if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
     dim3 grid((unsigned)a.nsplit, (unsigned)B);
     static const bool w4 = getenv("CDC_KVCTX_W4") != nullptr;      // C = 128: 4 waves with the f32-MFMA projection
-    if (a.C == 64 && a.f16) hipLaunchKernelGGL((kvctx_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
+    // fp16 arithmetic: kvctx16_kernel (shared x split).  Plane-form v tile (VP) only at C = 128: at C = 64 it costs
+    // the third workgroup per CU (LDS) and the barrier-synchronised waves gain nothing from moving the split
+    // (measured, batch 32: C = 64 / 256^2 0.417 -> 0.280 ms without VP, 0.350 with; C = 128 / 128^2 0.416 -> 0.253 / 0.245).
+    static const int kv16 = getenv("CDC_KVCTX16") ? atoi(getenv("CDC_KVCTX16")) : -1;  // 0 kvctx_kernel, 1 no VP, 2 VP, -1 per C
+    const int kv = kv16 >= 0 ? kv16 : (a.C == 128 ? 2 : 1);
+    if (a.C == 64 && a.f16 && kv == 2) hipLaunchKernelGGL((kvctx16_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
+    else if (a.C == 64 && a.f16 && kv == 1) hipLaunchKernelGGL((kvctx16_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
+    else if (a.C == 128 && a.f16 && kv == 2) hipLaunchKernelGGL((kvctx16_kernel<4, 8, true>), grid, dim3(512), 0, st, a);
+    else if (a.C == 128 && a.f16 && kv == 1) hipLaunchKernelGGL((kvctx16_kernel<4, 8, false>), grid, dim3(512), 0, st, a);
+    else if (a.C == 64 && a.f16) hipLaunchKernelGGL((kvctx_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
     else if (a.C == 128 && a.f16) hipLaunchKernelGGL((kvctx_kernel<4, 8, true>), grid, dim3(512), 0, st, a);
     else if (a.C == 64) hipLaunchKernelGGL((kvctx_kernel<2, 4>), grid, dim3(256), 0, st, a);
     else if (a.C == 128 && w4) hipLaunchKernelGGL((kvctx_kernel<4, 4>), grid, dim3(256), 0, st, a);
