@@ -481,30 +481,41 @@ hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nspli
 static_assert(true, "");
 constexpr int kFoldRows = 8;     // rows per workgroup: each WoT / T1 element is reused 8x from registers
 
-// R0: ctxn[b][d][e] = (sum_split S) / (sum_split Zp)   -- one thread per element, coalesced over e
-__global__ void __launch_bounds__(256) ctx_r0_kernel(const float *S, const float *Zp, int C, int nsplit,
-                                                     float *ctxn, const float *M) {
-    const int b = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C * C) return;
-    const int d = idx / C;
-    float s = 0.f, z = 0.f;
-    if (M) {
-        // every split carries its own row maximum (kvctx_kernel): bring them to the common one
-        float mg = -INFINITY;
-        for (int sp = 0; sp < nsplit; ++sp) mg = fmaxf(mg, M[((size_t)b * nsplit + sp) * C + d]);
-        for (int sp = 0; sp < nsplit; ++sp) {
-            const float f = expf(M[((size_t)b * nsplit + sp) * C + d] - mg);
-            s += S[((size_t)b * nsplit + sp) * C * C + idx] * f;
-            z += Zp[((size_t)b * nsplit + sp) * C + d] * f;
-        }
-    } else {
-        for (int sp = 0; sp < nsplit; ++sp) {
-            s += S[((size_t)b * nsplit + sp) * C * C + idx];
-            z += Zp[((size_t)b * nsplit + sp) * C + d];
-        }
+// R0: ctxn[b][d][e] = (sum_split S) / (sum_split Zp).  One workgroup per (image, row d): the per-split rescale
+// factors exp(M[split][d] - max) are computed once per row (not once per element), the C elements of the row are
+// summed by C x SPF threads (SPF interleaved split subsets, combined through LDS) with independent loads.
+__global__ void __launch_bounds__(512) ctx_r0_kernel(const float *S, const float *Zp, int C, int nsplit,
+                                                     float *ctxn, const float *M, int SPF) {
+    extern __shared__ float r0s[];                    // [nsplit] factors, [nsplit] Z * factor, [SPF][C] partial sums
+    float *fs = r0s, *zf = r0s + nsplit, *red = r0s + 2 * nsplit;
+    const int b = blockIdx.y, d = blockIdx.x;
+    const int tid = threadIdx.x, e = tid % C, q = tid / C;
+    for (int sp = tid; sp < nsplit; sp += blockDim.x) fs[sp] = M ? M[((size_t)b * nsplit + sp) * C + d] : 0.f;
+    __syncthreads();
+    float mg = -INFINITY;
+    if (M)          // every split carries its own row maximum (kvctx kernels): bring them to the common one
+        for (int sp = 0; sp < nsplit; ++sp) mg = fmaxf(mg, fs[sp]);
+    __syncthreads();
+    for (int sp = tid; sp < nsplit; sp += blockDim.x) {
+        const float f = M ? expf(fs[sp] - mg) : 1.0f;
+        fs[sp] = f;
+        zf[sp] = Zp[((size_t)b * nsplit + sp) * C + d] * f;
     }
-    ctxn[(size_t)b * C * C + idx] = s / z;
+    __syncthreads();
+    float z = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) z += zf[sp];
+    const float *sp0 = S + ((size_t)b * nsplit * C + d) * C + e;
+    const size_t ss = (size_t)C * C;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int sp = q; sp < nsplit; sp += SPF) acc += sp0[(size_t)sp * ss] * fs[sp];
+    if (SPF > 1) {
+        red[q * C + e] = acc;
+        __syncthreads();
+        if (q == 0)
+            for (int k = 1; k < SPF; ++k) acc += red[k * C + e];
+    }
+    if (q == 0) ctxn[((size_t)b * C + d) * C + e] = acc / z;
 }
 
 __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, const float *WoT, float *T1) {
@@ -628,7 +639,10 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
                            float *biasB, int B, hipStream_t st, const float *M, unsigned short *Ws, int ws_f16) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     // Mt doubles as scratch for the normalised context (C*C <= Cin_pad*COP) until R2 overwrites it
-    hipLaunchKernelGGL(ctx_r0_kernel, dim3(ceil_div(C * C, 256), B), dim3(256), 0, st, S, ksum, C, nsplit, Mt, M);
+    int spf = 1;
+    while (2 * spf * C <= 512 && 2 * spf <= nsplit) spf *= 2;
+    hipLaunchKernelGGL(ctx_r0_kernel, dim3(C, B), dim3(C * spf), sizeof(float) * (2 * nsplit + spf * C), st, S, ksum, C, nsplit,
+                       Mt, M, spf);
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
                        sizeof(float) * kFoldRows * C, st, Mt, C, WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),
