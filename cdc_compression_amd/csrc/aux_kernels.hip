@@ -176,7 +176,8 @@ hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache) {
         static const int pl8_max = getenv("CDC_LN_PL8_MAX") ? atoi(getenv("CDC_LN_PL8_MAX")) : 256;
-        if (a.HW <= pl8_max)
+        // 8-pixel workgroups also wherever 32-pixel ones would leave most of the chip idle (small batches)
+        if (a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < 1024)
             hipLaunchKernelGGL(ln_kernel_sliced<8>, dim3((unsigned)ceil_div(a.HW, 8), (unsigned)B), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL(ln_kernel_sliced<32>, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
