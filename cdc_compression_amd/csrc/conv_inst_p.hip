@@ -51,7 +51,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         const int xsw = (4 * PH * PW + 63) / 64;
         if (xsw > 2 * kPfXS) continue;
         const int taps = s.KH * s.KW, npb = taps == 1 ? 3 : 2;
-        const size_t patch = (size_t)npb * xsw * 64 * 16, wst = (size_t)6 * COPT * 16;
+        const size_t patch = (size_t)npb * xsw * 64 * 16, wst = (size_t)pf_rows(c.MB, c.NPW) * COPT * 16;
         const int ring = pf_ring(c.MB, c.NPW, c.WM, c.WP, s.KH, s.KW);    // compile-time in the kernel
         if (!ring) continue;
         const int S = (s.Cin / 16) * taps;

@@ -51,13 +51,17 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
 // Weight ring depth of a kernel shape: what fits next to the patch buffers in the LDS budget (two 4-wave workgroups
 // or one 8-wave workgroup per CU).  Compile-time in the kernel (the counted waits become immediates, the ring
 // arithmetic folds), shared with the host planner.
+// Weight rows per stage: planes x two k-halves.  Shapes whose accumulators fit twice in the register file use
+// the planes {WH, WL} and a second accumulator set (see mma); the others the three planes {WH, WL, WH2}.
+__host__ __device__ constexpr bool pf_acc2(int MB, int NPW) { return MB * NPW <= 4; }
+__host__ __device__ constexpr int pf_rows(int MB, int NPW) { return pf_acc2(MB, NPW) ? 4 : 6; }
 __host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW) {
     return ((4 * (WP * NPW + KH - 1) * (32 + KW - 1) + 63) / 64) * 64;
 }
 __host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW) {
     const size_t budget = WM * WP == 8 ? 156 * 1024 : 80 * 1024;
     const size_t patch = (size_t)(KH * KW == 1 ? 3 : 2) * pf_patch_units(NPW, WP, KH, KW) * 16;
-    const size_t wst = (size_t)6 * WM * MB * 32 * 16;
+    const size_t wst = (size_t)pf_rows(MB, NPW) * WM * MB * 32 * 16;
     return patch + 5 * wst <= budget ? 5 : (patch + 4 * wst <= budget ? 4 : (patch + 3 * wst <= budget ? 3 : 0));
 }
 #ifndef CDC_PF_ABLATE
@@ -70,7 +74,9 @@ template <int MB, int NPW, int WM, int WP, int KH, int KW>
 __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) ? 2 : 1) conv_pf_kernel(const PfArgs P) {
     constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
     static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
-    constexpr int WI = 6 * COPT / 64;                   // DMA instructions per weight stage
+    constexpr bool ACC2 = pf_acc2(MB, NPW);
+    constexpr int NPL = ACC2 ? 2 : 3, ROWS = 2 * NPL;     // weight planes / rows per stage
+    constexpr int WI = ROWS * COPT / 64;                   // DMA instructions per weight stage
     constexpr int NWV = NW - 2;                         // weight waves 0 .. NW-3; patch waves NW-2, NW-1
     constexpr int NWW = (WI + NWV - 1) / NWV;           // DMA instructions per stage and weight wave
     constexpr int TAPS = KH * KW;
@@ -83,7 +89,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     constexpr int PST = XSW * 64;                       // units per patch buffer (tail lanes land in the slack)
     // 1x1 layers have one tap per chunk: their patches run two chunks ahead through three buffers
     constexpr int LA = TAPS == 1 ? 2 : 1, NPB = LA + 1;
-    constexpr int WST = 6 * COPT;                       // units per weight stage
+    constexpr int WST = ROWS * COPT;                       // units per weight stage
     static_assert(KX <= kPfXS, "patch too large for two patch waves");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -159,13 +165,16 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
         if (++sw == R) sw = 0;
     };
 
-    f32x16 acc[MB][NPW];
+    f32x16 acc[MB][NPW], acc2[ACC2 ? MB : 1][ACC2 ? NPW : 1];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < NPW; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[m][n][r] = 0.f;
+                if constexpr (ACC2) acc2[m][n][r] = 0.f;
+            }
 
     const int half = lane >> 5, j = lane & 31;
     const int pr = 0, pc = j;
@@ -173,14 +182,14 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     const uint4 *a_base = smem_u + NPB * PST + half * COPT + wm * MB * 32 + j;
     const uint4 *b_base = smem_u + (half * 2) * PLANE + (wp * NPW) * PW + j;
 
-    typedef f16x8 OpsA[3][MB];
+    typedef f16x8 OpsA[NPL][MB];
     typedef f16x8 OpsB[2][NPW];
     // operands of tap t (compile-time: immediates) from patch buffer xb and ring slot wa
     auto fetch = [&](auto tc, const uint4 *xb, const uint4 *wa, OpsA &A, OpsB &Bv) {
         constexpr int t = decltype(tc)::value;
         constexpr int koff = (t / KW) * PW + (t % KW);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int m = 0; m < MB; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa[(pl * 2) * COPT + m * 32]);
 #pragma unroll
@@ -188,16 +197,34 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
 #pragma unroll
             for (int n = 0; n < NPW; ++n) Bv[pl][n] = __builtin_bit_cast(f16x8, xb[pl * PLANE + n * PW + koff]);
     };
-    auto mma = [&](const OpsA &A, const OpsB &Bv) {       // smallest terms first: WL.h, WH2.l', WH.h
-#pragma unroll
-        for (int term = 0; term < 3; ++term) {
-            constexpr int PA[3] = {1, 2, 0};
-            constexpr int PB[3] = {0, 1, 0};
+    // a = h + l' 2^-11, w 2^s = WH + WL:  acc += WL.h + WH.h,  acc2 += WH.l'  (result = acc + acc2 2^-11).  The second
+    // accumulator set replaces a third weight plane WH 2^-11: a third fewer A-operand bytes through LDS-DMA, the
+    // ring and ds_read (the LDS read rate is the co-limiter of this loop), and no fp16 underflow of small weights.
+    auto mma = [&](const OpsA &A, const OpsB &Bv) {
+        if constexpr (ACC2) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < NPW; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term]][m], Bv[PB[term]][n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NPW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], Bv[0][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[1][n], acc2[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[0][n], acc[m][n], 0, 0, 0);
+        } else {                                          // smallest terms first: WL.h, WH2.l', WH.h
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                constexpr int PA[3] = {1, 2, 0};
+                constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term] % NPL][m], Bv[PB[term]][n], acc[m][n], 0, 0, 0);
+            }
         }
     };
 
@@ -312,7 +339,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
         for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                acc[m][n][r] = acc[m][n][r] * P.acc_scale + epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+                acc[m][n][r] = (ACC2 ? acc[m][n][r] + acc2[ACC2 ? m : 0][ACC2 ? n : 0][r] * (1.0f / 2048.0f) : acc[m][n][r]) * P.acc_scale +
+                               epl[m * 32 + (r & 3) + 8 * (r >> 2)];
         if (P.pre_add && valid_v[n]) {
             const float *pp = P.pre_add + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll
