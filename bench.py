@@ -181,7 +181,8 @@ def main():
             ops.append(dict(label=lab.value.decode(), ms=ms.value / n.value, n=n.value, flops=fl.value))
     L.cdc_prof_enable(h, 0)
     if rank == 0 and os.environ.get("CDC_BENCH_OPS"):       # development aid: per-op table (hipEvent averages) on stderr
-        for o in sorted(ops, key=lambda o: -o["ms"])[: int(os.environ["CDC_BENCH_OPS"])]:
+        order = ops if os.environ.get("CDC_BENCH_OPS_ORDER") else sorted(ops, key=lambda o: -o["ms"])   # program order / by time
+        for o in order[: int(os.environ["CDC_BENCH_OPS"])]:
             print(f'[op] {o["ms"]:8.4f} ms  {o["flops"] / max(o["ms"], 1e-9) / 1e9:7.1f} TF  {o["label"]}', file=sys.stderr)
 
     if rank == 0:

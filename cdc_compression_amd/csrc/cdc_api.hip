@@ -692,10 +692,23 @@ struct Builder {
     // at batch 32 those extra HBM writes in the producers cost as much as the consumers gain (round 2: 3.64 images/s
     // with planes everywhere, 3.68 with planes up to 128 x 128 (CDC_PF_MAXPIX), 3.75 without).  It pays once the
     // remaining fp32 consumers read planes too.
-    // CDC_PF: 0 off; 1 planes for every activation (opt-in, see above); default 2: planes ONLY on the block1 -> block2
-    // edge of a ResnetBlock -- h1 has a single consumer, so it is written as planes INSTEAD of fp32 (same bytes) and
-    // block2, half of all 3x3 convolutions, runs on the DMA-fed kernel at no extra traffic.
-    int pf_mode() const { const char *e = getenv("CDC_PF"); return h->arith != 1 ? 0 : (e ? atoi(e) : 2); }
+    // CDC_PF: 0 off; 1 planes for every activation (see above); 2: planes ONLY on the block1 -> block2 edge of a
+    // ResnetBlock -- h1 has a single consumer, so it is written as planes INSTEAD of fp32 (same bytes) and block2, half
+    // of all 3x3 convolutions, runs on the DMA-fed kernel at no extra traffic; default 3: 2 + a second copy where the
+    // per-op table says the consumer gains more than the producer loses (batch 32, ms per launch, producer / consumer):
+    //   ResnetBlock output feeding the next ResnetBlock of the level   +0.08 / -0.12 @256^2 ... +0.01 / -0.09 @32^2
+    //   Downsample output (next level's first ResnetBlock)             +0.03 / -0.07
+    //   attention and Upsample outputs up to 64 x 64 (the two halves of a decoder concat: 384 -> 128 @64^2 -0.19 for
+    //   +0.025); at 128^2 the two costs (+0.13) eat the gain (-0.13), the 256^2 skip has no reader at all.
+    enum Site { SITE_NONE, SITE_ALWAYS, SITE_RB_CHAIN, SITE_DOWN, SITE_JOIN };
+    int pf_mode() const { const char *e = getenv("CDC_PF"); return h->arith != 1 ? 0 : (e ? atoi(e) : 3); }
+    bool pf_site(Site s, int H, int W) const {
+        const int m = pf_mode();
+        if (m == 1) return s != SITE_NONE;
+        if (m != 3) return false;
+        static const long long join_max = getenv("CDC_PF_JOIN_MAXPIX") ? atoll(getenv("CDC_PF_JOIN_MAXPIX")) : 4096;
+        return s == SITE_RB_CHAIN || s == SITE_DOWN || (s == SITE_JOIN && (long long)H * W <= join_max);
+    }
     bool pf_on() const { return pf_mode() != 0; }
     static long long pf_maxpix() { const char *e = getenv("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
     PfTwin *twin(const float *p) { auto it = pfmap.find(p); return it == pfmap.end() ? nullptr : &it->second; }
@@ -722,10 +735,10 @@ struct Builder {
         emit(op);
         t->valid = true;
     }
-    Act new_act(int C, int H, int W, bool want_twin = true) {
+    Act new_act(int C, int H, int W, bool want_twin = true, Site site = SITE_ALWAYS) {
         Act a; a.C = C; a.H = H; a.W = W;
         a.p = dalloc((size_t)B * C * H * W);
-        if (want_twin && pf_mode() == 1) add_twin(a.p, C, H, W);
+        if (want_twin && pf_site(site, H, W)) add_twin(a.p, C, H, W);
         return a;
     }
 
@@ -1061,13 +1074,14 @@ struct Builder {
     // ResnetBlock.forward (network_components.py:107-114).  a1 = second concat source.  If
     // `a1_is_context` the block was packed with split weights: the context halves are evaluated into
     // h->pre_ops (once per decode) and enter the per-step convolutions as `pre_add`.
-    Act resblock(const ResBlockW &rb, Act a0, const Act *a1, bool a1_is_context, float *sm, float *sr) {
+    Act resblock(const ResBlockW &rb, Act a0, const Act *a1, bool a1_is_context, float *sm, float *sr,
+                 Site out_site = SITE_ALWAYS) {
         if (rc) return Act();
         const int H = a0.H, W = a0.W, HW = H * W;
         const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
         const float *shift = rb.has_mlp ? h->shift + rb.shift_off : nullptr;   // Compressor blocks: no time embedding
-        Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W);
-        if (pf_mode() == 2 && pf_would_plan(rb.c2, H, W)) add_twin(h1.p, rb.cout, H, W);
+        Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W, true, out_site);
+        if (pf_mode() >= 2 && pf_would_plan(rb.c2, H, W)) add_twin(h1.p, rb.cout, H, W);
         // h1 feeds block2 only: when block2 runs on the pre-split operand kernel the fp32 copy is never read
         static const bool keep_h1 = getenv("CDC_PF_KEEP_H1") != nullptr;
         const bool h1_pf_only = !keep_h1 && twin(h1.p) && pf_would_plan(rb.c2, H, W);
@@ -1211,7 +1225,7 @@ struct Builder {
         ConvW cw;    // per-image weights produced above
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
         cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1; cw.bias = nullptr;
-        Act y = new_act(C, H, W);
+        Act y = new_act(C, H, W, true, SITE_JOIN);      // skip tensor / Upsample input: a decoder concat half
         if (!fused)
         dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
@@ -1302,7 +1316,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
         const bool has_ctx = i < n_ctx;
         const std::string dn = "downs." + std::to_string(i);
-        x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, true, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, true, nullptr, nullptr, Builder::SITE_RB_CHAIN);
         h->taps[dn + ".0"] = x;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         h->taps[dn + ".1"] = x;
@@ -1311,7 +1325,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         skips.push_back(x);
         if (i < n - 1) {
             const ConvW &dw = h->downs[i];
-            Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2);
+            Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2, true, Builder::SITE_DOWN);
             Builder::ConvOpts od; od.emit_pf = true;
             bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), od, false, PC_DOWN);
             x = y;
@@ -1326,7 +1340,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         h->taps["mid_block1"] = x;
         x = bd.attention(h->attns[ati++], x, sm, sr);                       // mid_attn
         h->taps["mid_attn"] = x;
-        x = bd.resblock(h->rbs[rbi++], x, nullptr, false, nullptr, nullptr); // mid_block2
+        x = bd.resblock(h->rbs[rbi++], x, nullptr, false, nullptr, nullptr, Builder::SITE_JOIN); // mid_block2 (decoder concat half)
         h->taps["mid_block2"] = x;
     }
     float *fsm = nullptr, *fsr = nullptr;       // LN statistics of the last Upsample output
@@ -1336,11 +1350,11 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         skips.pop_back();
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
-        x = bd.resblock(h->rbs[rbi++], x, &skip, false, nullptr, nullptr);
+        x = bd.resblock(h->rbs[rbi++], x, &skip, false, nullptr, nullptr, Builder::SITE_RB_CHAIN);
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         x = bd.attention(h->attns[ati++], x, sm, sr);
         const ConvW &uw = h->ups[i];
-        Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2);
+        Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2, true, Builder::SITE_JOIN);
         Builder::ConvOpts ou;
         ou.emit_pf = i < n - 2;              // (the last Upsample feeds the final convolution only)
         bool done = false;
