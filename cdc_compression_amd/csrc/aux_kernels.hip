@@ -442,32 +442,58 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
 }
 
 // ctxw[b][d][e] = scale * (sum_split S[b][split][d][e]) / ksum[b][d]   (q*scale folded in, :132)
+// One workgroup = 8 rows d (= 8 input channels of the per-image 1x1 convolution out[e] = sum_d ctxw[d][e] q[d]): the
+// 8 values of a thread are one 16-byte A-operand unit, so the kernel can also emit the convolution's weight planes
+// (Ws: fp16 {WH, WL, WH2} of ctxw 2^8, layout [C/16][3][2][C][8] per image -- conv_split_kernel.h AR = 1).
+constexpr float kCtxPlaneScale = 256.0f;
 __global__ void __launch_bounds__(256) ctx_reduce_kernel(const float *S, const float *ksum, int C,
                                                          int nsplit, float scale, float *ctxw,
-                                                         int Cin_pad, int COP) {
-    const int d = blockIdx.x, b = blockIdx.y;
-    float *row = ctxw + ((size_t)b * Cin_pad + d) * COP;
-    if (d >= C) {
-        for (int e = threadIdx.x; e < COP; e += blockDim.x) row[e] = 0.f;
-        return;
+                                                         int Cin_pad, int COP, unsigned short *Ws) {
+    const int d0 = blockIdx.x * 8, b = blockIdx.y;
+    float z[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        z[r] = 0.f;
+        if (d0 + r < C)
+            for (int sp = 0; sp < nsplit; ++sp) z[r] += ksum[((size_t)b * nsplit + sp) * C + d0 + r];
     }
-    float z = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) z += ksum[((size_t)b * nsplit + sp) * C + d];
     for (int e = threadIdx.x; e < COP; e += blockDim.x) {
-        float s = 0.f;
-        if (e < C) {
-            for (int sp = 0; sp < nsplit; ++sp)
-                s += S[(((size_t)b * nsplit + sp) * C + d) * C + e];
-            s = s / z * scale;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float s = 0.f;
+            if (e < C && d0 + r < C) {
+                for (int sp = 0; sp < nsplit; ++sp)
+                    s += S[(((size_t)b * nsplit + sp) * C + d0 + r) * C + e];
+                s = s / z[r] * scale;
+            }
+            v[r] = s;
+            if (d0 + r < Cin_pad) ctxw[((size_t)b * Cin_pad + d0 + r) * COP + e] = s;
         }
-        row[e] = s;
+        if (Ws && e < C && d0 < C) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 wh, wl, wh2;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float w = v[r] * kCtxPlaneScale;
+                const _Float16 hq = (_Float16)w;
+                wh[r] = hq;
+                wl[r] = (_Float16)(w - (float)hq);
+                wh2[r] = (_Float16)((float)hq * (1.0f / 2048.0f));
+            }
+            const int q = d0 >> 4, kh = (d0 >> 3) & 1;
+            uint4 *dst = reinterpret_cast<uint4 *>(Ws) + (size_t)b * (C / 16) * 6 * C;
+            dst[(size_t)((q * 3 + 0) * 2 + kh) * C + e] = __builtin_bit_cast(uint4, wh);
+            dst[(size_t)((q * 3 + 1) * 2 + kh) * C + e] = __builtin_bit_cast(uint4, wl);
+            dst[(size_t)((q * 3 + 2) * 2 + kh) * C + e] = __builtin_bit_cast(uint4, wh2);
+        }
     }
 }
 
 hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
-                             float *ctxw, int Cin_pad, int COP, int B, hipStream_t st) {
-    hipLaunchKernelGGL(ctx_reduce_kernel, dim3(Cin_pad, B), dim3(COP >= 256 ? 256 : 64), 0, st, S,
-                       ksum, C, nsplit, scale, ctxw, Cin_pad, COP);
+                             float *ctxw, int Cin_pad, int COP, int B, hipStream_t st, unsigned short *Ws) {
+    hipLaunchKernelGGL(ctx_reduce_kernel, dim3(ceil_div(Cin_pad, 8), B), dim3(COP >= 256 ? 256 : 64), 0, st, S,
+                       ksum, C, nsplit, scale, ctxw, Cin_pad, COP, Ws);
     return hipGetLastError();
 }
 

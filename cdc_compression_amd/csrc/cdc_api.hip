@@ -1215,8 +1215,11 @@ struct Builder {
         // (measured, batch 32: 0.41 -> 0.31 ms at C = 64 / 256^2, 0.30 -> 0.20 at C = 128 / 128^2, 0.18 -> 0.10 at C = 192 / 64^2:
         //  faster than the streaming lnconv_kernel everywhere, which stays as the CDC_NO_PERIMAGE_SPLIT fallback)
         const bool split_out = fold && !no_pic && (C % 32) == 0 && (W & 3) == 0;
-        const bool planes_f16 = split_out && h->arith == 1;
-        unsigned short *Ws = (stream_out || split_out) ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
+        // few-pixel levels (not folded): the per-image product out = ctx^T q as a split convolution as well (planes from
+        // ctx_reduce_kernel) -- it was the last user of the fp32 -> bf16x3 register-staged kernel on the decode path
+        const bool split_ctxq = !fold && !no_pic && h->arith == 1 && (C % 32) == 0 && (W & 3) == 0 && !getenv("CDC_NO_CTXQ_SPLIT");
+        const bool planes_f16 = (split_out && h->arith == 1) || split_ctxq;
+        unsigned short *Ws = (stream_out || split_out || split_ctxq) ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
         r.at_M = kmaxs; r.at_Ws = Ws; r.at_ws_f16 = planes_f16 ? 1 : 0;
         r.bytes = 4.0 * B * nsplit * C * C;
@@ -1229,7 +1232,7 @@ struct Builder {
         if (!fused)
         dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
-        if (split_out) {
+        if (split_out || split_ctxq) {
             cw.wsp = Ws;                                   // (bf16 planes unless planes_f16)
             if (planes_f16) { cw.wsh = Ws; cw.wscale_inv = 1.0f / 256.0f; }
         }
@@ -1260,6 +1263,7 @@ struct Builder {
         Act o = new_act(C, H, W, false);
         dbg_taps.push_back({o.p, (size_t)B * C * N});
         ConvOpts oo; oo.w_bs = (long long)Cin_pad * COP; oo.no_bias = true;
+        if (split_ctxq) oo.wsp_bs = (long long)(C / 16) * 6 * C * 8;
         conv(cw, qkv.p, C, qkv.bs(), nullptr, 0, H, W, o.p, o.bs(), oo, false, PC_CONV1);
         ConvOpts oy; oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
         oy.emit_pf = true;
@@ -1546,7 +1550,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             break;
         case Op::CTXR:
             HIP_TRY(h, ctx_reduce_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale,
-                                         op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st));
+                                         op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st, op.at_ws_f16 ? op.at_Ws : nullptr));
             break;
         case Op::KVCTX: HIP_TRY(h, kvctx_launch(op.kvc, B, st)); break;
         case Op::LNCONV: HIP_TRY(h, lnconv_launch(op.lnc, B, st)); break;

@@ -127,7 +127,7 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
 // ctxw[b][d][e] = scale * sum_split S / ksum[d], written as per-image packed 1x1 weights
 // [Cin_pad][COP] (rows d >= C and cols e >= C zeroed)
 hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
-                             float *ctxw, int Cin_pad, int COP, int B, hipStream_t st);
+                             float *ctxw, int Cin_pad, int COP, int B, hipStream_t st, unsigned short *Ws = nullptr);
 
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,

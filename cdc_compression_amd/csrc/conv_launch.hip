@@ -295,13 +295,15 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     const int xv = p.xvec ? 4 : 1;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
-    static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
     conv_kernel_fn fn = p.t4 ? conv_lookup_split2_t4(p.MB) : p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
+#ifdef CDC_WITH_ABLATIONS      // tuning build only (make ABL=1): compile-time ablated kernels, wrong results
+    static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
     if (ablate && p.split == 1)
         if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;
     if (ablate && p.lnmode == 0 && !p.split)
         if (conv_kernel_fn f2 = conv_lookup_abl(p.MB, p.NPW, ablate)) fn = f2;
+#endif
     if (!fn) return hipErrorInvalidValue;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn,
