@@ -288,6 +288,7 @@ __device__ __forceinline__ void ctx_dma16(const float *g, unsigned lds_byte) {
                  : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
 }
 
+template <bool F16>      // F16: sum_n p v on the fp16 matrix cores with two-plane operands (as kvctx16_kernel, attn_kernels.hip)
 __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const float *v,
                                                           long long kv_bs, int C, int N,
                                                           const float *kmax, float *S, float *Zp,
@@ -343,6 +344,50 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
         if (n0 + kCtxPch < n_end) issue(n0 + kCtxPch, stage ^ 1);
         const float *kl = sm + stage * 8192, *vl = kl + 4096;
         const int nb = wave * 16;
+        if constexpr (F16) {
+            // one K = 16 step per wave and chunk: lane (row jj, half) holds pixels nb + 8 half .. + 7 of its row -- two
+            // swizzled 4-pixel groups.  p = exp(k - max) in (0, 1] as {PH, PL, PH2 = PH 2^-11}, v as (h, l'): three products.
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const int g0 = (nb + 8 * half) >> 2;
+            const int o0 = 4 * (g0 ^ (jj & 15)), o1 = 4 * ((g0 + 1) ^ (jj & 15));
+            h8 ph[2], pl[2], ph2[2], vhi[2], vlo[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 k0 = *reinterpret_cast<const float4 *>(kl + (i * 32 + jj) * 64 + o0);
+                const float4 k1 = *reinterpret_cast<const float4 *>(kl + (i * 32 + jj) * 64 + o1);
+                const float kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const bool pv = n0 + nb + 8 * half + t < n_end;
+                    const float pp = pv ? expf(kk[t] - mrow[i]) : 0.f;
+                    zrow[i] += pp;
+                    const _Float16 hq = (_Float16)pp;
+                    ph[i][t] = hq;
+                    pl[i][t] = (_Float16)(pp - (float)hq);
+                    ph2[i][t] = (_Float16)((float)hq * (1.0f / 2048.0f));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(vl + (j * 32 + jj) * 64 + o0);
+                const float4 v1 = *reinterpret_cast<const float4 *>(vl + (j * 32 + jj) * 64 + o1);
+                const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const _Float16 hq = (_Float16)vv[t];
+                    vhi[j][t] = hq;
+                    vlo[j][t] = (_Float16)((vv[t] - (float)hq) * 2048.0f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[i], vhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph2[i], vlo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[i], vhi[j], acc[i][j], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 16; ks += 2) {
             const int nl = nb + ks + half;                       // pixel inside the chunk
@@ -421,7 +466,7 @@ __global__ void __launch_bounds__(256) ctx_partial_generic_kernel(const float *k
 
 hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
                               const float *kmax, float *S, float *Zp, int nsplit, int B,
-                              hipStream_t st) {
+                              hipStream_t st, int f16) {
     if (N & 3) {                                 // 16-byte DMA pieces need N % 4 == 0
         hipLaunchKernelGGL(ctx_partial_generic_kernel, dim3(C, nsplit, B), dim3(C >= 256 ? 256 : 64), 0, st,
                            k, v, kv_bs, C, N, kmax, S, Zp, nsplit);
@@ -431,13 +476,19 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
     const size_t lds = sizeof(float) * 4 * 64 * 64;      // ring == reduction buffer
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)ctx_partial_kernel,
+        hipError_t e = hipFuncSetAttribute((const void *)ctx_partial_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)ctx_partial_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(ctx_partial_kernel, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
-                       kv_bs, C, N, kmax, S, Zp, nsplit, tiles);
+    if (f16)
+        hipLaunchKernelGGL(ctx_partial_kernel<true>, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
+                           kv_bs, C, N, kmax, S, Zp, nsplit, tiles);
+    else
+        hipLaunchKernelGGL(ctx_partial_kernel<false>, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
+                           kv_bs, C, N, kmax, S, Zp, nsplit, tiles);
     return hipGetLastError();
 }
 

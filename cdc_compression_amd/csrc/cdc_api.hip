@@ -1544,10 +1544,12 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
         case Op::KSTATS:
             HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, B, st));
             break;
-        case Op::CTXP:
+        case Op::CTXP: {
+            static const bool ctxp_f32 = getenv("CDC_CTXP_F32") != nullptr;
             HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
-                                          op.at.S, op.at.ksum, op.at.nsplit, B, st));
+                                          op.at.S, op.at.ksum, op.at.nsplit, B, st, h->arith == 1 && !ctxp_f32));
             break;
+        }
         case Op::CTXR:
             HIP_TRY(h, ctx_reduce_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale,
                                          op.at.ctxw, op.at.Cin_pad, op.at.COP, B, st, op.at_ws_f16 ? op.at_Ws : nullptr));
