@@ -982,6 +982,10 @@ struct Builder {
             c.cp_parts = plan.ksplit; c.cp_part_stride = (long long)B * dense_bs;
             c.bytes = 4.0 * B * dense_bs * (plan.ksplit + 1);
             emit(c);
+            // split-K epilogues cannot emit planes (partial sums): pack the reduced tensor where a reader wants them
+            if (o.emit_pf && !w.transposed)
+                if (PfTwin *to = twin(out))
+                    if (to->C == w.Cout && to->H == s.Ho && to->W == s.Wo && out_bs == (long long)w.Cout * s.Ho * s.Wo) pack(out, out_bs);
         }
         return true;
     }
