@@ -706,7 +706,7 @@ struct Builder {
         const int m = pf_mode();
         if (m == 1) return s != SITE_NONE;
         if (m != 3) return false;
-        static const long long join_max = getenv("CDC_PF_JOIN_MAXPIX") ? atoll(getenv("CDC_PF_JOIN_MAXPIX")) : 4096;
+        const long long join_max = getenv("CDC_PF_JOIN_MAXPIX") ? atoll(getenv("CDC_PF_JOIN_MAXPIX")) : 4096;
         return s == SITE_RB_CHAIN || s == SITE_DOWN || (s == SITE_JOIN && (long long)H * W <= join_max);
     }
     bool pf_on() const { return pf_mode() != 0; }
@@ -1549,7 +1549,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, B, st));
             break;
         case Op::CTXP: {
-            static const bool ctxp_f32 = getenv("CDC_CTXP_F32") != nullptr;
+            const bool ctxp_f32 = getenv("CDC_CTXP_F32") != nullptr;
             HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
                                           op.at.S, op.at.ksum, op.at.nsplit, B, st, h->arith == 1 && !ctxp_f32));
             break;

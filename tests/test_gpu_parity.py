@@ -162,6 +162,31 @@ def test_linear_attention_matches_oracle(O, G, case):
     assert relerr(got, ref) < 5e-5, relerr(got, ref)
 
 
+@pytest.mark.parametrize("case,env", [((2, 64, 64, 64), {"CDC_KVCTX16": "0"}), ((2, 64, 64, 64), {"CDC_KVCTX16": "2"}),
+                                      ((1, 128, 64, 64), {"CDC_KVCTX16": "0"}), ((1, 128, 64, 64), {"CDC_KVCTX16": "1"}),
+                                      ((2, 128, 16, 16), {"CDC_NO_CTXQ_SPLIT": "1"}), ((2, 128, 16, 16), {"CDC_CTXP_F32": "1"}),
+                                      ((1, 192, 32, 32), {}), ((1, 192, 32, 32), {"CDC_CTXP_F32": "1", "CDC_NO_CTXQ_SPLIT": "1"}),
+                                      ((2, 64, 64, 64), {"CDC_ARITH": "0"})])
+def test_linear_attention_alternate_kernels(O, case, env, monkeypatch):
+    """The non-default attention kernels (older fused front half, plane-form v tile on / off, f32-MFMA partial context,
+    register-staged ctx^T q product, bf16x3 arithmetic) against the same oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from cdc_compression_amd.ops import Ops
+    G2 = Ops(0)                               # (the arithmetic is read when the handle is created)
+    B, C, H, W = case
+    x = synth.normal("ax", (B, C, H, W), 24)
+    sd = {"a.fn.norm.g": synth.normal("ag", (1, C, 1, 1), 24, 0.2, 1.0),
+          "a.fn.norm.b": synth.normal("ab", (1, C, 1, 1), 24, 0.2),
+          "a.fn.fn.to_qkv.weight": synth.normal("aq", (3 * C, C, 1, 1), 24, 2.0 / np.sqrt(C)),
+          "a.fn.fn.to_out.weight": synth.normal("ao", (C, C, 1, 1), 24, 1.0 / np.sqrt(C)),
+          "a.fn.fn.to_out.bias": synth.normal("aob", (C,), 24, 0.1)}
+    ref = om.attention(O, sd, "a", x)
+    got = G2.linear_attention(x, sd["a.fn.norm.g"], sd["a.fn.norm.b"], sd["a.fn.fn.to_qkv.weight"],
+                              sd["a.fn.fn.to_out.weight"], sd["a.fn.fn.to_out.bias"])
+    assert relerr(got, ref) < 5e-5, relerr(got, ref)
+
+
 def make_unet(name):
     kw, man, sd, x, time, ctx, g = load_case(name)
     un = cdc.Unet(**kw)
@@ -180,6 +205,8 @@ def test_unet_forward_matches_reference_golden(name):
 
 @pytest.mark.parametrize("name,env", [("full_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}), ("small_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),
                                       ("full_eps", {"CDC_PF": "1", "CDC_PF_MAXPIX": "16384"}),
+                                      ("full_x", {"CDC_PF": "2"}), ("full_x", {"CDC_PF": "0"}), ("full_eps", {"CDC_PF": "2"}),
+                                      ("full_x", {"CDC_PF_JOIN_MAXPIX": "65536"}),
                                       ("full_x", {"CDC_ARITH": "0"}), ("odd_x", {"CDC_ARITH": "0"})])
 def test_unet_forward_alternate_kernel_modes(name, env, monkeypatch):
     """The same goldens through the opt-in pre-split operand kernel and through the bf16x3 arithmetic."""
