@@ -57,6 +57,11 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         const int S = (s.Cin / 16) * taps;
         if (S < ring - 1) continue;                               // the prologue fills ring - 1 slots
         const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * (s.Cout / COPT) * s.nz;
+        // Few workgroups (small batches at the 64^2 / 32^2 levels): the register-staged kernel with split-K fills the
+        // chip better (batch 1: 192->192 @64^2 0.032 ms against 0.09 here; 128->128 @128^2 with 128 workgroups: 0.07
+        // against 0.038 -- the threshold sits between the two)
+        static const double min_waves = getenv("CDC_PF_MIN_WAVES") ? atof(getenv("CDC_PF_MIN_WAVES")) : 256.0;
+        if (wgs * NW < min_waves) continue;
         const double fill = std::min(1.0, wgs * NW / 2048.0);
         const double reads = (3.0 * c.MB + 2.0 * c.NPW) / (3.0 * c.MB * c.NPW);   // ds_read_b128 per MFMA
         const double score = fill * (1.0 - 0.35 * reads) * (s.Cout / COPT > 1 ? 0.9 : 1.0);
