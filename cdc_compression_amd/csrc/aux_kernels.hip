@@ -79,7 +79,10 @@ constexpr int kLnCache = 48;
 
 // PL pixels x CS = 256/PL channel slices per workgroup: PL = 32 normally, 8 for the few-pixel levels (more
 // workgroups; a thread then walks C/32 channels x nparts split-K slices).
-template <int PL>
+// NP: number of split-K slices summed on load (compile-time: all loads of a thread are issued back to back; with a
+// run-time slice loop every slice of every channel row was its own serialized round trip -- 26 us per launch at the
+// few-pixel levels); NP = 0: run-time a.nparts (> 4).
+template <int PL, int NP>
 __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
     constexpr int CS = 256 / PL, NV = 8 * kLnCache / CS;
     __shared__ float red[CS][PL + 1];
@@ -91,13 +94,31 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
     const float *x = a.in + base;
     float v[NV];
     float s = 0.f;
+    if constexpr (NP > 0) {
+        float t[NP][NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = cs + CS * i;
-        v[i] = (pv && c < a.C) ? x[(size_t)c * a.HW] : 0.f;
-        for (int k = 1; k < a.nparts; ++k)            // split-K slices of the producing convolution
-            v[i] += (pv && c < a.C) ? x[(size_t)k * a.part_stride + (size_t)c * a.HW] : 0.f;
-        s += v[i];
+        for (int k = 0; k < NP; ++k)                  // split-K slices of the producing convolution
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = cs + CS * i;
+                t[k][i] = (pv && c < a.C) ? x[(size_t)k * a.part_stride + (size_t)c * a.HW] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = t[0][i];
+#pragma unroll
+            for (int k = 1; k < NP; ++k) v[i] += t[k][i];           // same order as the run-time loop: slice 0, 1, 2, ...
+            s += v[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = cs + CS * i;
+            v[i] = (pv && c < a.C) ? x[(size_t)c * a.HW] : 0.f;
+            for (int k = 1; k < a.nparts; ++k)
+                v[i] += (pv && c < a.C) ? x[(size_t)k * a.part_stride + (size_t)c * a.HW] : 0.f;
+            s += v[i];
+        }
     }
     red[cs][pl] = s;
     __syncthreads();
@@ -177,11 +198,27 @@ hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.C <= 8 * kLnCache) {
         static const int pl8_max = getenv("CDC_LN_PL8_MAX") ? atoi(getenv("CDC_LN_PL8_MAX")) : 256;
         // 8-pixel workgroups also wherever 32-pixel ones would leave most of the chip idle (small batches)
-        if (a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < 1024)
-            hipLaunchKernelGGL(ln_kernel_sliced<8>, dim3((unsigned)ceil_div(a.HW, 8), (unsigned)B), dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL(ln_kernel_sliced<32>, dim3((unsigned)ceil_div(a.HW, 32), (unsigned)B), dim3(256), 0,
-                               st, a);
+        const bool pl8 = a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < 1024;
+        const dim3 grid((unsigned)ceil_div(a.HW, pl8 ? 8 : 32), (unsigned)B);
+#define CDC_LN_LAUNCH(PLV, NPV) hipLaunchKernelGGL((ln_kernel_sliced<PLV, NPV>), grid, dim3(256), 0, st, a)
+        if (pl8) {
+            switch (a.nparts) {
+                case 1: CDC_LN_LAUNCH(8, 1); break;
+                case 2: CDC_LN_LAUNCH(8, 2); break;
+                case 3: CDC_LN_LAUNCH(8, 3); break;
+                case 4: CDC_LN_LAUNCH(8, 4); break;
+                default: CDC_LN_LAUNCH(8, 0); break;
+            }
+        } else {
+            switch (a.nparts) {                       // (48 cached values per thread and slice)
+                case 1: CDC_LN_LAUNCH(32, 1); break;
+                case 2: CDC_LN_LAUNCH(32, 2); break;
+                case 3: CDC_LN_LAUNCH(32, 3); break;
+                case 4: CDC_LN_LAUNCH(32, 4); break;
+                default: CDC_LN_LAUNCH(32, 0); break;
+            }
+        }
+#undef CDC_LN_LAUNCH
         return hipGetLastError();
     }
     const int block = a.HW >= 256 ? 256 : 64;
