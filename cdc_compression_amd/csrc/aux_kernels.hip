@@ -853,17 +853,39 @@ hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
 }
 
 // dst[b][i] = sum_k src[k*part_stride + b*src_bs + i]   (parts = 1: plain channel copy; > 1: split-K slices)
+// dst = sum of `PARTS` slices of src (split-K reduce; PARTS = 1: plain copy), float4 per thread; PARTS = 0: run-time
+// count.  The slices are summed in slice order (0, 1, 2, ...), all loads of a thread in flight together.
+template <int PARTS, class V>
 __global__ void __launch_bounds__(256) copy_kernel(const float *src, long long src_bs, float *dst,
                                                    long long dst_bs, long long n, int parts, long long part_stride,
                                                    const int *step_ptr, long long step_stride) {
     const int b = blockIdx.y;
-    const float *s = src + (size_t)b * src_bs + (step_ptr ? (size_t)*step_ptr * step_stride : 0);
-    float *d = dst + (size_t)b * dst_bs;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+    const V *s = reinterpret_cast<const V *>(src + (size_t)b * src_bs + (step_ptr ? (size_t)*step_ptr * step_stride : 0));
+    V *d = reinterpret_cast<V *>(dst + (size_t)b * dst_bs);
+    constexpr int VW = sizeof(V) / sizeof(float);
+    const long long nv = n / VW, ps = part_stride / VW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
          i += (long long)gridDim.x * blockDim.x) {
-        float v = s[i];
-        for (int k = 1; k < parts; ++k) v += s[(size_t)k * part_stride + i];
-        d[i] = v;
+        if constexpr (PARTS > 0) {
+            V t[PARTS];
+#pragma unroll
+            for (int k = 0; k < PARTS; ++k) t[k] = s[(size_t)k * ps + i];
+            V v = t[0];
+#pragma unroll
+            for (int k = 1; k < PARTS; ++k) {
+                if constexpr (VW == 4) { v.x += t[k].x; v.y += t[k].y; v.z += t[k].z; v.w += t[k].w; }
+                else v += t[k];
+            }
+            d[i] = v;
+        } else {
+            V v = s[i];
+            for (int k = 1; k < parts; ++k) {
+                const V u = s[(size_t)k * ps + i];
+                if constexpr (VW == 4) { v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                else v += u;
+            }
+            d[i] = v;
+        }
     }
 }
 
@@ -954,9 +976,24 @@ hipError_t dequantize_launch(const float *x, const float *loc, float *out, long 
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
                                 long long n, int B, hipStream_t st, int parts, long long part_stride,
                                 const int *step_ptr, long long step_stride) {
-    const int gx = (int)std::min<long long>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(copy_kernel, dim3(gx, B), dim3(256), 0, st, src, src_bs, dst, dst_bs, n, parts, part_stride,
-                       step_ptr, step_stride);
+    const bool v4 = ((n | src_bs | dst_bs | part_stride | step_stride) & 3) == 0 &&
+                    ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0;
+    const long long nv = v4 ? n / 4 : n;
+    const dim3 grid((unsigned)std::min<long long>((nv + 255) / 256, 2048), (unsigned)B);
+#define CDC_COPY(P, V) hipLaunchKernelGGL((copy_kernel<P, V>), grid, dim3(256), 0, st, src, src_bs, dst, dst_bs, n, parts, \
+                                          part_stride, step_ptr, step_stride)
+    if (v4) {
+        switch (parts) {
+            case 1: CDC_COPY(1, float4); break;
+            case 2: CDC_COPY(2, float4); break;
+            case 3: CDC_COPY(3, float4); break;
+            case 4: CDC_COPY(4, float4); break;
+            default: CDC_COPY(0, float4); break;
+        }
+    } else {
+        CDC_COPY(0, float);
+    }
+#undef CDC_COPY
     return hipGetLastError();
 }
 
