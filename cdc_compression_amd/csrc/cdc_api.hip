@@ -1215,7 +1215,7 @@ struct Builder {
                                 !getenv("CDC_NO_LNCONV");
         // folded output as a 1x1 split convolution with per-image planes (C % 16 == 0, planes layout = the A-operand
         // layout of conv_split2_kernel with COP == C): replaces the f32-MFMA kernel and, where faster, lnconv_kernel
-        static const bool no_pic = getenv("CDC_NO_PERIMAGE_SPLIT") != nullptr;
+        const bool no_pic = getenv("CDC_NO_PERIMAGE_SPLIT") != nullptr;
         // (measured, batch 32: 0.41 -> 0.31 ms at C = 64 / 256^2, 0.30 -> 0.20 at C = 128 / 128^2, 0.18 -> 0.10 at C = 192 / 64^2:
         //  faster than the streaming lnconv_kernel everywhere, which stays as the CDC_NO_PERIMAGE_SPLIT fallback)
         const bool split_out = fold && !no_pic && (C % 32) == 0 && (W & 3) == 0;

@@ -20,7 +20,6 @@ conv_kernel_fn conv_lookup_split(int MB, int NPW);           // conv_split_kerne
 conv_kernel_fn conv_lookup_split_abl(int MB, int NPW, int abl);
 conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);
 conv_kernel_fn conv_lookup_split2h(int MB, int NPW, int lnmode, int xu = 1);   // AR = 1: two fp16 planes
-conv_kernel_fn conv_lookup_split2_t4(int MB);     // ConvTranspose2d(4,2,1): all four phases per workgroup   // register-staged variant, 2 WGs/CU
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;

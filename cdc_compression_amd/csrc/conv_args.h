@@ -145,7 +145,6 @@ struct ConvPlan {
     int ipw;                // images per workgroup (1: tiles inside one image)
     int ksplit = 1;         // K slices (split2 only)
     int xu = 1;             // patch units per thread (split2 only)
-    int t4 = 0;             // transposed convolution with all four phases per workgroup
     int arith = 0;          // split2 only: 0 three bf16 planes (6 MFMA products), 1 two fp16 planes (3 products)
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };

@@ -53,8 +53,4 @@ conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu) {
     }
     return nullptr;
 }
-conv_kernel_fn conv_lookup_split2_t4(int MB) {
-    if (MB == 2) return conv_split2_kernel<2, 1, 0, 1, 4>;
-    return nullptr;
-}
 }  // namespace cdc

@@ -206,27 +206,6 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                           s.Cin >= (s.KH * s.KW > 1 ? 16 : 32) && (s.C0 % 16) == 0 &&
                           s.Win > 0 && (s.Win & 3) == 0 && (((1 << lognbw) * s.stride) & 3) == 0 &&
                           !getenv("CDC_NO_SPLIT");
-    // ConvTranspose2d(4,2,1) with wide maps: all four phases in one workgroup (conv_split2_kernel NZ = 4).
-    // Measured SLOWER than four phase launches folded onto one XCD (0.54 vs 0.46 ms at 128^2 -> 256^2): the
-    // 128 accumulator registers force (2,1) tiles and two workgroups per CU.  Kept as an experiment (CDC_T4=1).
-    if (split_ok && s.nz == 4 && s.KH == 2 && s.KW == 2 && s.stride == 1 && s.lnmode == 0 && (s.Cout % 64) == 0 &&
-        lognbw == 5 && nb_rows >= 4 && conv_lookup_split2_t4(2) && !f_mb && (!s.need_all_cout || nblocks == 2) &&
-        getenv("CDC_T4")) {
-        ConvPlan p;
-        p.MB = 2; p.NPW = 1; p.WN = 4;
-        p.groups = nblocks / 2;
-        p.KC = 16; p.nchunk = ceil_div(s.Cin, 16);
-        p.lognbw = lognbw;
-        const int TH = 4 * NBH;
-        p.tiles_x = ceil_div(s.Wo, 32); p.tiles_y = ceil_div(s.Ho, TH);
-        p.PH = TH + 2; p.PW = round_up(3 + 32 + 2, 4);
-        p.xvec = 1;
-        for (int z = 0; z < 4; ++z) p.xshift[z] = 3;
-        p.lds_bytes = sizeof(float) * ((size_t)24 * p.PH * p.PW + (size_t)2 * 24 * 64);
-        p.lnmode = 0; p.split = 2; p.tg = 1; p.ipw = 1; p.xu = 1; p.t4 = 1; p.ksplit = 1;
-        *plan = p;
-        return true;
-    }
     if (split_ok) {
         for (int MB : mbs) {
             if (f_mb && !s.need_all_cout && MB != f_mb) continue;
@@ -295,7 +274,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     const int xv = p.xvec ? 4 : 1;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
-    conv_kernel_fn fn = p.t4 ? conv_lookup_split2_t4(p.MB) : p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
+    conv_kernel_fn fn = p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
 #ifdef CDC_WITH_ABLATIONS      // tuning build only (make ABL=1): compile-time ablated kernels, wrong results
     static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
@@ -314,9 +293,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
               (unsigned)(nz * a.ksplit));
     a.zfold = 0;
-    if (p.t4) grid.z = 1;                        // the kernel walks the four phases itself
     a.xcd_remap = (p.split != 1 && p.ipw == 1 && grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
-    if (!p.t4 && p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0 && !getenv("CDC_NO_ZFOLD")) {
+    if (p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0 && !getenv("CDC_NO_ZFOLD")) {
         a.zfold = 1; grid.x *= 4; grid.z = 1;
     }
     dim3 block(64 * p.WN);

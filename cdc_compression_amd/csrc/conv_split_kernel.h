@@ -250,23 +250,20 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 // LNMODE 2 (1x1 only): PreNorm LayerNorm folded as in conv_kernel.h -- the pixel mean is subtracted before
 // the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
 // three workgroups per CU wherever the accumulators leave room (<= 168 VGPRs)
-constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int NZ = 1, int AR = 0) {
-    if (XU > 1 || NZ > 1) return 2;
+constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int AR = 0) {
+    if (XU > 1) return 2;
     return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (LNMODE == 2 && (MB * NPW == 3 || (MB == 4 && NPW == 1))))) ? 3 : 2;
 }
 
 // XU = patch units per thread (2 for the large stride-2 patches).  Stride 2 keeps the even and the odd
 // patch columns in separate half-rows of the LDS planes, so that the B-operand reads of a tap (every
 // other column) are contiguous 16-byte units instead of a 2-way bank conflict.
-// NZ = 4: ConvTranspose2d(4, 2, 1) with ALL FOUR output phases in one workgroup.  The phases read the same
-// (TH+2) x (NBW+2) input patch (a pad-1 3x3 window), so it is fetched and split once instead of four times,
-// a chunk carries 16 (phase, tap) stages instead of 4, and a lane ends up holding out[2y+py][2x], out[..][2x+1]
-// which go out as 8-byte stores (full lines) instead of two interleaved 4-byte-strided writes.
-template <int MB, int NPW, int LNMODE = 0, int XU = 1, int NZ = 1, int AR = 0>
-__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, AR)) conv_split2_kernel(const ConvArgs P) {
+// (An all-phase ConvTranspose2d variant -- four phases per workgroup, one shared patch -- was measured slower than four
+// phase launches folded onto one XCD, 0.54 vs 0.46 ms at 128^2 -> 256^2, and was removed in round 2.)
+template <int MB, int NPW, int LNMODE = 0, int XU = 1, int AR = 0>
+__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) conv_split2_kernel(const ConvArgs P) {
     constexpr int NP = AR == 1 ? 2 : 3;               // B-operand (activation) planes
     static_assert(XU == 1 || LNMODE == 0, "two-unit variant carries no LayerNorm-on-load");
-    static_assert(NZ == 1 || (NZ == 4 && XU == 1 && LNMODE == 0), "all-phase variant: plain transposed convolution");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef CDC_TIMELINE
     int tl_n = 0;
@@ -311,15 +308,15 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
     const int team = wpi * 64, uid = (ipw > 1 ? (wave % wpi) * 64 : wave * 64) + lane;
     const int TH = wpi * NPW * NBH;
     const int oy0 = ty * TH, ox0 = tx * NBW;
-    const int iy0 = NZ == 4 ? oy0 - 1 : oy0 * P.stride - P.pad_y[z];     // NZ = 4: the union window of the phases
-    const int ix0 = NZ == 4 ? ox0 - 1 : ox0 * P.stride - P.pad_x[z];
+    const int iy0 = oy0 * P.stride - P.pad_y[z];
+    const int ix0 = ox0 * P.stride - P.pad_x[z];
     const int PH = P.PH, PW = P.PW;
     const int plane = PH * PW;
     const int nc16 = P.Cin_pad >> 4;
 
     const int TG = P.tg;                              // taps per weight stage (a kernel row, or 1)
     const int ntg1 = (P.KH * P.KW) / TG;              // stages per phase
-    const int ntg = NZ * ntg1;                        // stages per chunk (NZ = 4: phase-major)
+    const int ntg = ntg1;                             // stages per chunk
     const int xc_floats = NP * 8 * plane, wst_floats = TG * 24 * COPT;
     float *xc = smem + (ipw > 1 ? (wave / wpi) * xc_floats : 0);     // one split patch per image
     float *wl = smem + ipw * xc_floats;
@@ -452,7 +449,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
     };
     const int n_w = TG * 6 * COPT;
     const int wsl = (n_w + nthr - 1) / nthr;
-    const unsigned short *wsrc = P.wsp + (size_t)(NZ == 4 ? 0 : z) * P.wsp_zs + (size_t)cog * COPT * 8 + (size_t)b * P.wsp_bs;
+    const unsigned short *wsrc = P.wsp + (size_t)z * P.wsp_zs + (size_t)cog * COPT * 8 + (size_t)b * P.wsp_bs;
     // Per-thread byte offsets of its units inside one (group, chunk) weight stage: they do not depend on
     // the group or the chunk (those move the scalar base), so the in-loop DMA issue is address-free.
     // A stage has TG*6*COPT units = a whole number of waves, so the tail test is wave-uniform.
@@ -482,8 +479,8 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
     }
     const bool w_fast = wsl <= kWS;
     auto issue_w = [&](int grp, int chunk, int stage) {
-        const int zz = NZ == 4 ? grp / ntg1 : 0, g1 = NZ == 4 ? grp - zz * ntg1 : grp;
-        const unsigned short *base = wsrc + (size_t)zz * P.wsp_zs + ((size_t)(g1 * TG) * nc16 + chunk) * 6 * P.COP * 8;
+        const int g1 = grp;
+        const unsigned short *base = wsrc + ((size_t)(g1 * TG) * nc16 + chunk) * 6 * P.COP * 8;
         const float *wbase = uniform_ptr(reinterpret_cast<const float *>(base));
         const unsigned dst = wl_lds + (unsigned)(stage * wst_floats) * 4u + (unsigned)(wave * 64) * 16u;
         if (w_fast) {
@@ -506,20 +503,18 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
         }
     };
 
-    f32x16 acc[NZ][MB][NPW];
-#pragma unroll
-    for (int q = 0; q < NZ; ++q)
+    f32x16 acc[1][MB][NPW];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < NPW; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[0][m][n][r] = 0.f;
 
     const int half = lane >> 5;
     const int j = lane & 31;
     const int pr = j >> P.lognbw, pc = j & (NBW - 1);
-    const int xs = P.xshift[NZ == 4 ? 0 : z];
+    const int xs = P.xshift[z];
     const int b_lane = half * plane + (rb * NPW * NBH + pr) * P.stride * PW + (s2 ? pc : pc + xs);
     const int nb_stride = NBH * P.stride * PW;
     const int a_lane = half * COPT + j;
@@ -554,17 +549,16 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
         if (chunk + 1 < c_hi) load_x(chunk + 1);     // in flight during the tap loop; the group-end
                                                      // waits cover it (issued >= one group earlier)
 #endif
-#pragma unroll
-        for (int zz = 0; zz < NZ; ++zz)              // NZ = 4: the output phase of this stage (static: acc[zz])
+        constexpr int zz = 0;
         for (int g1 = 0; g1 < ntg1; ++g1) {
-            const int grp = zz * ntg1 + g1;
+            const int grp = g1;
 #ifndef CDC_AB_NOW
             if (grp + 1 < ntg) issue_w(grp + 1, chunk, wstage ^ 1);
             else if (chunk + 1 < c_hi) issue_w(0, chunk + 1, wstage ^ 1);
 #endif
             const uint4 *wa = reinterpret_cast<const uint4 *>(wl + wstage * wst_floats) + a_lane;
             int ky = (g1 * TG) / P.KW, kx = g1 * TG - ky * P.KW;        // uniform tap walk (SALU)
-            const int zoff = NZ == 4 ? (zz >> 1) * PW + (zz & 1) : 0;   // phase (py, px): window shifted by (py, px)
+            const int zoff = 0;
             __builtin_amdgcn_s_setprio(3);      // waves inside the tap loop win issue arbitration over waves that are
                                                 // converting / in an epilogue (+1 % measured, whole model)
             for (int t = 0; t < TG; ++t) {
@@ -644,66 +638,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, NZ, A
     TileGeom geom{tid, nthr, wave, half, pr, pc, ipw > 1 ? (int)blockIdx.x * ipw : b, z, cog, oy0, ox0, NBH};
     geom.ipw = ipw; geom.wpi = wpi; geom.nimg = P.B;
     geom.out_off = (long long)ks * P.out_ks; geom.no_bias = ks > 0;
-    if constexpr (NZ == 4) {
-        // ---- all-phase epilogue: bias, optional LN statistics per output pixel, 8-byte stores -----------
-        __syncthreads();
-        float *ep = smem;
-        for (int i = tid; i < COPT; i += nthr) {
-            const int co = cog * COPT + i;
-            ep[i] = (co < P.Cout && P.bias) ? P.bias[co] : 0.f;
-        }
-        __syncthreads();
-        const float *epl = ep + 4 * half;
-        const float inv_c = 1.0f / (float)P.Cout;
-        const int Wout = 2 * P.Wo;
-#pragma unroll
-        for (int n = 0; n < NPW; ++n) {
-            const int oy = oy0 + (rb * NPW + n) * NBH + pr, ox = ox0 + pc;
-            const bool valid = (oy < P.Ho) && (ox < P.Wo) && img_ok;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[q][m][n][r] = acc[q][m][n][r] * P.acc_scale + epl[m * 32 + (r & 3) + 8 * (r >> 2)];
-            if (P.stat_mean) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float sm = 0.f;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sm += acc[q][m][n][r];
-                    sm += __shfl_xor(sm, 32);
-                    const float mean = sm * inv_c;
-                    float sq = 0.f;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { const float d = acc[q][m][n][r] - mean; sq += d * d; }
-                    sq += __shfl_xor(sq, 32);
-                    if (valid && half == 0) {
-                        const size_t pix = (size_t)(2 * oy + (q >> 1)) * Wout + 2 * ox + (q & 1);
-                        P.stat_mean[(size_t)b * P.out_cs + pix] = mean;
-                        P.stat_rstd[(size_t)b * P.out_cs + pix] = 1.0f / sqrtf(sq * inv_c + P.eps);
-                    }
-                }
-            }
-            if (valid) {
-#pragma unroll
-                for (int py = 0; py < 2; ++py) {
-                    float *op = P.out + (size_t)b * P.out_bs + (size_t)(2 * oy + py) * Wout + 2 * ox +
-                                (size_t)(cog * COPT + 4 * half) * P.out_cs;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            *reinterpret_cast<float2 *>(op + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs) =
-                                make_float2(acc[2 * py][m][n][r], acc[2 * py + 1][m][n][r]);
-                }
-            }
-        }
-    } else {
+    {
 #ifdef CDC_AB_NOEPI
     { float sacc = 0.f;
       for (int m = 0; m < MB; ++m) for (int n = 0; n < NPW; ++n) for (int r = 0; r < 16; ++r) sacc += acc[0][m][n][r];

@@ -207,9 +207,12 @@ def test_unet_forward_matches_reference_golden(name):
                                       ("full_eps", {"CDC_PF": "1", "CDC_PF_MAXPIX": "16384"}),
                                       ("full_x", {"CDC_PF": "2"}), ("full_x", {"CDC_PF": "0"}), ("full_eps", {"CDC_PF": "2"}),
                                       ("full_x", {"CDC_PF_JOIN_MAXPIX": "65536"}),
+                                      ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
+                                      ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
+                                      ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
                                       ("full_x", {"CDC_ARITH": "0"}), ("odd_x", {"CDC_ARITH": "0"})])
 def test_unet_forward_alternate_kernel_modes(name, env, monkeypatch):
-    """The same goldens through the opt-in pre-split operand kernel and through the bf16x3 arithmetic."""
+    """The same goldens through the non-default kernel selections: plane policies, bf16x3 arithmetic, the f32-MFMA convolution path, no context hoisting, unfused / unfolded attention."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     un, kw, sd, x, time, ctx, g = make_unet(name)
