@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) 
     int wstage = 0;
     TL();
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
-        if (chunk > c_lo) __syncthreads();          // everyone finished reading the previous chunk's planes
+        // (everyone finished reading the previous chunk's planes: the barrier that ends its last tap group)
         TL();
 #ifndef CDC_AB_NOSTOREX
         store_x(chunk);
