@@ -1685,7 +1685,7 @@ int check_ready(cdc_handle *h) {
 // =================================================================================================
 extern "C" {
 
-const char *cdc_version(void) { return "cdc_hip 0.8 (gfx950; fp32-exact convolutions on the bf16 matrix cores)"; }
+const char *cdc_version(void) { return "cdc_hip 0.9 (gfx950; fp32-class convolutions from split fp16 / bf16 operands on the matrix cores)"; }
 
 const char *cdc_last_error(const cdc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
