@@ -195,7 +195,7 @@ def main():
         groups = {}
         def launch_key(label):                              # shape + tile shape + which kernel + residual input
             t = label.split()
-            kern = "PF" if "PF" in t else ("SPLIT2H" if "SPLIT2H" in t else ("SPLIT2" if "SPLIT2" in t else "CONV"))
+            kern = "PF" if "PF" in t else ("PW" if "PW" in t else ("SPLIT2H" if "SPLIT2H" in t else ("SPLIT2" if "SPLIT2" in t else "CONV")))
             return " ".join(t[:8]) + " " + kern + (" +res" if "+res" in t else "")
         for o in conv_ops:
             key = launch_key(o["label"])

@@ -72,6 +72,7 @@ struct Op {
     double flops = 0, bytes = 0;
     ConvArgs conv; ConvPlan plan; int nz = 1;
     PfArgs pf; PfPlan pfplan;     // CONVPF: pre-split fp16 operands by LDS-DMA (conv_pf_kernel.h)
+    bool pw = false;              // CONVPF on conv_pw_kernel (pointwise, activations from the fp32 tensor)
     LnArgs ln;
     TembArgs temb;
     struct { const float *k, *v; long long bs; int C, N; float *kmax, *ksum, *S, *ctxw;
@@ -649,9 +650,9 @@ struct Builder {
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)
-            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d PF%s%s%s%s", op.pf.KH, op.pf.KW,
+            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s", op.pf.KH, op.pf.KW,
                      op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
-                     op.pfplan.groups, op.pfplan.ring, op.pf.ep_g ? " LN" : "", op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
+                     op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pf.ep_g ? "PF LN" : "PF"), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
                      op.pf.resid ? " +res" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
@@ -847,6 +848,58 @@ struct Builder {
         return true;
     }
 
+    // Pointwise convolutions at the >= 32-pixel-wide levels on conv_pw_kernel (fp16 arithmetic): activations staged
+    // per wave straight from the fp32 sources, PreNorm folded as (x - mean) on load / rstd in the epilogue.
+    bool try_pw(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W,
+                float *out, long long out_bs, const ConvOpts &o, bool need_all, int prof, const ConvShape &s) {
+        if (h->arith != 1 || !w.wsh || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
+        if (getenv("CDC_NO_PW")) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0) return false;
+        if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || o.no_f32) return false;
+        if (o.pre_mean && o.pre_mode != 2) return false;
+        if (o.w_bs && !o.wsp_bs) return false;              // per-image weights without planes
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = 1; ps.KW = 1; ps.nz = 1;
+        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = B; ps.need_all_cout = false;
+        PfPlan plan;
+        if (!pw_make_plan(ps, &plan)) return false;
+        Op op;
+        if (getenv("CDC_DEBUG_PLAN"))
+            fprintf(stderr, "[plan] conv1x1 PW Cin=%4d Cout=%4d out=%3dx%-3d %s%s| MB=%d NPW=%d WM=%d WP=%d groups=%d R=%d wgs=%d lds=%zu\n", w.Cin, w.Cout,
+                    s.Ho, s.Wo, o.pre_mean ? "pre2 " : "", o.wsp_bs ? "per-image " : "", plan.MB, plan.NPW, plan.WM, plan.WP, plan.groups, plan.ring,
+                    plan.tiles_x * plan.tiles_y * B * plan.groups, plan.lds_bytes);
+        op.kind = Op::CONVPF; op.prof = prof; op.pfplan = plan; op.nz = 1; op.pw = true;
+        PfArgs &a = op.pf;
+        memset(&a, 0, sizeof a);
+        a.x0 = s0; a.x0_bs = bs0; a.x1 = s1; a.x1_bs = bs1;
+        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
+        a.pre_mean = o.pre_mean; a.pre_rstd = o.pre_mean ? o.pre_rstd : nullptr;
+        a.w = w.wsh; a.w_bs = o.wsp_bs / 8;             // units of 8 halfs
+        a.KH = 1; a.KW = 1; a.nz = 1;
+        a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout;
+        a.acc_scale = w.wscale_inv;
+        a.out = out; a.out_bs = out_bs;
+        a.out_cs = (long long)s.Ho * s.Wo; a.out_ys = s.Wo; a.out_xs = 1;
+        a.Ho = s.Ho; a.Wo = s.Wo;
+        if (PfTwin *to = o.emit_pf ? twin(out) : nullptr)
+            if (to->C == w.Cout && to->H == s.Ho && to->W == s.Wo && out_bs == (long long)w.Cout * s.Ho * s.Wo && (w.Cout % 32) == 0) {
+                a.out_pf = to->p; a.pf_bs = to->bs(); a.pf_ps = to->ps();
+                a.pf_ys = s.Wo + 2; a.pf_xs = 1; a.pf_zoff[0] = (s.Wo + 2) + 1;
+                to->valid = true;
+            }
+        a.bias = o.no_bias ? nullptr : w.bias;
+        a.pre_add = o.pre_add;
+        a.relu = o.relu; a.relu_slope = o.relu_slope; a.eps = 1e-5f;
+        a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
+        a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
+        const double px = (double)B * s.Ho * s.Wo;
+        op.flops = 2.0 * px * w.Cout * w.Cin;
+        op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
+        last_ksplit = 1;
+        emit(op);
+        return true;
+    }
+
     // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
     bool conv(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1,
@@ -878,6 +931,7 @@ struct Builder {
         s.B = B; s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
         if (try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
+        if (try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
         if (!getenv("CDC_NO_KSPLIT") && !getenv("CDC_NO_KSPLIT_PLAN"))
@@ -1539,7 +1593,10 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
     }
     switch (op.kind) {
         case Op::CONV: HIP_TRY(h, conv_launch(op.conv, op.plan, B, op.nz, st)); break;
-        case Op::CONVPF: HIP_TRY(h, pf_launch(op.pf, op.pfplan, B, op.nz, st)); break;
+        case Op::CONVPF:
+            if (op.pw) HIP_TRY(h, pw_launch(op.pf, op.pfplan, B, st));
+            else HIP_TRY(h, pf_launch(op.pf, op.pfplan, B, op.nz, st));
+            break;
         case Op::PFPACK:
             HIP_TRY(h, pf_pack_launch(op.pk.src, op.pk.src_bs, op.pk.dst, op.pk.dst_bs, op.pk.C, op.pk.H, op.pk.W, B, st));
             break;

@@ -48,6 +48,9 @@ struct PfShape {
 struct PfPlan { int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; };
 bool pf_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pf_launch(PfArgs a, const PfPlan &plan, int B, int nz, hipStream_t st);
+// pointwise (1x1) convolution with per-wave activation staging from the fp32 tensor (conv_pw_kernel.h, conv_inst_w.hip)
+bool pw_make_plan(const PfShape &s, PfPlan *plan);
+hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
 hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long long dst_bs, int C, int H, int W, int B,
                           hipStream_t st);
 

@@ -126,6 +126,11 @@ struct PfArgs {
     float *stat_mean, *stat_rstd;
     const float *res3_w, *res3_x;   // 3-channel res_conv in the epilogue (see ConvArgs)
     long long res3_bs;
+    // conv_pw_kernel (conv_pw_kernel.h): the activation operand is read from fp32 NCHW sources by the lanes themselves
+    const float *x0, *x1;           // fp32 sources (channel concatenation), x1 may be null
+    long long x0_bs, x1_bs;         // batch strides in floats
+    const float *pre_mean, *pre_rstd;   // [B][H*W] PreNorm statistics: (x - mean) on load, rstd in the epilogue (or null)
+    long long w_bs;                 // per-image weight planes (folded attention output): stride in units, 0 = shared
     int dbg;                        // CDC_PF_DBG (timing experiments, wrong results): 1 no weight DMA in the loop, 2 no patch
                                     // DMA in the loop, 4 no barrier in the loop, 8 no DMA waits, 16 no epilogue stores
 };

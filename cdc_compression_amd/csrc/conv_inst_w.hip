@@ -1,0 +1,73 @@
+// conv_inst_w.hip -- instantiations, plan chooser and launcher of conv_pw_kernel (pointwise convolution, activations
+// staged per wave by 4-byte LDS-DMA from the fp32 tensor).
+#include <algorithm>
+#include <stdlib.h>
+
+#include "cdc_internal.h"
+#include "conv_pw_kernel.h"
+
+namespace cdc {
+
+typedef void (*pw_kernel_fn)(const PfArgs);
+static pw_kernel_fn pw_lookup(int MB, int NPW, int WM, int WP) {
+    if (MB == 2 && NPW == 2 && WM == 1 && WP == 4) return conv_pw_kernel<2, 2, 1, 4>;
+    if (MB == 2 && NPW == 2 && WM == 2 && WP == 2) return conv_pw_kernel<2, 2, 2, 2>;
+    if (MB == 2 && NPW == 2 && WM == 4 && WP == 2) return conv_pw_kernel<2, 2, 4, 2>;
+    if (MB == 3 && NPW == 1 && WM == 2 && WP == 4) return conv_pw_kernel<3, 1, 2, 4>;
+    return nullptr;
+}
+struct PwCand { int MB, NPW, WM, WP; };
+static const PwCand kPwCands[] = {
+    {2, 2, 4, 2},   // 256 channels per workgroup, 8 waves, 4 rows
+    {3, 1, 2, 4},   // 192 channels, 8 waves, 4 rows
+    {2, 2, 2, 2},   // 128 channels, 4 waves, 4 rows
+    {2, 2, 1, 4},   //  64 channels, 4 waves, 8 rows
+};
+
+bool pw_make_plan(const PfShape &s, PfPlan *p) {
+    if (s.KH != 1 || s.KW != 1 || s.nz != 1) return false;
+    if (s.Cout % 32 || s.Cin % 16 || (s.C0 % 16) || s.Cin < 32) return false;
+    if (s.Wo < 32) return false;                              // 32-pixel blocks are row segments
+    const double min_waves = getenv("CDC_PW_MIN_WAVES") ? atof(getenv("CDC_PW_MIN_WAVES")) : 512.0;   // (per call: tests switch it)
+    double best = -1;
+    for (const PwCand &c : kPwCands) {
+        const int COPT = c.WM * c.MB * 32, NW = c.WM * c.WP;
+        if (s.Cout % COPT) continue;
+        if (s.need_all_cout && COPT != s.Cout) continue;
+        const int ring = pw_ring(c.MB, c.NPW, c.WM, c.WP);
+        if (ring < 5 || s.Cin / 16 < 2) continue;
+        const int TH = c.WP * c.NPW;
+        const int groups = s.Cout / COPT;
+        const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * groups;
+        if (wgs * NW < min_waves) continue;
+        const double fill = std::min(1.0, wgs * NW / 2048.0);
+        // every channel group reads and splits the activations again: prefer few groups; wider tiles reuse the weights
+        const double score = fill / (1.0 + 0.25 * (groups - 1)) * (c.MB * c.NPW >= 4 ? 1.0 : 0.8);
+        if (score > best) {
+            best = score;
+            p->MB = c.MB; p->NPW = c.NPW; p->WM = c.WM; p->WP = c.WP;
+            p->ring = ring;
+            p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + TH - 1) / TH;
+            p->groups = groups;
+            p->lds_bytes = (size_t)ring * pf_rows(c.MB, c.NPW) * COPT * 16 + pw_x_bytes(c.NPW, c.WM, c.WP);
+        }
+    }
+    return best >= 0;
+}
+
+hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
+    pw_kernel_fn fn = pw_lookup(p.MB, p.NPW, p.WM, p.WP);
+    if (!fn) return hipErrorInvalidValue;
+    a.lognbw = 5;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
+    if (p.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
+    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
+    hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace cdc

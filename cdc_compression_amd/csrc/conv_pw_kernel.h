@@ -1,0 +1,290 @@
+// conv_pw_kernel.h -- 1x1 (pointwise) convolution in fp16x2 arithmetic with a barrier-free activation path.
+//
+// For a pointwise convolution the MFMA B operand of a lane (pixel j, k-half) is 8 channels of ITS OWN pixel.  Every wave
+// stages its own activations: 4-byte LDS-DMA, one instruction per channel row and 32-pixel block (lanes 0-31 / 32-63 =
+// the two k-halves, 128-byte row segments of the fp32 NCHW tensor), into a private LDS area PD steps ahead; the lane
+// reads its 8 values back, subtracts the PreNorm mean if there is one and splits into the two fp16 planes in registers.
+// No patch, no conversion pass, no ds_write, and no barrier for the activations (a wave only ever reads what it
+// requested itself: its own s_waitcnt suffices).  All vector-memory operations of the main loop are LDS-DMA, so the
+// counted s_waitcnt vmcnt is exact: per step a wave issues L = 8*NPW activation pieces, then its NWW weight pieces.
+// The weights go through the LDS-DMA ring of conv_pf_kernel.h (every wave issues its share of a stage, one s_barrier
+// per 16-channel step), shared by the WM x WP waves; shapes with MB*NPW <= 4 use the planes {WH, WL} and a second
+// accumulator set.  Epilogue: scale (2^-s, x rstd of the pixel with PreNorm), bias, hoisted partial sums, ReLU,
+// per-image shift, residual, fp32 store and / or PF planes.
+//
+// It replaces conv_split2_kernel for 1x1 layers at the >= 32-pixel-wide levels, where that kernel's per-chunk cost (two
+// barriers, conversion through LDS, loads one chunk ahead) bounds the 18 MFMAs of a chunk (256 -> 768 @32^2 batch 32:
+// 0.098 ms there).
+#pragma once
+#include "conv_pf_kernel.h"
+
+namespace cdc {
+
+constexpr int kPwPD = 2;                            // activation stages in flight per wave
+__host__ __device__ constexpr size_t pw_x_bytes(int NPW, int WM, int WP) { return (size_t)WM * WP * kPwPD * NPW * 8 * 256; }
+__host__ __device__ constexpr int pw_ring(int MB, int NPW, int WM, int WP) {
+    const size_t budget = (WM * WP == 8 ? 150 * 1024 : 78 * 1024) - pw_x_bytes(NPW, WM, WP);
+    const size_t wst = (size_t)pf_rows(MB, NPW) * WM * MB * 32 * 16;
+    const int r = (int)(budget / wst);
+    return r > 6 ? 6 : r;
+}
+
+__device__ __forceinline__ void dma4(unsigned voff, const void *sbase, unsigned lds_byte) {   // 4 bytes per lane
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte)
+                 : "memory");
+}
+
+template <int MB, int NPW, int WM, int WP>
+__global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_kernel(const PfArgs P) {
+    constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
+    static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
+    constexpr bool ACC2 = pf_acc2(MB, NPW);
+    constexpr int NPL = ACC2 ? 2 : 3, ROWS = 2 * NPL;
+    constexpr int WI = ROWS * COPT / 64;                // DMA instructions per weight stage
+    constexpr int NWW = (WI + NW - 1) / NW;             // ... per wave (every wave issues)
+    constexpr int WST = ROWS * COPT;                    // units per weight stage
+    constexpr int R = pw_ring(MB, NPW, WM, WP);
+    static_assert(R >= 5, "no room for the weight ring");
+    constexpr int TH = WP * NPW;
+    constexpr int PD = kPwPD;                           // activation stages in flight
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WP, wp = wave % WP;
+    const int cog = blockIdx.y;
+    unsigned bid0 = blockIdx.x;
+    if (P.xcd_remap) bid0 = (bid0 & 7) * (gridDim.x >> 3) + (bid0 >> 3);
+    int bid = (int)bid0;
+    const int tx = bid % P.tiles_x;
+    bid /= P.tiles_x;
+    const int ty = bid % P.tiles_y;
+    const int b = bid / P.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * 32;
+    const int S = P.nchunk;                             // steps = 16-channel chunks
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
+
+    // ---- weights: instruction jj of a stage covers units [64jj, 64jj+64) = row jj / (COPT/64) of {plane, k-half} ----
+    const char *wsrc = reinterpret_cast<const char *>(P.w) + ((size_t)b * P.w_bs + (size_t)cog * COPT) * 16;
+    unsigned wvo[NWW], wdo[NWW];
+#pragma unroll
+    for (int k = 0; k < NWW; ++k) {
+        const int jj = min(wave + k * NW, WI - 1);        // clamped duplicates are harmless
+        const int row = jj / (COPT / 64), seg = jj - row * (COPT / 64);
+        wvo[k] = (unsigned)(row * P.COP + seg * 64 + lane) * 16u;
+        wdo[k] = __builtin_amdgcn_readfirstlane((unsigned)jj * 1024u);
+    }
+    const long long w_dc = (long long)6 * P.COP * 16;     // next chunk (the stored layout keeps three planes)
+    const char *wptr = wsrc;
+    int sw = 0;
+    auto issue_w = [&]() {
+        const unsigned dst = lds0 + (unsigned)(sw * WST) * 16u;
+#pragma unroll
+        for (int k = 0; k < NWW; ++k) dma16(wvo[k], wptr, dst + wdo[k]);
+        wptr += w_dc;
+        if (++sw == R) sw = 0;
+    };
+
+    // ---- activations: lane (pixel j of its row block, k-half) requests channels 16c + 8 half + i of that pixel -------
+    const int half = lane >> 5, j = lane & 31;
+    const int HW = P.H * P.W;
+    unsigned xvo[NPW];                                  // byte offset of the lane's (k-half, pixel) inside a 16-channel chunk
+    float mu[NPW];
+    bool valid[NPW];
+    unsigned pixo[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int oy = oy0 + wp * NPW + n, ox = ox0 + j;
+        valid[n] = oy < P.Ho && ox < P.Wo;
+        pixo[n] = (unsigned)(min(oy, P.Ho - 1) * P.W + min(ox, P.Wo - 1));
+        xvo[n] = ((unsigned)(8 * half) * (unsigned)HW + pixo[n]) * 4u;
+        mu[n] = P.pre_mean ? P.pre_mean[(size_t)b * HW + pixo[n]] : 0.f;
+    }
+    const float *xs0 = P.x0 + (size_t)b * P.x0_bs;
+    const float *xs1 = P.x1 ? P.x1 + (size_t)b * P.x1_bs : nullptr;
+    const int c0_chunks = P.C0 >> 4;
+    constexpr int L = 8 * NPW;                          // activation pieces per step and wave
+    constexpr int XST = NPW * 8 * 64;                   // floats per activation stage of one wave
+    float *xw = reinterpret_cast<float *>(smem_u + R * WST) + wave * (PD * XST);    // this wave's private stages
+    const unsigned xw_lds = lds0 + (unsigned)(R * WST) * 16u + (unsigned)(wave * (PD * XST)) * 4u;
+    auto issue_x = [&](int c, int slot) {               // stage layout [n][i][lane]
+        const char *base = reinterpret_cast<const char *>(uniform_ptr(c < c0_chunks ? xs0 + (size_t)c * 16 * HW : xs1 + (size_t)(c - c0_chunks) * 16 * HW));
+        const unsigned dst = xw_lds + (unsigned)(slot * XST) * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const char *row = base + (size_t)i * HW * 4;  // wave-uniform
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) dma4(xvo[n], row, dst + (unsigned)((n * 8 + i) * 64) * 4u);
+        }
+    };
+
+    f32x16 acc[MB][NPW], acc2[ACC2 ? MB : 1][ACC2 ? NPW : 1];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[m][n][r] = 0.f;
+                if constexpr (ACC2) acc2[m][n][r] = 0.f;
+            }
+    const uint4 *a_base = smem_u + half * COPT + wm * MB * 32 + j;
+    typedef f16x8 OpsA[NPL][MB];
+    typedef f16x8 OpsB[2][NPW];
+    auto fetch_a = [&](const uint4 *wa, OpsA &A) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa[(pl * 2) * COPT + m * 32]);
+    };
+    auto split_b = [&](int slot, OpsB &Bv) {           // the wave's own stage -> the two fp16 planes
+        const float *src = xw + slot * XST + lane;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                _Float16 hq, lq;
+                split2h(src[(n * 8 + i) * 64] - mu[n], hq, lq);
+                Bv[0][n][i] = hq; Bv[1][n][i] = lq;
+            }
+    };
+    auto mma = [&](const OpsA &A, const OpsB &Bv) {
+        if constexpr (ACC2) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], Bv[0][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[1][n], acc2[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[0][n], acc[m][n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                constexpr int PA[3] = {1, 2, 0};
+                constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term] % NPL][m], Bv[PB[term]][n], acc[m][n], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: activations of steps 0 .. PD-1, weight stages 0 .. R-2 ----------------------------------------
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < S) issue_x(d, d);
+    for (int q = 0; q < R - 1 && q < S; ++q) issue_w();
+    dma_wait();                                         // prologue: everything, once
+    __builtin_amdgcn_s_barrier();
+    OpsA A0, A1;
+    OpsB B0, B1;
+    fetch_a(a_base, A0);
+    split_b(0, B0);
+    if (PD < S) issue_x(PD, 0);                         // (after the reads of slot 0: same wave, program order)
+    int sn = 0;
+    // One step: operands of step s in (Ac, Bc).  Order of a wave's VM queue per step: [x pieces of step s+1+PD][weight
+    // pieces of stage s+R-1].  Needed now: the x pieces of step s+1 (requested at step s-PD... i.e. PD steps ago) and
+    // W(s+1).  Newer than the former: that step's weight pieces + (PD-1) full steps = NWW + (PD-1)(L+NWW); W(s+1) is
+    // older still (R >= PD+2).  In the tail (something was not issued) wait for everything.
+    auto step = [&](int s, auto slotc, OpsA &Ac, OpsB &Bc, OpsA &An, OpsB &Bn) {
+        constexpr int slot = decltype(slotc)::value;    // (s + 1) % PD, compile-time: PD == 2
+        if (s + 1 < S) {
+            if (++sn == R) sn = 0;
+            if (s >= PD && s + R - 1 < S && s + 1 + PD < S) vm_wait<NWW + (PD - 1) * (L + NWW)>(); else dma_wait();
+            __builtin_amdgcn_s_barrier();
+            fetch_a(a_base + sn * WST, An);
+            split_b(slot, Bn);
+            if (s + 1 + PD < S) issue_x(s + 1 + PD, slot);
+            if (s + R - 1 < S) issue_w();
+        }
+        __builtin_amdgcn_s_setprio(2);
+        mma(Ac, Bc);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    static_assert(PD == 2 && R >= PD + 3, "two activation stages; W(s+1) must be older than the activation pieces of step s+1");
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    {
+        int s = 0;
+        for (; s + 1 < S; s += 2) {
+            step(s, P1{}, A0, B0, A1, B1);
+            step(s + 1, P0{}, A1, B1, A0, B0);
+        }
+        if (s < S) step(s, P1{}, A0, B0, A1, B1);
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_barrier();                         // every wave is done with the ring
+    float *ep = reinterpret_cast<float *>(smem_u);        // [2][COPT]: bias, shift
+    for (int i = tid; i < COPT; i += NT) {
+        const int co = cog * COPT + i;
+        const bool ok = co < P.Cout;
+        ep[i] = (ok && P.bias) ? P.bias[co] : 0.f;
+        ep[COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
+    }
+    __syncthreads();
+    const int cobase = cog * COPT + wm * MB * 32;
+    const float *epl = ep + wm * MB * 32 + 4 * half;
+    const bool ch_ok = cobase + MB * 32 <= P.Cout;        // host: Cout % (MB*32) == 0 per wave part
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int oy = oy0 + wp * NPW + n, ox = ox0 + j;
+        const bool ok = valid[n] && ch_ok;
+        const float sc = P.pre_rstd ? P.acc_scale * P.pre_rstd[(size_t)b * HW + pixo[n]] : P.acc_scale;
+        const size_t opix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[0];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[m][n][r] = (ACC2 ? acc[m][n][r] + acc2[ACC2 ? m : 0][ACC2 ? n : 0][r] * (1.0f / 2048.0f) : acc[m][n][r]) * sc +
+                               epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+        if (!ok) continue;
+        if (P.pre_add) {
+            const float *pp = P.pre_add + (size_t)b * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += pp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs];
+        }
+        if (P.relu) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], P.relu_slope * acc[m][n][r]);
+        }
+        if (P.shift) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += epl[COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
+        }
+        if (P.resid) {
+            const float *rp = P.resid + (size_t)b * P.resid_bs + opix + (size_t)(cobase + 4 * half) * P.resid_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += rp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.resid_cs];
+        }
+        if (P.out) {
+            float *op = P.out + (size_t)b * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
+        }
+        if (P.out_pf) {
+            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[0];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps, P.pf_ps, half, acc[m][n]);
+        }
+    }
+}
+
+}  // namespace cdc

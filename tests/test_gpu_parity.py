@@ -210,6 +210,7 @@ def test_unet_forward_matches_reference_golden(name):
                                       ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
                                       ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
                                       ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
+                                      ("full_x", {"CDC_NO_PW": "1"}), ("full_x", {"CDC_PW_MIN_WAVES": "1"}), ("full_eps", {"CDC_PW_MIN_WAVES": "1"}),
                                       ("full_x", {"CDC_ARITH": "0"}), ("odd_x", {"CDC_ARITH": "0"})])
 def test_unet_forward_alternate_kernel_modes(name, env, monkeypatch):
     """The same goldens through the non-default kernel selections: plane policies, bf16x3 arithmetic, the f32-MFMA convolution path, no context hoisting, unfused / unfolded attention."""
