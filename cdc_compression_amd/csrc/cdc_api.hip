@@ -863,6 +863,7 @@ struct Builder {
         ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = B; ps.need_all_cout = false;
         PfPlan plan;
         if (!pw_make_plan(ps, &plan)) return false;
+        if (plan.lin && (o.shift || o.wsp_bs || (long long)w.Cout * s.Ho * s.Wo != out_bs)) return false;   // tiles span images
         Op op;
         if (getenv("CDC_DEBUG_PLAN"))
             fprintf(stderr, "[plan] conv1x1 PW Cin=%4d Cout=%4d out=%3dx%-3d %s%s| MB=%d NPW=%d WM=%d WP=%d groups=%d R=%d wgs=%d lds=%zu\n", w.Cin, w.Cout,
@@ -881,7 +882,7 @@ struct Builder {
         a.out = out; a.out_bs = out_bs;
         a.out_cs = (long long)s.Ho * s.Wo; a.out_ys = s.Wo; a.out_xs = 1;
         a.Ho = s.Ho; a.Wo = s.Wo;
-        if (PfTwin *to = o.emit_pf ? twin(out) : nullptr)
+        if (PfTwin *to = (o.emit_pf && !plan.lin) ? twin(out) : nullptr)
             if (to->C == w.Cout && to->H == s.Ho && to->W == s.Wo && out_bs == (long long)w.Cout * s.Ho * s.Wo && (w.Cout % 32) == 0) {
                 a.out_pf = to->p; a.pf_bs = to->bs(); a.pf_ps = to->ps();
                 a.pf_ys = s.Wo + 2; a.pf_xs = 1; a.pf_zoff[0] = (s.Wo + 2) + 1;

@@ -45,7 +45,7 @@ struct PfShape {
     int Cin, Cout, C0 = 0, KH, KW, nz = 1, Ho, Wo, B;
     bool need_all_cout = false;
 };
-struct PfPlan { int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; };
+struct PfPlan { int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; int lin = 0; };
 bool pf_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pf_launch(PfArgs a, const PfPlan &plan, int B, int nz, hipStream_t st);
 // pointwise (1x1) convolution with per-wave activation staging from the fp32 tensor (conv_pw_kernel.h, conv_inst_w.hip)

@@ -131,6 +131,8 @@ struct PfArgs {
     long long x0_bs, x1_bs;         // batch strides in floats
     const float *pre_mean, *pre_rstd;   // [B][H*W] PreNorm statistics: (x - mean) on load, rstd in the epilogue (or null)
     long long w_bs;                 // per-image weight planes (folded attention output): stride in units, 0 = shared
+    int lin;                        // conv_pw_kernel on maps narrower than 32 pixels: a 32-pixel block = 32 consecutive pixels
+                                    // of one image's flattened H*W (H*W % 32 == 0), a workgroup may span images
     int dbg;                        // CDC_PF_DBG (timing experiments, wrong results): 1 no weight DMA in the loop, 2 no patch
                                     // DMA in the loop, 4 no barrier in the loop, 8 no DMA waits, 16 no epilogue stores
 };

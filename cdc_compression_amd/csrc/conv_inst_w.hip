@@ -27,7 +27,9 @@ static const PwCand kPwCands[] = {
 bool pw_make_plan(const PfShape &s, PfPlan *p) {
     if (s.KH != 1 || s.KW != 1 || s.nz != 1) return false;
     if (s.Cout % 32 || s.Cin % 16 || (s.C0 % 16) || s.Cin < 32) return false;
-    if (s.Wo < 32) return false;                              // 32-pixel blocks are row segments
+    // maps narrower than 32 pixels: 32-pixel blocks of the flattened image, a workgroup may span images ("linear" tiles)
+    const bool lin = s.Wo < 32;
+    if (lin && ((s.Ho * s.Wo) % 32)) return false;
     const double min_waves = getenv("CDC_PW_MIN_WAVES") ? atof(getenv("CDC_PW_MIN_WAVES")) : 512.0;   // (per call: tests switch it)
     double best = -1;
     for (const PwCand &c : kPwCands) {
@@ -38,7 +40,9 @@ bool pw_make_plan(const PfShape &s, PfPlan *p) {
         if (ring < 5 || s.Cin / 16 < 2) continue;
         const int TH = c.WP * c.NPW;
         const int groups = s.Cout / COPT;
-        const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * groups;
+        const long long nb = (long long)s.B * (s.Ho * s.Wo / 32);     // linear mode: blocks of the whole batch
+        const double wgs = lin ? (double)((nb + TH - 1) / TH) * groups
+                               : (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * groups;
         if (wgs * NW < min_waves) continue;
         const double fill = std::min(1.0, wgs * NW / 2048.0);
         // every channel group reads and splits the activations again: prefer few groups; wider tiles reuse the weights
@@ -47,7 +51,9 @@ bool pw_make_plan(const PfShape &s, PfPlan *p) {
             best = score;
             p->MB = c.MB; p->NPW = c.NPW; p->WM = c.WM; p->WP = c.WP;
             p->ring = ring;
-            p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + TH - 1) / TH;
+            p->lin = lin ? 1 : 0;
+            p->tiles_x = lin ? (int)((nb + TH - 1) / TH) : (s.Wo + 31) / 32;
+            p->tiles_y = lin ? 1 : (s.Ho + TH - 1) / TH;
             p->groups = groups;
             p->lds_bytes = (size_t)ring * pf_rows(c.MB, c.NPW) * COPT * 16 + pw_x_bytes(c.NPW, c.WM, c.WP);
         }
@@ -64,7 +70,8 @@ hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
+    a.lin = p.lin;
+    dim3 grid((unsigned)(p.lin ? p.tiles_x : p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
     a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
     hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
     return hipGetLastError();

@@ -55,10 +55,11 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
     unsigned bid0 = blockIdx.x;
     if (P.xcd_remap) bid0 = (bid0 & 7) * (gridDim.x >> 3) + (bid0 >> 3);
     int bid = (int)bid0;
+    const int tile = bid;                               // (linear mode: TH consecutive 32-pixel blocks of the batch)
     const int tx = bid % P.tiles_x;
     bid /= P.tiles_x;
     const int ty = bid % P.tiles_y;
-    const int b = bid / P.tiles_y;
+    const int b = P.lin ? 0 : bid / P.tiles_y;          // (linear mode: the image is a property of the block, bimg[])
     const int oy0 = ty * TH, ox0 = tx * 32;
     const int S = P.nchunk;                             // steps = 16-channel chunks
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
@@ -91,29 +92,39 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
     float mu[NPW];
     bool valid[NPW];
     unsigned pixo[NPW];
+    int bimg[NPW];                                      // image of the block (wave-uniform)
+    const int bpi = HW >> 5;                            // linear mode: blocks per image
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
-        const int oy = oy0 + wp * NPW + n, ox = ox0 + j;
-        valid[n] = oy < P.Ho && ox < P.Wo;
-        pixo[n] = (unsigned)(min(oy, P.Ho - 1) * P.W + min(ox, P.Wo - 1));
+        if (P.lin) {
+            const int gb = tile * TH + wp * NPW + n, nb = P.B * bpi;
+            valid[n] = gb < nb;
+            const int gc = min(gb, nb - 1);
+            bimg[n] = __builtin_amdgcn_readfirstlane(gc / bpi);
+            pixo[n] = (unsigned)((gc - bimg[n] * bpi) * 32 + j);
+        } else {
+            const int oy = oy0 + wp * NPW + n, ox = ox0 + j;
+            valid[n] = oy < P.Ho && ox < P.Wo;
+            bimg[n] = b;
+            pixo[n] = (unsigned)(min(oy, P.Ho - 1) * P.W + min(ox, P.Wo - 1));
+        }
         xvo[n] = ((unsigned)(8 * half) * (unsigned)HW + pixo[n]) * 4u;
-        mu[n] = P.pre_mean ? P.pre_mean[(size_t)b * HW + pixo[n]] : 0.f;
+        mu[n] = P.pre_mean ? P.pre_mean[(size_t)bimg[n] * HW + pixo[n]] : 0.f;
     }
-    const float *xs0 = P.x0 + (size_t)b * P.x0_bs;
-    const float *xs1 = P.x1 ? P.x1 + (size_t)b * P.x1_bs : nullptr;
     const int c0_chunks = P.C0 >> 4;
     constexpr int L = 8 * NPW;                          // activation pieces per step and wave
     constexpr int XST = NPW * 8 * 64;                   // floats per activation stage of one wave
     float *xw = reinterpret_cast<float *>(smem_u + R * WST) + wave * (PD * XST);    // this wave's private stages
     const unsigned xw_lds = lds0 + (unsigned)(R * WST) * 16u + (unsigned)(wave * (PD * XST)) * 4u;
     auto issue_x = [&](int c, int slot) {               // stage layout [n][i][lane]
-        const char *base = reinterpret_cast<const char *>(uniform_ptr(c < c0_chunks ? xs0 + (size_t)c * 16 * HW : xs1 + (size_t)(c - c0_chunks) * 16 * HW));
         const unsigned dst = xw_lds + (unsigned)(slot * XST) * 4u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const char *row = base + (size_t)i * HW * 4;  // wave-uniform
+        for (int n = 0; n < NPW; ++n) {
+            const float *src = c < c0_chunks ? P.x0 + (size_t)bimg[n] * P.x0_bs + (size_t)c * 16 * HW
+                                             : P.x1 + (size_t)bimg[n] * P.x1_bs + (size_t)(c - c0_chunks) * 16 * HW;
+            const char *base = reinterpret_cast<const char *>(uniform_ptr(src));
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) dma4(xvo[n], row, dst + (unsigned)((n * 8 + i) * 64) * 4u);
+            for (int i = 0; i < 8; ++i) dma4(xvo[n], base + (size_t)i * HW * 4, dst + (unsigned)((n * 8 + i) * 64) * 4u);
         }
     };
 
@@ -235,9 +246,10 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
         const int oy = oy0 + wp * NPW + n, ox = ox0 + j;
+        const int bn = bimg[n];
         const bool ok = valid[n] && ch_ok;
-        const float sc = P.pre_rstd ? P.acc_scale * P.pre_rstd[(size_t)b * HW + pixo[n]] : P.acc_scale;
-        const size_t opix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[0];
+        const float sc = P.pre_rstd ? P.acc_scale * P.pre_rstd[(size_t)bn * HW + pixo[n]] : P.acc_scale;
+        const size_t opix = P.lin ? (size_t)pixo[n] : (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[0];
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -246,7 +258,7 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
                                epl[m * 32 + (r & 3) + 8 * (r >> 2)];
         if (!ok) continue;
         if (P.pre_add) {
-            const float *pp = P.pre_add + (size_t)b * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
+            const float *pp = P.pre_add + (size_t)bn * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -265,21 +277,21 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
                 for (int r = 0; r < 16; ++r) acc[m][n][r] += epl[COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
         }
         if (P.resid) {
-            const float *rp = P.resid + (size_t)b * P.resid_bs + opix + (size_t)(cobase + 4 * half) * P.resid_cs;
+            const float *rp = P.resid + (size_t)bn * P.resid_bs + opix + (size_t)(cobase + 4 * half) * P.resid_cs;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] += rp[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.resid_cs];
         }
         if (P.out) {
-            float *op = P.out + (size_t)b * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
+            float *op = P.out + (size_t)bn * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
         }
         if (P.out_pf) {
-            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[0];
+            const long long u0 = (long long)bn * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[0];
 #pragma unroll
             for (int m = 0; m < MB; ++m)
                 pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps, P.pf_ps, half, acc[m][n]);
