@@ -16,8 +16,8 @@ rows = [
  ('3×3 s1 on `conv_pf_kernel` (pre-split planes)', lambda l: 'conv 3x3 s1' in l and ' PF' in l),
  ('3×3 s1 on `conv_split2_kernel`, ≥ 64² (the 128² decoder concat)', lambda l: 'conv 3x3 s1' in l and ' PF' not in l and res(l) >= 64),
  ('3×3 s1 on `conv_split2_kernel`, < 64² (16², 8²: split-K)', lambda l: 'conv 3x3 s1' in l and ' PF' not in l and res(l) < 64),
- ('1×1, ≥ 64²', lambda l: 'conv 1x1' in l and res(l) >= 64),
- ('1×1, < 64²', lambda l: 'conv 1x1' in l and res(l) < 64),
+ ('1×1 on `conv_pw_kernel` / `conv_pf_kernel`', lambda l: 'conv 1x1' in l and (' PW' in l or ' PF' in l)),
+ ('1×1 on `conv_split2_kernel` (small launches, per-image weights at 16² / 8²)', lambda l: 'conv 1x1' in l and ' PW' not in l and ' PF' not in l),
  ('`kvctx16_kernel` (fused attention front)', lambda l: l.strip().startswith('kvctx')),
  ('ConvTranspose (4 phases of 2×2)', lambda l: 'conv 2x2' in l),
  ('3×3 s2 (Downsample)', lambda l: 'conv 3x3 s2' in l),
