@@ -120,6 +120,28 @@ def test_conv2d_pre_split_operand_kernel(O, case, monkeypatch):
     _conv_check(O, Ops(0), case)
 
 
+PW_CASES = [  # B, Cin, H, W, Cout: every tile shape of conv_pw_kernel's planner, ragged rows, linear (narrow-map) tiles
+    (2, 64, 36, 64, 64), (1, 128, 20, 32, 128), (2, 256, 32, 32, 256), (1, 96, 64, 64, 192), (1, 64, 40, 96, 384),
+    (3, 320, 16, 16, 128), (4, 384, 8, 8, 256), (1, 48, 12, 16, 64)]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_conv2d_pointwise_kernel(O, case, monkeypatch):
+    """conv_pw_kernel (1x1, activations staged per wave straight from the fp32 tensor), forced also for small launches;
+    plain, and with ReLU + per-image shift + residual."""
+    monkeypatch.setenv("CDC_PW_MIN_WAVES", "1")
+    G2 = Ops(0)
+    B, Ci, H, W, Co = case
+    x = synth.normal("px", (B, Ci, H, W), 27)
+    w = synth.normal("pw", (Co, Ci, 1, 1), 27, 1.0 / np.sqrt(Ci))
+    b = synth.normal("pb", (Co,), 27, 0.1)
+    ref = O.conv2d(x, w, b, 1, 0)
+    assert relerr(G2.conv2d(x, w, b, 1, 0), ref) < 2e-5
+    resid = synth.normal("pr", ref.shape, 27)
+    r2 = ref + resid
+    assert relerr(G2.conv2d(x, w, b, 1, 0, resid=resid), r2) < 2e-5
+
+
 @pytest.mark.parametrize("case", [CONV_CASES[4], CONV_CASES[6], CONV_CASES[7], CONV_CASES[10], CONV_CASES[11]] + PF_CASES[:2])
 def test_conv2d_three_plane_bf16_arithmetic(O, case, monkeypatch):
     """CDC_ARITH=0: the exact three-way bf16 split (six MFMA products) stays available as the full-range path."""
