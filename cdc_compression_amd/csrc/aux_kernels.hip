@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const bool pv = n0 + nb + 8 * half + t < n_end;
-                    const float pp = pv ? expf(kk[t] - mrow[i]) : 0.f;
+                    // v_exp_f32 (exp2(x log2 e)), as kvctx16_kernel: <= 2 ulp on a weight in (0, 1]
+                    const float pp = pv ? __builtin_amdgcn_exp2f((kk[t] - mrow[i]) * 1.44269504088896341f) : 0.f;
                     zrow[i] += pp;
                     const _Float16 hq = (_Float16)pp;
                     ph[i][t] = hq;
