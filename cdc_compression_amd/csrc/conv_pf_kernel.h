@@ -62,7 +62,12 @@ __host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int K
     const size_t budget = WM * WP == 8 ? 156 * 1024 : 80 * 1024;
     const size_t patch = (size_t)(KH * KW == 1 ? 3 : 2) * pf_patch_units(NPW, WP, KH, KW) * 16;
     const size_t wst = (size_t)pf_rows(MB, NPW) * WM * MB * 32 * 16;
-    return patch + 5 * wst <= budget ? 5 : (patch + 4 * wst <= budget ? 4 : (patch + 3 * wst <= budget ? 3 : 0));
+#ifndef CDC_PF_RING_MAX
+#define CDC_PF_RING_MAX 5
+#endif
+    for (int r = CDC_PF_RING_MAX; r >= 3; --r)
+        if (patch + r * wst <= budget) return r;
+    return 0;
 }
 #ifndef CDC_PF_ABLATE
 #define CDC_PF_ABLATE 0      // 1: honour PfArgs::dbg (timing experiments with wrong results)
