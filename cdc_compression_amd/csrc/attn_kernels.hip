@@ -327,6 +327,14 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
 #pragma unroll
         for (int r = 0; r < 16; ++r) bias[r] = a.bias[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
     }
+    // The k rows (waves 0 .. CB-1) live in the log2 domain: k log2(e) -- folded into the scale and the bias of the
+    // projection's write-out -- so that exp(k - max) is one subtraction and one v_exp_f32; M is converted back at the end.
+    constexpr float kLog2e = 1.44269504088896341f;
+    const float kdom = wave < CB ? kLog2e : 1.0f;
+    if (wave < CB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] *= kLog2e;
+    }
     const int db = wave / WPD;
     const int eb0 = (wave % WPD) * SPW;
     f32x16 S[SPW];
@@ -384,7 +392,7 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
         }
         // k rows as fp32 [row][pixel]; v rows as fp32 or (VP) as the planes phase 2 multiplies with
         {
-            const float sc = rs_cur * a.wscale_inv;
+            const float sc = rs_cur * a.wscale_inv * kdom;
             if (!VP || wave < CB) {
                 float *kv = kbuf[buf];
 #pragma unroll
@@ -420,7 +428,7 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         if (__any(tmax > m_run)) {                   // a new row maximum somewhere in the block: rescale
             const float mn = fmaxf(m_run, tmax);
-            const float f = fast_exp(m_run - mn);     // exp2(-inf) = 0 on the first tile
+            const float f = __builtin_amdgcn_exp2f(m_run - mn);     // exp2(-inf) = 0 on the first tile
             m_run = mn;
             zsum *= f;
             if (kh == 0) fac[wave][j] = f;
@@ -442,7 +450,7 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float p = fast_exp(kk[8 * st + i] - m_run);
+                const float p = __builtin_amdgcn_exp2f(kk[8 * st + i] - m_run);
                 zsum += p;
                 const _Float16 h = (_Float16)p;
                 ph[st][i] = h;
@@ -487,7 +495,7 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
     zsum += __shfl_xor(zsum, 32);
     if (kh == 0 && eb0 == 0) {
         a.Z[slot * C + db * 32 + j] = zsum;
-        a.M[slot * C + db * 32 + j] = m_run;
+        a.M[slot * C + db * 32 + j] = m_run * (1.0f / kLog2e);     // back to the natural-log domain (ctx_r0_kernel)
     }
 }
 
