@@ -455,8 +455,9 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
                 const _Float16 h = (_Float16)p;
                 ph[st][i] = h;
                 pl[st][i] = (_Float16)(p - (float)h);
-                ph2[st][i] = (_Float16)((float)h * (1.0f / 2048.0f));
             }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) ph2[st] = ph[st] * (_Float16)(1.0f / 2048.0f);     // packed fp16 multiplies (same rounding)
 #pragma unroll
         for (int q = 0; q < SPW; ++q) {
 #pragma unroll
