@@ -80,6 +80,8 @@ def lib():
     L.cdc_version.restype = ctypes.c_char_p
     L.cdc_set_arith.argtypes = [H, _i]
     L.cdc_get_arith.argtypes = [H]
+    L.cdc_get_range_faults.argtypes = [H]
+    L.cdc_get_nonfinite_results.argtypes = [H]
     L.cdc_num_tensors.argtypes = [H]
     L.cdc_tensor_info.argtypes = [H, _i, ctypes.POINTER(ctypes.c_char_p),
                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_i)]
@@ -128,7 +130,18 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
            "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap", "cdc_prof_num_ops", "cdc_prof_op",
-           "cdc_entropy_encode", "cdc_entropy_peek", "cdc_entropy_decode"]
+           "cdc_entropy_encode", "cdc_entropy_peek", "cdc_entropy_decode", "cdc_get_range_faults",
+           "cdc_get_nonfinite_results"]
+
+
+def handle_status(handle):
+    """{'arith', 'range_faults', 'nonfinite_results'} of one library handle (None -> zeros): the fp16-range guard of
+    include/cdc_hip.h repeats a call in the full-range arithmetic and LEAVES the handle there -- these tell."""
+    if handle is None:
+        return {"arith": None, "range_faults": 0, "nonfinite_results": 0}
+    L = lib()
+    return {"arith": int(L.cdc_get_arith(handle)), "range_faults": int(L.cdc_get_range_faults(handle)),
+            "nonfinite_results": int(L.cdc_get_nonfinite_results(handle))}
 
 
 def check(handle, rc):

@@ -54,6 +54,14 @@ class _ContextDecoder:
         self.reversed_hyper_dims = None
         self._full_sd = None          # host copy of every entry load_state_dict() used (replayed by .to())
 
+    def status(self):
+        """Per library handle (context decoder, hyper decoder, encoder): arithmetic mode and range-guard counters."""
+        return {name: _lib.handle_status(getattr(self, attr, None)) for name, attr in (("dec", "_h"), ("hyper_dec", "_hh"), ("enc", "_eh"))}
+
+    @property
+    def range_faults(self):
+        return sum(v["range_faults"] for v in self.status().values())
+
     # ---- handle management ----------------------------------------------------------------
     def _handle(self):
         if self._h is None:

@@ -962,6 +962,23 @@ hipError_t clamp_min_launch(float *x, long long bs, long long n, float lo, int B
     return hipGetLastError();
 }
 
+// sets *flag when any of x[b][0 .. n) (b < B, batch stride bs) is inf or NaN: the fp16-range guard of the entry points
+__global__ void __launch_bounds__(256) nonfinite_kernel(const float *x, long long bs, long long n, int *flag) {
+    const float *p = x + (size_t)blockIdx.y * bs;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned u = __float_as_uint(p[i]);
+        bad |= (u & 0x7f800000u) == 0x7f800000u;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+hipError_t nonfinite_launch(const float *x, long long bs, long long n, int B, int *flag, hipStream_t st) {
+    const int gx = (int)std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(nonfinite_kernel, dim3(gx, B), dim3(256), 0, st, x, bs, n, flag);
+    return hipGetLastError();
+}
+
 // round_w_offset (utils.py:72-75): out = round(x - loc) + loc, torch.round = round-half-to-even = rintf
 __global__ void __launch_bounds__(256) dequantize_kernel(const float *x, const float *loc, float *out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

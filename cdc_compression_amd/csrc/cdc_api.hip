@@ -156,7 +156,9 @@ struct cdc_handle {
     float *d_shift_tab = nullptr;        // [steps][shift_bs]: time-embedding shifts of every step
     // hipGraph replay of one DDIM iteration (launch-bound small batches): the step index lives on the device
     int *d_step = nullptr;
-    int range_faults = 0;                // decodes repeated in bf16x3 arithmetic after an fp16 range overflow
+    int range_faults = 0;                // calls repeated in bf16x3 arithmetic after an fp16 range overflow
+    int nonfinite_results = 0;           // results that are non-finite in the full-range arithmetic too (as the reference's would be)
+    bool in_retry = false;               // the current call is the bf16x3 repetition of a faulted one
     int *d_fault = nullptr;              // sticky "non-finite U-Net output" flag written by the sampler kernel
     hipGraphExec_t graph_exec = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;   // order the caller's stream around the graph stream
@@ -652,7 +654,7 @@ struct Builder {
         else if (op.kind == Op::CONVPF)
             snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s", op.pf.KH, op.pf.KW,
                      op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
-                     op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pf.ep_g ? "PF LN" : "PF"), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
+                     op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
                      op.pf.resid ? " +res" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
@@ -840,6 +842,10 @@ struct Builder {
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
+        pf3_make_plan(a, B, w.nz, &op.pfplan);          // large 3x3 layers: the persistent ping-ponged kernel
+        if (getenv("CDC_DEBUG_PLAN"))
+            fprintf(stderr, "[plan] conv %dx%d %d->%d out %dx%d on conv_pf%s_kernel (epv %d, %d workgroups x %d tiles per group)\n", w.KH, w.KW, w.Cin, w.Cout,
+                    s.Ho, s.Wo, op.pfplan.pf3_epv ? "3" : "", op.pfplan.pf3_epv, op.pfplan.pf3_G, op.pfplan.pf3_iters);
         const double px = (double)B * s.Ho * s.Wo * w.nz;
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
@@ -1741,6 +1747,58 @@ int check_ready(cdc_handle *h) {
 // =================================================================================================
 // C-ABI
 // =================================================================================================
+namespace {
+// no C++ exception crosses the C boundary (std::bad_alloc from a vector sized by a hostile header, ...)
+template <class F> int no_throw(cdc_handle *h, F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return h ? fail(h, CDC_ERR_NOMEM, "out of host memory") : CDC_ERR_NOMEM; }
+    catch (const std::exception &e) { return h ? fail(h, CDC_ERR_INVALID, "internal error: %s", e.what()) : CDC_ERR_INVALID; }
+    catch (...) { return h ? fail(h, CDC_ERR_INVALID, "internal error") : CDC_ERR_INVALID; }
+}
+}  // namespace
+
+// ---- range guard of the two-plane fp16 arithmetic ------------------------------------------------------------------
+// |activation| >= 65504 becomes inf / NaN in CDC_ARITH_F16X2 and propagates to the results of the call.  Every entry point
+// that runs the arithmetic checks its results (one small kernel + one 4-byte read-back, i.e. a stream synchronisation);
+// a call whose results are not finite is repeated ONCE in the full-range three-plane bf16 arithmetic, and the handle stays
+// in that mode (cdc_get_arith / cdc_get_range_faults tell).  Results that are non-finite there too -- a non-finite input,
+// parameters that overflow fp32 -- are returned as they are, as the reference would (cdc_get_nonfinite_results counts them).
+namespace {
+bool guard_enabled(const cdc_handle *h) {
+    static const bool no_guard = getenv("CDC_NO_RANGE_GUARD") != nullptr;
+    return !no_guard && (h->arith == CDC_ARITH_F16X2 || h->in_retry);
+}
+int ensure_fault_flag(cdc_handle *h) {
+    if (!h->d_fault) { void *p = nullptr; HIP_TRY(h, hipMalloc(&p, sizeof(int))); h->d_fault = (int *)p; h->weight_allocs.push_back(p); }
+    return CDC_OK;
+}
+struct GuardBuf { const float *p; long long bs, n; };
+// OR of "not finite" over device tensors (and of whatever a kernel already left in d_fault) -> *fault
+int guard_check(cdc_handle *h, std::initializer_list<GuardBuf> bufs, int B, hipStream_t st, int *fault) {
+    for (const GuardBuf &g : bufs)
+        if (g.p && g.n > 0) HIP_TRY(h, cdc::nonfinite_launch(g.p, g.bs, g.n, B, h->d_fault, st));
+    *fault = 0;
+    HIP_TRY(h, hipMemcpyAsync(fault, h->d_fault, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return CDC_OK;
+}
+// a fault in F16X2: switch to the full-range arithmetic (returns true: repeat the call); a fault in the repetition: count it
+bool guard_escalate(cdc_handle *h, int *rc) {
+    *rc = CDC_OK;
+    if (h->in_retry || h->arith != CDC_ARITH_F16X2) { ++h->nonfinite_results; return false; }
+    ++h->range_faults;
+    static bool warned = false;
+    if (!warned) {
+        warned = true;
+        fprintf(stderr, "cdc_hip: a value left the fp16 range of CDC_ARITH_F16X2; the call is repeated in CDC_ARITH_BF16X3 and the handle stays "
+                        "in that (slower, full-range) arithmetic -- see cdc_get_range_faults()\n");
+    }
+    *rc = cdc_set_arith(h, CDC_ARITH_BF16X3);
+    return *rc == CDC_OK;
+}
+struct RetryScope { cdc_handle *h; explicit RetryScope(cdc_handle *h_) : h(h_) { h->in_retry = true; } ~RetryScope() { h->in_retry = false; } };
+}  // namespace
+
 extern "C" {
 
 const char *cdc_version(void) { return "cdc_hip 0.9 (gfx950; fp32-class convolutions from split fp16 / bf16 operands on the matrix cores)"; }
@@ -1803,6 +1861,8 @@ int cdc_set_arith(cdc_handle *h, int mode) {
 }
 
 int cdc_get_arith(const cdc_handle *h) { return h ? h->arith : CDC_ERR_INVALID; }
+int cdc_get_range_faults(const cdc_handle *h) { return h ? h->range_faults : CDC_ERR_INVALID; }
+int cdc_get_nonfinite_results(const cdc_handle *h) { return h ? h->nonfinite_results : CDC_ERR_INVALID; }
 
 int cdc_num_tensors(const cdc_handle *h) {
     if (!h) return CDC_ERR_INVALID;
@@ -2051,10 +2111,20 @@ int cdc_encoder_encode(cdc_handle *h, const float *images, float *latent, float 
     if ((rc = build_encoder_program(h, B, H, W))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
     if ((rc = copy_in(h, h->in_x, images, (size_t)B * h->enc_dims[0] * H * W, mem, st))) return rc;
+    const bool guard = guard_enabled(h);
+    if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
     h->prof_now = true;
     for (const Op &op : h->ops)
         if ((rc = run_op(h, op, h->pB, st))) return rc;
     const Act &l = h->dec_outs[0], &hl = h->dec_outs[1];
+    if (guard) {
+        int fault = 0;
+        if ((rc = guard_check(h, {{l.p, l.bs(), (long long)l.C * l.H * l.W}, {hl.p, hl.bs(), (long long)hl.C * hl.H * hl.W}}, B, st, &fault))) return rc;
+        if (fault) {
+            if (guard_escalate(h, &rc)) { RetryScope r(h); return cdc_encoder_encode(h, images, latent, hyper_latent, B, H, W, mem, stream); }
+            if (rc) return rc;
+        }
+    }
     if ((rc = copy_out(h, latent, l.p, (size_t)B * l.C * l.H * l.W, mem, st))) return rc;
     return copy_out(h, hyper_latent, hl.p, (size_t)B * hl.C * hl.H * hl.W, mem, st);
 }
@@ -2142,12 +2212,22 @@ int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean,
     if ((rc = build_hyperdec_program(h, B, hh, wh))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
     if ((rc = copy_in(h, h->in_x, q_hyper_latent, (size_t)B * h->hyper_dims[0] * hh * wh, mem, st))) return rc;
+    const bool guard = guard_enabled(h);
+    if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
     h->prof_now = true;
     for (const Op &op : h->ops)
         if ((rc = run_op(h, op, h->pB, st))) return rc;
     const Act &o = h->dec_outs[0];                  // [B][2C][4hh][4wh]: mean = channels [0, C), scale = [C, 2C)
     const int C = o.C / 2;
     const long long half = (long long)C * o.H * o.W;
+    if (guard) {
+        int fault = 0;
+        if ((rc = guard_check(h, {{o.p, o.bs(), 2 * half}}, B, st, &fault))) return rc;
+        if (fault) {
+            if (guard_escalate(h, &rc)) { RetryScope r(h); return cdc_hyperdec_decode(h, q_hyper_latent, mean, scale, B, hh, wh, scale_min, mem, stream); }
+            if (rc) return rc;
+        }
+    }
     HIP_TRY(h, clamp_min_launch(o.p + half, o.bs(), half, scale_min, B, st));
     for (int b = 0; b < B; ++b) {
         if ((rc = copy_out(h, mean + (size_t)b * half, o.p + (size_t)b * o.bs(), (size_t)half, mem, st))) return rc;
@@ -2158,7 +2238,8 @@ int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean,
 
 // ---- entropy coder (entropy.hip) ---------------------------------------------------------
 namespace {
-constexpr int kStreamHeader = 18;     // 'C' 'D' 'C' 1 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32
+constexpr int kStreamVersion = 2;
+constexpr int kStreamHeader = 26;     // 'C' 'D' 'C' 2 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 | model hash u32 | symbol hash u32
 
 int ensure_entropy(cdc_handle *h, const float *medians) {
     if (h->kind != 2) return fail(h, CDC_ERR_STATE, "handle is not a hyper decoder");
@@ -2176,42 +2257,63 @@ int ensure_entropy(cdc_handle *h, const float *medians) {
 }
 
 // hyper_dec on ONE image (the batch-1 launch program, see the contract in entropy.hip): q_hyper (host) -> device mean / scale
+// (escalate: the encoder may leave CDC_ARITH_F16X2 when hyper_dec overflows its range -- the stream header records the
+// arithmetic that was finally used; the decoder runs what the header says)
 int hyperdec_one(cdc_handle *h, const float *qh_host, int hh, int wh, hipStream_t st, const float **mean, const float **scale,
-                 long long *nl) {
+                 long long *nl, bool escalate = false) {
     int rc = build_hyperdec_program(h, 1, hh, wh);
     if (rc) return rc;
     const size_t nh = (size_t)h->hyper_dims[0] * hh * wh;
     HIP_TRY(h, hipMemcpyAsync(h->in_x, qh_host, nh * sizeof(float), hipMemcpyHostToDevice, st));
+    const bool guard = escalate && guard_enabled(h) && !h->in_retry;
+    if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
     h->prof_now = false;
     for (const Op &op : h->ops)
         if ((rc = run_op(h, op, 1, st))) return rc;
     const Act &o = h->dec_outs[0];
     const long long half = (long long)(o.C / 2) * o.H * o.W;
+    if (guard) {
+        int fault = 0;
+        if ((rc = guard_check(h, {{o.p, o.bs(), 2 * half}}, 1, st, &fault))) return rc;
+        if (fault && guard_escalate(h, &rc)) { RetryScope r(h); return hyperdec_one(h, qh_host, hh, wh, st, mean, scale, nl, false); }
+        if (rc) return rc;
+    }
     HIP_TRY(h, clamp_min_launch(o.p + half, o.bs(), half, 0.1f, 1, st));       // scale.clamp(min=0.1), compress_modules.py:59
     *mean = o.p; *scale = o.p + half; *nl = half;
     return CDC_OK;
 }
 }  // namespace
 
-int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
-                       int hh, int wh, unsigned char *out, size_t cap, size_t *offsets, int mem, void *stream) {
+namespace {
+// device scratch of one entropy call, released on every exit path
+struct EntScratch {
+    void *sym = nullptr, *bin = nullptr, *buf = nullptr, *bad = nullptr;
+    ~EntScratch() { for (void *p : {sym, bin, buf, bad}) if (p) (void)hipFree(p); }
+};
+inline void put_u32(unsigned char *o, uint32_t v) { for (int i = 0; i < 4; ++i) o[i] = (unsigned char)(v >> (8 * i)); }
+inline uint32_t get_u32(const unsigned char *s) { uint32_t v = 0; for (int i = 0; i < 4; ++i) v |= (uint32_t)s[i] << (8 * i); return v; }
+constexpr int kMaxHyperPositions = 1 << 22;       // hh * wh of a 131072 x 131072 image; bounds every allocation of the decoder
+
+int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
+                        int hh, int wh, unsigned char *out, size_t cap, size_t *offsets, int mem, void *stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!latent || !hyper_latent || !medians || !out || !offsets || B < 1 || hh < 1 || wh < 1 || hh > 65535 || wh > 65535)
+    if (!latent || !hyper_latent || !medians || !out || !offsets || B < 1 || hh < 1 || wh < 1 || hh > 65535 || wh > 65535 ||
+        (long long)hh * wh > kMaxHyperPositions)
         return fail(h, CDC_ERR_INVALID, "null/invalid argument");
     if ((rc = ensure_entropy(h, medians))) return rc;
     hipStream_t st = h->own_stream;                       // synchronous entry point: the coder runs on the host
     if (mem == CDC_MEM_DEVICE) HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     const int Ch = h->hyper_dims[0];
     const size_t nh = (size_t)Ch * hh * wh;
+    const uint32_t model = cdc::entropy_model_hash(h->ent.get());
     std::vector<float> hl(nh), qh(nh);
     std::vector<int32_t> sh(nh), sl;
     std::vector<uint8_t> bins, bytes_h, bytes_l;
     std::vector<const cdc::EntropyTable *> tabs;
-    void *d_sym = nullptr, *d_bin = nullptr, *d_lat = nullptr;
+    EntScratch d;
     size_t pos = 0;
     offsets[0] = 0;
-    auto cleanup = [&]() { if (d_sym) (void)hipFree(d_sym); if (d_bin) (void)hipFree(d_bin); if (d_lat) (void)hipFree(d_lat); };
     for (int b = 0; b < B; ++b) {
         if (mem == CDC_MEM_DEVICE) { HIP_TRY(h, hipMemcpy(hl.data(), hyper_latent + (size_t)b * nh, nh * sizeof(float), hipMemcpyDeviceToHost)); }
         else memcpy(hl.data(), hyper_latent + (size_t)b * nh, nh * sizeof(float));
@@ -2219,27 +2321,33 @@ int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_la
             for (int i = 0; i < hh * wh; ++i) {
                 const size_t k = (size_t)c * hh * wh + i;
                 const float r = rintf(hl[k] - medians[c]);          // quantize(x, "dequantize", medians) (utils.py:72-85)
+                if (!(fabsf(r) < 2.0e9f)) return fail(h, CDC_ERR_INVALID, "image %d: non-finite / out-of-range hyper-latent", b);
                 sh[k] = (int32_t)r;
                 qh[k] = r + medians[c];
             }
         const float *dmean, *dscale;
         long long nl;
-        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl))) { cleanup(); return rc; }
-        if (!d_sym) {
-            HIP_TRY(h, hipMalloc(&d_sym, nl * sizeof(int32_t)));
-            HIP_TRY(h, hipMalloc(&d_bin, nl));
-            if (mem == CDC_MEM_HOST) HIP_TRY(h, hipMalloc(&d_lat, nl * sizeof(float)));
+        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl, true))) return rc;
+        if (!d.sym) {
+            HIP_TRY(h, hipMalloc(&d.sym, nl * sizeof(int32_t)));
+            HIP_TRY(h, hipMalloc(&d.bin, nl));
+            HIP_TRY(h, hipMalloc(&d.bad, sizeof(int)));
+            if (mem == CDC_MEM_HOST) HIP_TRY(h, hipMalloc(&d.buf, nl * sizeof(float)));
         }
         const float *dl = latent + (size_t)b * nl;
         if (mem == CDC_MEM_HOST) {
-            HIP_TRY(h, hipMemcpyAsync(d_lat, dl, nl * sizeof(float), hipMemcpyHostToDevice, st));
-            dl = (const float *)d_lat;
+            HIP_TRY(h, hipMemcpyAsync(d.buf, dl, nl * sizeof(float), hipMemcpyHostToDevice, st));
+            dl = (const float *)d.buf;
         }
-        HIP_TRY(h, cdc::latent_symbols_launch(dl, dmean, dscale, h->ent->d_edges, nl, (int32_t *)d_sym, (uint8_t *)d_bin, st));
+        HIP_TRY(h, hipMemsetAsync(d.bad, 0, sizeof(int), st));
+        HIP_TRY(h, cdc::latent_symbols_launch(dl, dmean, dscale, h->ent->d_edges, nl, (int32_t *)d.sym, (uint8_t *)d.bin, (int *)d.bad, st));
         sl.resize(nl); bins.resize(nl);
-        HIP_TRY(h, hipMemcpyAsync(sl.data(), d_sym, nl * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipMemcpyAsync(bins.data(), d_bin, nl, hipMemcpyDeviceToHost, st));
+        int bad = 0;
+        HIP_TRY(h, hipMemcpyAsync(sl.data(), d.sym, nl * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(bins.data(), d.bin, nl, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(&bad, d.bad, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipStreamSynchronize(st));
+        if (bad) return fail(h, CDC_ERR_INVALID, "image %d: non-finite latent, mean or scale (nothing to code)", b);
         tabs.resize(nh);
         for (int c = 0; c < Ch; ++c)
             for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
@@ -2248,23 +2356,98 @@ int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_la
         for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
         cdc::entropy_encode_symbols(sl.data(), (size_t)nl, tabs, &bytes_l);
         const size_t need = kStreamHeader + bytes_h.size() + bytes_l.size();
-        if (pos + need > cap) { cleanup(); return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: image %d needs %zu bytes at offset %zu of %zu", b, need, pos, cap); }
+        if (pos + need > cap) return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: image %d needs %zu bytes at offset %zu of %zu", b, need, pos, cap);
         unsigned char *o = out + pos;
-        o[0] = 'C'; o[1] = 'D'; o[2] = 'C'; o[3] = 1; o[4] = (unsigned char)h->arith; o[5] = 0;
+        o[0] = 'C'; o[1] = 'D'; o[2] = 'C'; o[3] = kStreamVersion; o[4] = (unsigned char)h->arith; o[5] = 0;
         o[6] = (unsigned char)(hh & 255); o[7] = (unsigned char)(hh >> 8); o[8] = (unsigned char)(wh & 255); o[9] = (unsigned char)(wh >> 8);
-        const uint32_t a = (uint32_t)bytes_h.size(), bl = (uint32_t)bytes_l.size();
-        for (int i = 0; i < 4; ++i) { o[10 + i] = (unsigned char)(a >> (8 * i)); o[14 + i] = (unsigned char)(bl >> (8 * i)); }
+        put_u32(o + 10, (uint32_t)bytes_h.size());
+        put_u32(o + 14, (uint32_t)bytes_l.size());
+        put_u32(o + 18, model);
+        put_u32(o + 22, cdc::entropy_symbol_hash(sh.data(), nh, sl.data(), (size_t)nl));
         memcpy(o + kStreamHeader, bytes_h.data(), bytes_h.size());
         memcpy(o + kStreamHeader + bytes_h.size(), bytes_l.data(), bytes_l.size());
         pos += need;
         offsets[b + 1] = pos;
     }
-    cleanup();
     return CDC_OK;
 }
 
+int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *offsets, const float *medians, int B,
+                        float *q_latent, float *q_hyper_latent, int mem, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!in || !offsets || !medians || !q_latent || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
+    if ((rc = ensure_entropy(h, medians))) return rc;
+    hipStream_t st = h->own_stream;
+    // the outputs may be device buffers that queued work of the caller's stream still uses
+    if (mem == CDC_MEM_DEVICE) HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    const int Ch = h->hyper_dims[0];
+    const int arith_in = h->arith;
+    // the decoder runs hyper_dec in the encoder's arithmetic (see the contract in entropy.hip); the handle's own mode comes back
+    struct Restore { cdc_handle *h; int a; ~Restore() { if (h->arith != a) (void)cdc_set_arith(h, a); } } restore{h, arith_in};
+    std::vector<int32_t> sh, sl;
+    std::vector<float> qh;
+    std::vector<uint8_t> bins;
+    std::vector<const cdc::EntropyTable *> tabs;
+    EntScratch d;
+    for (int b = 0; b < B; ++b) {
+        if (offsets[b + 1] < offsets[b]) return fail(h, CDC_ERR_INVALID, "image %d: offsets decrease", b);
+        const unsigned char *s = in + offsets[b];
+        const size_t n = offsets[b + 1] - offsets[b];
+        int hh, wh, ar;
+        if (cdc_entropy_peek(s, n, &hh, &wh, &ar)) return fail(h, CDC_ERR_INVALID, "image %d: not a CDC bitstream (version %d container)", b, kStreamVersion);
+        if (hh < 1 || wh < 1 || (long long)hh * wh > kMaxHyperPositions) return fail(h, CDC_ERR_INVALID, "image %d: implausible hyper-latent size %d x %d", b, hh, wh);
+        if (ar != CDC_ARITH_BF16X3 && ar != CDC_ARITH_F16X2) return fail(h, CDC_ERR_INVALID, "image %d: unknown arithmetic %d", b, ar);
+        const uint32_t nbh = get_u32(s + 10), nbl = get_u32(s + 14);
+        if ((size_t)kStreamHeader + nbh + nbl != n) return fail(h, CDC_ERR_INVALID, "image %d: truncated bitstream", b);
+        if (get_u32(s + 18) != cdc::entropy_model_hash(h->ent.get()))
+            return fail(h, CDC_ERR_INVALID, "image %d: the stream was coded with other probability tables (prior parameters, medians, library build or libm differ)", b);
+        if (ar != h->arith && (rc = cdc_set_arith(h, ar))) return rc;
+        const size_t nh = (size_t)Ch * hh * wh;
+        sh.resize(nh); qh.resize(nh); tabs.resize(nh);
+        for (int c = 0; c < Ch; ++c)
+            for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
+        if (!cdc::entropy_decode_symbols(s + kStreamHeader, nbh, nh, tabs, sh.data())) return fail(h, CDC_ERR_INVALID, "image %d: corrupt hyper stream", b);
+        for (int c = 0; c < Ch; ++c)
+            for (int i = 0; i < hh * wh; ++i) { const size_t k = (size_t)c * hh * wh + i; qh[k] = (float)sh[k] + medians[c]; }
+        const float *dmean, *dscale;
+        long long nl;
+        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl))) return rc;
+        if (!d.sym) {
+            HIP_TRY(h, hipMalloc(&d.sym, nl * sizeof(int32_t)));
+            HIP_TRY(h, hipMalloc(&d.bin, nl));
+            HIP_TRY(h, hipMalloc(&d.buf, nl * sizeof(float)));
+        }
+        HIP_TRY(h, cdc::latent_symbols_launch(nullptr, dmean, dscale, h->ent->d_edges, nl, nullptr, (uint8_t *)d.bin, nullptr, st));
+        bins.resize(nl); sl.resize(nl); tabs.resize(nl);
+        HIP_TRY(h, hipMemcpyAsync(bins.data(), d.bin, nl, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
+        if (!cdc::entropy_decode_symbols(s + kStreamHeader + nbh, nbl, (size_t)nl, tabs, sl.data())) return fail(h, CDC_ERR_INVALID, "image %d: corrupt latent stream", b);
+        if (get_u32(s + 22) != cdc::entropy_symbol_hash(sh.data(), nh, sl.data(), (size_t)nl))
+            return fail(h, CDC_ERR_INVALID, "image %d: symbol checksum mismatch -- this decoder's hyper-decoder output differs from the encoder's "
+                                           "(other library build, launch-plan switches or GPU), or the payload is corrupt", b);
+        HIP_TRY(h, hipMemcpyAsync(d.sym, sl.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, cdc::symbols_to_latent_launch((const int32_t *)d.sym, dmean, nl, (float *)d.buf, st));
+        HIP_TRY(h, hipMemcpyAsync(q_latent + (size_t)b * nl, d.buf, nl * sizeof(float),
+                                  mem == CDC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        if (q_hyper_latent)
+            HIP_TRY(h, hipMemcpyAsync(q_hyper_latent + (size_t)b * nh, qh.data(), nh * sizeof(float),
+                                      mem == CDC_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    return CDC_OK;
+}
+
+}  // namespace
+
+int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
+                       int hh, int wh, unsigned char *out, size_t cap, size_t *offsets, int mem, void *stream) {
+    return no_throw(h, [&] { return entropy_encode_impl(h, latent, hyper_latent, medians, B, hh, wh, out, cap, offsets, mem, stream); });
+}
+
 int cdc_entropy_peek(const unsigned char *in, size_t n, int *hh, int *wh, int *arith) {
-    if (!in || n < (size_t)kStreamHeader || in[0] != 'C' || in[1] != 'D' || in[2] != 'C' || in[3] != 1) return CDC_ERR_INVALID;
+    if (!in || n < (size_t)kStreamHeader || in[0] != 'C' || in[1] != 'D' || in[2] != 'C' || in[3] != kStreamVersion) return CDC_ERR_INVALID;
     if (arith) *arith = in[4];
     if (hh) *hh = in[6] | (in[7] << 8);
     if (wh) *wh = in[8] | (in[9] << 8);
@@ -2273,63 +2456,7 @@ int cdc_entropy_peek(const unsigned char *in, size_t n, int *hh, int *wh, int *a
 
 int cdc_entropy_decode(cdc_handle *h, const unsigned char *in, const size_t *offsets, const float *medians, int B,
                        float *q_latent, float *q_hyper_latent, int mem, void *stream) {
-    int rc = check_ready(h);
-    if (rc) return rc;
-    if (!in || !offsets || !medians || !q_latent || B < 1) return fail(h, CDC_ERR_INVALID, "null/invalid argument");
-    if ((rc = ensure_entropy(h, medians))) return rc;
-    hipStream_t st = h->own_stream;
-    const int Ch = h->hyper_dims[0];
-    std::vector<int32_t> sh, sl;
-    std::vector<float> qh;
-    std::vector<uint8_t> bins;
-    std::vector<const cdc::EntropyTable *> tabs;
-    void *d_sym = nullptr, *d_bin = nullptr, *d_q = nullptr;
-    auto cleanup = [&]() { if (d_sym) (void)hipFree(d_sym); if (d_bin) (void)hipFree(d_bin); if (d_q) (void)hipFree(d_q); };
-    for (int b = 0; b < B; ++b) {
-        const unsigned char *s = in + offsets[b];
-        const size_t n = offsets[b + 1] - offsets[b];
-        int hh, wh, ar;
-        if (cdc_entropy_peek(s, n, &hh, &wh, &ar)) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: not a CDC bitstream", b); }
-        if (ar != h->arith) {
-            // the decoder must run hyper_dec in the encoder's arithmetic (see the contract in entropy.hip)
-            if ((rc = cdc_set_arith(h, ar))) { cleanup(); return rc; }
-        }
-        uint32_t nbh = 0, nbl = 0;
-        for (int i = 0; i < 4; ++i) { nbh |= (uint32_t)s[10 + i] << (8 * i); nbl |= (uint32_t)s[14 + i] << (8 * i); }
-        if ((size_t)kStreamHeader + nbh + nbl != n) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: truncated bitstream", b); }
-        const size_t nh = (size_t)Ch * hh * wh;
-        sh.resize(nh); qh.resize(nh); tabs.resize(nh);
-        for (int c = 0; c < Ch; ++c)
-            for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
-        if (!cdc::entropy_decode_symbols(s + kStreamHeader, nbh, nh, tabs, sh.data())) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: corrupt hyper stream", b); }
-        for (int c = 0; c < Ch; ++c)
-            for (int i = 0; i < hh * wh; ++i) { const size_t k = (size_t)c * hh * wh + i; qh[k] = (float)sh[k] + medians[c]; }
-        const float *dmean, *dscale;
-        long long nl;
-        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl))) { cleanup(); return rc; }
-        if (!d_sym) {
-            HIP_TRY(h, hipMalloc(&d_sym, nl * sizeof(int32_t)));
-            HIP_TRY(h, hipMalloc(&d_bin, nl));
-            HIP_TRY(h, hipMalloc(&d_q, nl * sizeof(float)));
-        }
-        HIP_TRY(h, cdc::latent_symbols_launch(nullptr, dmean, dscale, h->ent->d_edges, nl, nullptr, (uint8_t *)d_bin, st));
-        bins.resize(nl); sl.resize(nl); tabs.resize(nl);
-        HIP_TRY(h, hipMemcpyAsync(bins.data(), d_bin, nl, hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
-        for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
-        if (!cdc::entropy_decode_symbols(s + kStreamHeader + nbh, nbl, (size_t)nl, tabs, sl.data())) { cleanup(); return fail(h, CDC_ERR_INVALID, "image %d: corrupt latent stream", b); }
-        HIP_TRY(h, hipMemcpyAsync(d_sym, sl.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(h, cdc::symbols_to_latent_launch((const int32_t *)d_sym, dmean, nl, (float *)d_q, st));
-        HIP_TRY(h, hipMemcpyAsync(q_latent + (size_t)b * nl, d_q, nl * sizeof(float),
-                                  mem == CDC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-        if (q_hyper_latent)
-            HIP_TRY(h, hipMemcpyAsync(q_hyper_latent + (size_t)b * nh, qh.data(), nh * sizeof(float),
-                                      mem == CDC_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
-    }
-    cleanup();
-    (void)stream;
-    return CDC_OK;
+    return no_throw(h, [&] { return entropy_decode_impl(h, in, offsets, medians, B, q_latent, q_hyper_latent, mem, stream); });
 }
 
 int cdc_dequantize(cdc_handle *h, const float *x, const float *offset, float *out, long long n, int mem, void *stream) {
@@ -2398,9 +2525,23 @@ int cdc_ctxdec_decode(cdc_handle *h, const float *q_latent, float *const *outs, 
     if ((rc = build_ctxdec_program(h, B, hl, wl))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
     if ((rc = copy_in(h, h->in_x, q_latent, (size_t)B * h->rev_dims[0] * hl * wl, mem, st))) return rc;
+    const bool guard = guard_enabled(h);
+    if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
     h->prof_now = true;
     for (const Op &op : h->ops)
         if ((rc = run_op(h, op, h->pB, st))) return rc;
+    if (guard) {
+        for (int i = 0; i < n; ++i) {
+            const Act &a = h->dec_outs[i];
+            HIP_TRY(h, cdc::nonfinite_launch(a.p, a.bs(), (long long)a.C * a.H * a.W, B, h->d_fault, st));
+        }
+        int fault = 0;
+        if ((rc = guard_check(h, {}, B, st, &fault))) return rc;
+        if (fault) {
+            if (guard_escalate(h, &rc)) { RetryScope r(h); return cdc_ctxdec_decode(h, q_latent, outs, n_outs, B, hl, wl, mem, stream); }
+            if (rc) return rc;
+        }
+    }
     for (int i = 0; i < n; ++i) {       // outs[0] = finest = the last level's output (output[::-1])
         const Act &a = h->dec_outs[n - 1 - i];
         if ((rc = copy_out(h, outs[i], a.p, (size_t)B * a.C * a.H * a.W, mem, st))) return rc;
@@ -2419,9 +2560,19 @@ int cdc_unet_forward(cdc_handle *h, const float *x, const float *time, const flo
     if ((rc = copy_in(h, h->in_x, x, (size_t)B * h->cfg.channels * H * W, mem, st))) return rc;
     if ((rc = copy_in(h, h->in_time, time, B, mem, st))) return rc;
     if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
+    const bool guard = guard_enabled(h);
+    if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
     h->prof_now = true;
     if ((rc = run_pre(h, st))) return rc;
     if ((rc = run_unet(h, st, -1))) return rc;
+    if (guard) {
+        int fault = 0;
+        if ((rc = guard_check(h, {{h->out_fx, 0, (long long)B * h->out_dim * H * W}}, 1, st, &fault))) return rc;
+        if (fault) {
+            if (guard_escalate(h, &rc)) { RetryScope r(h); return cdc_unet_forward(h, x, time, ctx, n_ctx, out, B, H, W, mem, stream); }
+            if (rc) return rc;
+        }
+    }
     return copy_out(h, out, h->out_fx, (size_t)B * h->out_dim * H * W, mem, st);
 }
 
@@ -2541,8 +2692,22 @@ int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *c
         if ((rc = run_pre(h, st))) return rc;
     }
     if (eta != 0.f && (rc = copy_in(h, h->noise_buf, noise, n, mem, st))) return rc;
+    if ((rc = ensure_fault_flag(h))) return rc;              // (the sampler kernel writes the flag)
+    const bool guard = guard_enabled(h);
+    HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st));
     if ((rc = ddim_on_device(h, h->in_x, i, h->noise_buf, eta, h->xa, B, H, W, pred_mode, clip, st)))
         return rc;
+    if (guard) {
+        int fault = 0;
+        if ((rc = guard_check(h, {{h->xa, 0, (long long)n}}, 1, st, &fault))) return rc;
+        if (fault) {
+            const bool esc = guard_escalate(h, &rc);
+            if (esc && !ctx)            // the staged context went with the old launch program: the caller has to hand it over again
+                return fail(h, CDC_ERR_STATE, "fp16 range overflow in step %d; the handle is now in CDC_ARITH_BF16X3 -- repeat the step WITH the context", i);
+            if (esc) { RetryScope r(h); return cdc_ddim_step(h, x_in, i, ctx, n_ctx, noise, eta, x_out, B, H, W, pred_mode, clip, mem, stream); }
+            if (rc) return rc;
+        }
+    }
     return copy_out(h, x_out, h->xa, n, mem, st);
 }
 
@@ -2561,7 +2726,7 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     if ((rc = ensure_time_rows(h, B))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
     const size_t n = (size_t)B * h->cfg.channels * H * W;
-    if (!h->d_fault) { void *p = nullptr; HIP_TRY(h, hipMalloc(&p, sizeof(int))); h->d_fault = (int *)p; h->weight_allocs.push_back(p); }
+    if ((rc = ensure_fault_flag(h))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st));
     if (init) { if ((rc = copy_in(h, h->in_x, init, n, mem, st))) return rc; }
     else HIP_TRY(h, hipMemsetAsync(h->in_x, 0, n * sizeof(float), st));
@@ -2621,18 +2786,14 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
             return rc;
     }
     h->prof_now = true;
-    // Range guard of the two-plane fp16 arithmetic: |activation| >= 65504 turns into inf / NaN, reaches the U-Net
-    // output and is flagged by the sampler kernel.  Such a decode is repeated once with the full-range three-plane
-    // bf16 arithmetic (the handle stays in that mode).  One 4-byte read-back per decode.
-    static const bool no_guard = getenv("CDC_NO_RANGE_GUARD") != nullptr;
-    if (h->arith == CDC_ARITH_F16X2 && !no_guard) {
+    // Range guard (see guard_enabled above): a non-finite U-Net output is flagged by the sampler kernel of the iteration it
+    // occurs in; the final image is checked as well.  One 4-byte read-back per decode.
+    if (guard_enabled(h)) {
         int fault = 0;
-        HIP_TRY(h, hipMemcpyAsync(&fault, h->d_fault, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
+        if ((rc = guard_check(h, {{h->in_x, 0, (long long)n}}, 1, st, &fault))) return rc;
         if (fault) {
-            if ((rc = cdc_set_arith(h, CDC_ARITH_BF16X3))) return rc;
-            ++h->range_faults;
-            return cdc_decode(h, init, ctx, n_ctx, out, B, H, W, pred_mode, clip, mem, stream);
+            if (guard_escalate(h, &rc)) { RetryScope r(h); return cdc_decode(h, init, ctx, n_ctx, out, B, H, W, pred_mode, clip, mem, stream); }
+            if (rc) return rc;
         }
     }
     return copy_out(h, out, h->in_x, n, mem, st);

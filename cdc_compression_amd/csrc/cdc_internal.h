@@ -45,9 +45,15 @@ struct PfShape {
     int Cin, Cout, C0 = 0, KH, KW, nz = 1, Ho, Wo, B;
     bool need_all_cout = false;
 };
-struct PfPlan { int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; int lin = 0; };
+struct PfPlan {
+    int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; int lin = 0;
+    int pf3_epv = 0, pf3_G = 0, pf3_iters = 0;      // != 0: conv_pf3_kernel (conv_pf3_kernel.h) runs the layer
+};
 bool pf_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pf_launch(PfArgs a, const PfPlan &plan, int B, int nz, hipStream_t st);
+// persistent ping-ponged kernel for the large 3x3 layers (conv_pf3_kernel.h, conv_inst_q.hip): decided on the complete argument block
+bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *plan);
+hipError_t pf3_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
 // pointwise (1x1) convolution with per-wave activation staging from the fp32 tensor (conv_pw_kernel.h, conv_inst_w.hip)
 bool pw_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
@@ -160,6 +166,7 @@ hipError_t step_dec_launch(int *step, hipStream_t st);
 hipError_t bpp_launch(const float *qh, long long nh, int hw_h, const float *prior, const float *ql, const float *mean,
                       const float *scale, long long nl, float inv_hw, float *bpp, int B, hipStream_t st);
 hipError_t clamp_min_launch(float *x, long long bs, long long n, float lo, int B, hipStream_t st);
+hipError_t nonfinite_launch(const float *x, long long bs, long long n, int B, int *flag, hipStream_t st);
 hipError_t dequantize_launch(const float *x, const float *loc, float *out, long long n, hipStream_t st);
 hipError_t unfold_x_launch(const float *src, long long src_bs, float *dst, long long dst_bs, int C, int KW,
                            int pad, int H, int W, int B, hipStream_t st);

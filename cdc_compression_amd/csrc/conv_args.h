@@ -102,6 +102,7 @@ struct PfArgs {
     int nchunk, COP, Cout;
     float acc_scale;
     int ring;                       // weight ring slots (3..6)
+    int n_iter;                     // conv_pf3_kernel: tile iterations per group = ceil(max tiles per workgroup / 2)
     // fp32 NCHW output (may be null): b*out_bs + co*out_cs + oy*out_ys + ox*out_xs + out_zoff[z]
     float *out;
     long long out_bs, out_cs;

@@ -78,6 +78,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
 }
 
 hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
+    if (p.pf3_epv) return pf3_launch(a, p, B, st);
     pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW);
     if (!fn) return hipErrorInvalidValue;
     a.lognbw = 5;

@@ -197,10 +197,11 @@ static int decode_symbol(RansDec &d, const EntropyTable &t) {
     d.advance(t.start[j], t.freq[j]);
     if (j <= 2 * K) return j - K;
     uint32_t w = 0;
-    for (int sh = 0; sh < 48; sh += 12) {
+    for (int sh = 0; sh < 36; sh += 12) {             // the encoder writes at most three 12-bit digits (w < 2^32)
         const uint32_t dg = d.get_bits(13);
-        w |= (dg & 4095u) << sh;
+        w |= (dg & 4095u) << sh;                      // (the third digit's upper bits fall off: a corrupt stream, caught below)
         if (!(dg & 4096u)) break;
+        if (sh == 24) d.bad = true;                   // a fourth continuation digit cannot come from the encoder
     }
     const int mag = (int)(w >> 1) + K + 1;
     return (w & 1u) ? -mag : mag;
@@ -222,8 +223,30 @@ void entropy_encode_symbols(const int32_t *sym, size_t n, const std::vector<cons
 bool entropy_decode_symbols(const uint8_t *in, size_t nbytes, size_t n, const std::vector<const EntropyTable *> &tables, int32_t *sym) {
     if (nbytes < 4) return false;
     RansDec d(in, nbytes);
-    for (size_t i = 0; i < n; ++i) sym[i] = decode_symbol(d, *tables[i]);
+    for (size_t i = 0; i < n && !d.bad; ++i) sym[i] = decode_symbol(d, *tables[i]);     // stop at the first read past the end
     return !d.bad;
+}
+
+// ---- fingerprints carried by the stream header (include/cdc_hip.h): FNV-1a, 32 bit --------------------------------------
+static inline uint32_t fnv_u32(uint32_t h, uint32_t v) {
+    for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
+    return h;
+}
+// every integer the coder uses: per table K, then the 2K + 2 frequencies; hyper tables (channel order), then the scale tables
+uint32_t entropy_model_hash(const EntropyModel *m) {
+    uint32_t h = 2166136261u;
+    for (const std::vector<EntropyTable> *v : {&m->hyper, &m->gauss})
+        for (const EntropyTable &t : *v) {
+            h = fnv_u32(h, (uint32_t)t.K);
+            for (uint32_t f : t.freq) h = fnv_u32(h, f);
+        }
+    return h;
+}
+uint32_t entropy_symbol_hash(const int32_t *a, size_t na, const int32_t *b, size_t nb) {
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < na; ++i) h = fnv_u32(h, (uint32_t)a[i]);
+    for (size_t i = 0; i < nb; ++i) h = fnv_u32(h, (uint32_t)b[i]);
+    return h;
 }
 
 // ---- device side: the per-element work ---------------------------------------------------------------------------------
@@ -236,12 +259,19 @@ __device__ __forceinline__ int scale_bin(const float *edges, float s) {
     return lo;
 }
 
+// *bad is set when a value cannot be coded: a non-finite latent / mean / scale, or a symbol beyond the int32 range
 __global__ void __launch_bounds__(256) latent_symbols_kernel(const float *latent, const float *mean, const float *scale,
-                                                             const float *edges, long long n, int32_t *sym, uint8_t *bin) {
+                                                             const float *edges, long long n, int32_t *sym, uint8_t *bin, int *bad) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (latent) sym[i] = (int32_t)rintf(latent[i] - mean[i]);        // quantize(x, "dequantize", mean) - mean (utils.py:72-85)
-    bin[i] = (uint8_t)scale_bin(edges, scale[i]);
+    bool ok = isfinite(scale[i]) && isfinite(mean[i]);
+    if (latent) {
+        const float r = rintf(latent[i] - mean[i]);                  // quantize(x, "dequantize", mean) - mean (utils.py:72-85)
+        ok = ok && isfinite(r) && fabsf(r) < 2.0e9f;
+        sym[i] = ok ? (int32_t)r : 0;
+    }
+    bin[i] = (uint8_t)scale_bin(edges, ok ? scale[i] : 1.0f);
+    if (!ok && bad) atomicOr(bad, 1);
 }
 
 __global__ void __launch_bounds__(256) symbols_to_latent_kernel(const int32_t *sym, const float *mean, long long n, float *q) {
@@ -250,8 +280,8 @@ __global__ void __launch_bounds__(256) symbols_to_latent_kernel(const int32_t *s
 }
 
 hipError_t latent_symbols_launch(const float *latent, const float *mean, const float *scale, const float *edges, long long n,
-                                 int32_t *sym, uint8_t *bin, hipStream_t st) {
-    hipLaunchKernelGGL(latent_symbols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latent, mean, scale, edges, n, sym, bin);
+                                 int32_t *sym, uint8_t *bin, int *bad, hipStream_t st) {
+    hipLaunchKernelGGL(latent_symbols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latent, mean, scale, edges, n, sym, bin, bad);
     return hipGetLastError();
 }
 

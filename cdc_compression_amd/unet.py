@@ -114,6 +114,14 @@ class Unet:
                 self._finalized = True
         return self._h
 
+    def status(self):
+        """Arithmetic mode and range-guard counters of the library handle (see _lib.handle_status)."""
+        return _lib.handle_status(self._h)
+
+    @property
+    def range_faults(self):
+        return self.status()["range_faults"]
+
     def __del__(self):
         try:
             if self._h is not None:

@@ -78,10 +78,17 @@ const char *cdc_version(void);
  * Tensors are float32 everywhere; the k x k (and wide 1x1) convolutions form their fp32 products on the
  * 16-bit matrix cores from split operands (no reference counterpart -- torch delegates to oneDNN / cuDNN fp32):
  *   CDC_ARITH_F16X2 (default)  a = h + l*2^-11 as two fp16 numbers, w*2^s as {WH, WL}: three
- *                              v_mfma_f32_32x32x16_f16 per product block, error <= 3 fp32 ulp per product,
- *                              activations must satisfy |a| < 65504 -- beyond that the U-Net output is inf / NaN,
- *                              cdc_decode notices (a flag written by the sampler kernel) and repeats the decode
- *                              once in CDC_ARITH_BF16X3; cdc_unet_forward returns the non-finite values as they are;
+ *                              v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulation; operands carry 22-23 significant
+ *                              bits for 6e-5 <= |a| < 65504.  RANGE GUARD: |a| >= 65504 becomes inf / NaN and reaches the
+ *                              results of the call, so EVERY entry point that runs the arithmetic (cdc_unet_forward,
+ *                              cdc_ddim_step, cdc_decode, cdc_ctxdec_decode, cdc_hyperdec_decode, cdc_encoder_encode,
+ *                              cdc_entropy_encode) checks its results (one small kernel + a 4-byte read-back: the call
+ *                              synchronises its stream) and repeats a call with non-finite results ONCE in
+ *                              CDC_ARITH_BF16X3.  The handle then STAYS in that mode (a warning is printed once;
+ *                              cdc_get_arith / cdc_get_range_faults tell).  Results that are non-finite in the full-range
+ *                              arithmetic too (non-finite inputs, parameters beyond fp32) come back as they are, as the
+ *                              reference's would (counted by cdc_get_nonfinite_results).  CDC_NO_RANGE_GUARD=1 in the
+ *                              environment switches the check off.
  *   CDC_ARITH_BF16X3           a = a1 + a2 + a3 exactly as three bf16 numbers: six v_mfma_f32_32x32x16_bf16,
  *                              full fp32 range.
  * Changing the mode drops the handle's launch program (rebuilt on the next call).  New handles take
@@ -89,6 +96,8 @@ const char *cdc_version(void);
 enum { CDC_ARITH_BF16X3 = 0, CDC_ARITH_F16X2 = 1 };
 int cdc_set_arith(cdc_handle *h, int mode);
 int cdc_get_arith(const cdc_handle *h);
+int cdc_get_range_faults(const cdc_handle *h);        /* calls repeated in CDC_ARITH_BF16X3 by the range guard */
+int cdc_get_nonfinite_results(const cdc_handle *h);   /* calls whose results are non-finite in the full-range arithmetic as well */
 
 /* ---- parameters: replaces nn.Module.load_state_dict on the Unet (test_xparam.py:62-68) ------- */
 
@@ -232,9 +241,19 @@ int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, c
  * streams agree byte for byte).  Entry points of a hyper-decoder handle (cdc_hyperdec_create) that has the prior.* tensors.
  * latent / hyper_latent are the UNquantised encoder outputs (cdc_encoder_encode); medians [dims[0]] is a host array.
  * out receives B concatenated streams, image b at [offsets[b], offsets[b+1]) (offsets has B+1 entries).  Each stream:
- *   'C' 'D' 'C' 1 | arith u8 | 0 | h_hyper u16 | w_hyper u16 | n_hyper u32 | n_latent u32 | hyper bytes | latent bytes.
+ *   'C' 'D' 'C' 2 | arith u8 | 0 | h_hyper u16 | w_hyper u16 | n_hyper u32 | n_latent u32 | model u32 | symbols u32 |
+ *   hyper bytes | latent bytes                                                        (version 2, 26-byte header).
+ * model   = FNV-1a over every integer of the probability tables (per table K, then its 2K+2 frequencies; the per-channel
+ *           hyper tables, then the 128 scale tables): a decoder whose tables differ (other prior.* parameters or medians,
+ *           another build, another libm) refuses the stream instead of decoding garbage;
+ * symbols = FNV-1a over the int32 symbols (hyper, then latent): the decoder checks it after decoding.
  * Encoder and decoder run hyper_dec one image at a time (batch-1 launch plan) in the arithmetic the header records, so
- * that the decoder reproduces the encoder's (mean, scale) bit for bit -- the contract every learned codec has.
+ * that the decoder reproduces the encoder's scale bins bit for bit -- the contract every learned codec has.  LIMITS: same
+ * library build, same launch-plan switches (the CDC_* development variables), same GPU architecture on both sides; a
+ * decoder whose hyper_dec output lands in other scale bins decodes other symbols and fails the `symbols` check loudly.
+ * cdc_entropy_decode leaves the handle's own arithmetic as it found it.  hh, wh >= 1 and hh * wh <= 2^22 are enforced
+ * before anything is sized by them; no C++ exception crosses this boundary (CDC_ERR_NOMEM / CDC_ERR_INVALID instead).
+ * cdc_entropy_encode refuses non-finite latents / means / scales (CDC_ERR_INVALID).
  * Synchronous; latent / hyper_latent / q_latent / q_hyper_latent follow `mem`, in / out / offsets / medians are host. */
 int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
                        int h_hyper, int w_hyper, unsigned char *out, size_t cap, size_t *offsets, int mem_kind, void *stream);

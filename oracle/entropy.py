@@ -27,6 +27,11 @@ def lib():
         L.orc_entropy_decode_latent.argtypes = [vp, sz, vp, ctypes.c_longlong, vp]
         L.orc_entropy_ideal_bits_latent.argtypes = [vp, vp, ctypes.c_longlong]
         L.orc_entropy_ideal_bits_latent.restype = ctypes.c_double
+        L.orc_entropy_model_hash.argtypes = [i, vp, vp]
+        L.orc_entropy_model_hash.restype = ctypes.c_uint32
+        L.orc_entropy_symbol_hash.argtypes = [vp, sz, vp, sz]
+        L.orc_entropy_symbol_hash.restype = ctypes.c_uint32
+        L.orc_entropy_gauss_table.argtypes = [i, vp, i]
         _lib = L
     return _lib
 
@@ -99,7 +104,29 @@ def ideal_bits_latent(sym, scale):
     return float(lib().orc_entropy_ideal_bits_latent(sym.ctypes.data, scale.ctypes.data, sym.size))
 
 
-def stream(arith, hh, wh, hyper_bytes, latent_bytes):
-    """The container of include/cdc_hip.h: 'CDC' 1 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 | payloads."""
+def model_hash(prior44, medians):
+    p, m = np.ascontiguousarray(prior44, np.float32), np.ascontiguousarray(medians, np.float32).reshape(-1)
+    return int(lib().orc_entropy_model_hash(p.shape[0], p.ctypes.data, m.ctypes.data))
+
+
+def symbol_hash(sym_h, sym_l):
+    a, b = np.ascontiguousarray(sym_h, np.int32).reshape(-1), np.ascontiguousarray(sym_l, np.int32).reshape(-1)
+    return int(lib().orc_entropy_symbol_hash(a.ctypes.data, a.size, b.ctypes.data, b.size))
+
+
+def gauss_table(bin_index):
+    """(K, freq[2K+2]) of one scale bin."""
+    f = np.zeros(4096, np.uint32)
+    K = lib().orc_entropy_gauss_table(bin_index, f.ctypes.data, f.size)
+    assert K >= 0
+    return K, f[:2 * K + 2].copy()
+
+
+HEADER = 26
+
+
+def stream(arith, hh, wh, hyper_bytes, latent_bytes, model, symbols):
+    """The version-2 container of include/cdc_hip.h: 'CDC' 2 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 |
+    model hash u32 | symbol hash u32 | payloads."""
     import struct
-    return b"CDC\x01" + struct.pack("<BBHHII", arith, 0, hh, wh, len(hyper_bytes), len(latent_bytes)) + hyper_bytes + latent_bytes
+    return b"CDC\x02" + struct.pack("<BBHHIIII", arith, 0, hh, wh, len(hyper_bytes), len(latent_bytes), model, symbols) + hyper_bytes + latent_bytes

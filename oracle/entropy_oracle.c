@@ -217,6 +217,41 @@ int orc_entropy_decode_latent(const uint8_t *in, size_t nbytes, const float *sca
     for (long long i = 0; i < n; ++i) sym[i] = dec_symbol(&d, &g_gauss[scale_bin(scale[i])]);
     return d.bad;
 }
+/* ---- fingerprints of the version-2 container (include/cdc_hip.h): FNV-1a, 32 bit, over little-endian u32 words ---- */
+static uint32_t fnv_u32(uint32_t h, uint32_t v) {
+    for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
+    return h;
+}
+/* every integer the coder uses: per table K, then its 2K + 2 frequencies; hyper tables in channel order, then the 128 scale tables */
+uint32_t orc_entropy_model_hash(int C, const float *raw_prior, const float *medians) {
+    gauss_tables();
+    uint32_t h = 2166136261u;
+    for (int c = 0; c < C; ++c) {
+        table_t t;
+        hyper_table(raw_prior + (size_t)c * 44, medians[c], &t);
+        h = fnv_u32(h, (uint32_t)t.K);
+        for (int j = 0; j < t.n; ++j) h = fnv_u32(h, t.f[j]);
+        table_free(&t);
+    }
+    for (int i = 0; i < NBINS; ++i) {
+        h = fnv_u32(h, (uint32_t)g_gauss[i].K);
+        for (int j = 0; j < g_gauss[i].n; ++j) h = fnv_u32(h, g_gauss[i].f[j]);
+    }
+    return h;
+}
+uint32_t orc_entropy_symbol_hash(const int32_t *a, size_t na, const int32_t *b, size_t nb) {
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < na; ++i) h = fnv_u32(h, (uint32_t)a[i]);
+    for (size_t i = 0; i < nb; ++i) h = fnv_u32(h, (uint32_t)b[i]);
+    return h;
+}
+/* the integer table of one scale bin / one hyper channel, for checkers written elsewhere (tests/test_entropy.py) */
+int orc_entropy_gauss_table(int bin, uint32_t *freq, int cap) {
+    gauss_tables();
+    if (bin < 0 || bin >= NBINS || g_gauss[bin].n > cap) return -1;
+    memcpy(freq, g_gauss[bin].f, sizeof(uint32_t) * g_gauss[bin].n);
+    return g_gauss[bin].K;
+}
 /* ideal code length (bits) of the same symbols under the integer tables: sum -log2(f / 65536) (+ escape payloads) */
 double orc_entropy_ideal_bits_latent(const int32_t *sym, const float *scale, long long n) {
     gauss_tables();

