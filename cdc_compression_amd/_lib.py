@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CDC_HIP_LIB") or os.path.join(_HERE, "libcdc_hip.so")
 
 CDC_MEM_HOST, CDC_MEM_DEVICE = 0, 1
-CDC_PRED_X, CDC_PRED_NOISE, CDC_PRED_NOISE_XTREE = 0, 1, 2
+CDC_PRED_X, CDC_PRED_NOISE, CDC_PRED_NOISE_XTREE, CDC_PRED_V = 0, 1, 2, 3
 CDC_CLIP_NONE, CDC_CLIP_ALL, CDC_CLIP_HALF = 0, 1, 2
 CDC_MAX_LEVELS = 8
 
@@ -101,6 +101,7 @@ def lib():
     L.cdc_dequantize.argtypes = [H, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp]
     L.cdc_bpp.argtypes = [H, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     L.cdc_set_schedule.argtypes = [H, _i, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.cdc_set_schedule_v.argtypes = [H, _i, _vp, _vp]
     L.cdc_ddim_step.argtypes = [H, _vp, _i, pp, _i, _vp, ctypes.c_float, _vp, _i, _i, _i, _i, _i,
                                 _i, _vp]
     L.cdc_decode.argtypes = [H, _vp, pp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]
@@ -131,7 +132,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
            "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap", "cdc_prof_num_ops", "cdc_prof_op",
            "cdc_entropy_encode", "cdc_entropy_peek", "cdc_entropy_decode", "cdc_get_range_faults",
-           "cdc_get_nonfinite_results"]
+           "cdc_get_nonfinite_results", "cdc_set_schedule_v"]
 
 
 def handle_status(handle):

@@ -811,8 +811,10 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
     const float c_acp = a.tab[2 * a.steps + si];
     const float c_1macp = a.tab[3 * a.steps + si];
     const float sig = a.eta * a.tab[4 * a.steps + si];
+    // pred_mode 3 ("v", xparam :128-139,161-162): x0 = sqrt(ac) x - sqrt(1 - ac) v
+    const float c_sac = a.tab_v ? a.tab_v[si] : 0.f, c_s1mac = a.tab_v ? a.tab_v[a.steps + si] : 0.f;
     float var = c_1macp - sig * sig;
-    // x-tree (pred_mode 0 "x", 2 "noise"): .clamp(min=0) under the square root (xparam :169); eps-tree: none
+    // x-tree (pred_mode 0 "x", 2 "noise", 3 "v"): .clamp(min=0) under the square root (xparam :169); eps-tree: none
     if (a.pred_mode != 1) var = fmaxf(var, 0.f);
     const float c_eps = sqrtf(var);
     // clip: 0 none, 1 every image, 2 the first B/2 images only (eps-tree clip_noise "half", eps :142-143)
@@ -823,8 +825,8 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
         const float fx = a.fx[idx], x = a.x[idx];
         bad |= !(fabsf(fx) <= 3.0e38f);                    // inf / NaN from the U-Net (fp16-plane range overflow)
         float x0, eps;
-        if (a.pred_mode == 0) {
-            x0 = fx;
+        if (a.pred_mode == 0 || a.pred_mode == 3) {
+            x0 = a.pred_mode == 0 ? fx : c_sac * x - c_s1mac * fx;
             if (idx < clip_n) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
             eps = (c_recip * x - x0) / c_recipm1;
         } else {

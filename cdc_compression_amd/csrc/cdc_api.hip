@@ -148,6 +148,8 @@ struct cdc_handle {
     // schedule
     int steps = 0;
     float *d_tab = nullptr;              // [5][steps]
+    float *d_tab_v = nullptr;            // [2][steps] (cdc_set_schedule_v), valid for schedule generation tab_v_gen
+    int tab_v_gen = -1, tab_v_steps = 0;
     std::vector<float> h_tab;            // host copy of d_tab: an unchanged schedule is not uploaded again
     size_t tab_cap = 0, trows_cap = 0;   // capacities (floats) of d_tab / d_shift_tab: buffers are reused, not leaked
     int sched_gen = 0;                   // bumped whenever the device tables change (invalidates the captured graph)
@@ -1836,6 +1838,7 @@ void cdc_destroy(cdc_handle *h) {
     free_program(h);
     free_pool(&h->weight_allocs);
     if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->d_tab_v) (void)hipFree(h->d_tab_v);
     if (h->d_time_steps) (void)hipFree(h->d_time_steps);
     if (h->d_shift_tab) (void)hipFree(h->d_shift_tab);
     (void)resolve_pending(h);
@@ -2653,6 +2656,27 @@ static int ensure_time_rows(cdc_handle *h, int B) {
     return CDC_OK;
 }
 
+int cdc_set_schedule_v(cdc_handle *h, int steps, const float *sqrt_ac, const float *sqrt_one_minus_ac) {
+    if (h && h->kind != 0) return fail(h, CDC_ERR_STATE, "handle is not a U-Net");
+    if (!h || !sqrt_ac || !sqrt_one_minus_ac) return fail(h, CDC_ERR_INVALID, "null argument");
+    if (!h->steps || steps != h->steps) return fail(h, CDC_ERR_STATE, "cdc_set_schedule_v follows cdc_set_schedule with the same number of steps");
+    int rc0 = ensure_device(h);
+    if (rc0) return rc0;
+    std::vector<float> tab((size_t)2 * steps);
+    memcpy(&tab[0], sqrt_ac, sizeof(float) * steps);
+    memcpy(&tab[steps], sqrt_one_minus_ac, sizeof(float) * steps);
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (steps > h->tab_v_steps) {
+        if (h->d_tab_v) { (void)hipFree(h->d_tab_v); h->d_tab_v = nullptr; }
+        HIP_TRY(h, hipMalloc((void **)&h->d_tab_v, tab.size() * sizeof(float)));
+        h->tab_v_steps = steps;
+    }
+    HIP_TRY(h, hipMemcpy(h->d_tab_v, tab.data(), sizeof(float) * steps, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_tab_v + h->steps, tab.data() + steps, sizeof(float) * steps, hipMemcpyHostToDevice));
+    h->tab_v_gen = h->sched_gen;
+    return CDC_OK;
+}
+
 static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *noise, float eta,
                           float *x_out, int B, int H, int W, int pred_mode, int clip,
                           hipStream_t st) {
@@ -2665,7 +2689,7 @@ static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *
     op.kind = Op::DDIM; op.prof = PC_SMALL;
     op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i < 0 ? 0 : i,
                i == -2 ? h->d_step : nullptr, pred_mode, clip, eta, (long long)n,
-               (long long)(B / 2) * h->cfg.channels * H * W, h->d_fault};
+               (long long)(B / 2) * h->cfg.channels * H * W, h->d_fault, pred_mode == CDC_PRED_V ? h->d_tab_v : nullptr};
     op.bytes = 16.0 * n;
     return run_op(h, op, B, st);
 }
@@ -2681,6 +2705,9 @@ int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *c
     if (h->out_dim != h->cfg.channels)
         return fail(h, CDC_ERR_UNSUPPORTED, "sampler needs out_dim == channels");
     if (eta != 0.f && !noise) return fail(h, CDC_ERR_INVALID, "eta != 0 needs the noise draw");
+    if (pred_mode < 0 || pred_mode > 3 || clip < 0 || clip > 2) return fail(h, CDC_ERR_INVALID, "pred_mode %d / clip %d out of range", pred_mode, clip);
+    if (pred_mode == CDC_PRED_V && (!h->d_tab_v || h->tab_v_gen != h->sched_gen))
+        return fail(h, CDC_ERR_STATE, "pred_mode \"v\" needs cdc_set_schedule_v after cdc_set_schedule");
     if ((rc = build_program(h, B, H, W))) return rc;
     if ((rc = ensure_time_rows(h, B))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);
@@ -2720,8 +2747,10 @@ int cdc_decode(cdc_handle *h, const float *init, const float *const *ctx, int n_
     if (h->out_dim != h->cfg.channels)
         return fail(h, CDC_ERR_UNSUPPORTED, "sampler needs out_dim == channels");
     if (!out || !ctx) return fail(h, CDC_ERR_INVALID, "null argument");
-    if (pred_mode < 0 || pred_mode > 2 || clip < 0 || clip > 2)
+    if (pred_mode < 0 || pred_mode > 3 || clip < 0 || clip > 2)
         return fail(h, CDC_ERR_INVALID, "pred_mode %d / clip %d out of range", pred_mode, clip);
+    if (pred_mode == CDC_PRED_V && (!h->d_tab_v || h->tab_v_gen != h->sched_gen))
+        return fail(h, CDC_ERR_STATE, "pred_mode \"v\" needs cdc_set_schedule_v after cdc_set_schedule");
     if ((rc = build_program(h, B, H, W))) return rc;
     if ((rc = ensure_time_rows(h, B))) return rc;
     hipStream_t st = pick_stream(h, stream, mem);

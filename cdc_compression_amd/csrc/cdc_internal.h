@@ -152,11 +152,12 @@ struct DdimArgs {
                         //                          one_minus_ac_prev, sigma
     int steps, i;
     const int *step_ptr;   // non-null: the step index is read from device memory (hipGraph replay)
-    int pred_mode, clip;   // pred_mode: 0 x-tree "x", 1 eps-tree "noise", 2 x-tree "noise"; clip: 0 none, 1 all, 2 first half
+    int pred_mode, clip;   // pred_mode: 0 x-tree "x", 1 eps-tree "noise", 2 x-tree "noise", 3 x-tree "v"; clip: 0 none, 1 all, 2 first half
     float eta;
     long long n;
     long long clip_half_n; // elements of the first B/2 images
     int *fault;            // set to 1 when the U-Net output holds inf / NaN (may be null)
+    const float *tab_v;    // pred_mode 3: device table [2][steps]: sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod
 };
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,

@@ -23,9 +23,6 @@ class _GaussianDiffusionBase:
 
     def _init_common(self, denoise_fn, context_fn, num_timesteps, pred_mode, var_schedule):
         assert pred_mode in ["noise", "x", "v"]
-        if pred_mode == "v":
-            raise NotImplementedError('pred_mode "v" (predict_start_from_v) is not implemented: neither reference '
-                                      "test script uses it")
         self.denoise_fn = denoise_fn
         self.context_fn = context_fn
         self.num_timesteps = int(num_timesteps)
@@ -71,6 +68,8 @@ class _GaussianDiffusionBase:
         p = lambda a: a.ctypes.data                                   # noqa: E731
         _lib.check(h, L.cdc_set_schedule(h, s.steps, p(s.time_in), p(s.sqrt_recip), p(s.sqrt_recipm1),
                                          p(s.sqrt_ac_prev), p(s.one_minus_ac_prev), p(s.sigma)))
+        if self._param == "x" and self.pred_mode == "v":             # predict_start_from_v reads two more tables (x :128-139)
+            _lib.check(h, L.cdc_set_schedule_v(h, s.steps, p(s.sqrt_ac), p(s.sqrt_one_minus_ac)))
 
     # ---- sampler ----------------------------------------------------------------------------
     def _clip_flag(self, clip_denoised):
@@ -82,8 +81,8 @@ class _GaussianDiffusionBase:
 
     def _pred_flag(self):
         if self._param == "x":
-            return _lib.CDC_PRED_X if self.pred_mode == "x" else _lib.CDC_PRED_NOISE_XTREE
-        return _lib.CDC_PRED_NOISE
+            return {"x": _lib.CDC_PRED_X, "noise": _lib.CDC_PRED_NOISE_XTREE, "v": _lib.CDC_PRED_V}[self.pred_mode]
+        return _lib.CDC_PRED_NOISE                        # (the eps tree's ddim ignores pred_mode: eps :137-139)
 
     def _loop(self, shape, context, clip_denoised, init, eta):
         L, un = _lib.lib(), self.denoise_fn

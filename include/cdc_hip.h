@@ -47,9 +47,10 @@ enum { CDC_MEM_HOST = 0, CDC_MEM_DEVICE = 1 };
  *   CDC_PRED_X            x-tree, pred_mode "x"     (xparam/modules/denoising_diffusion.py:157-158)
  *   CDC_PRED_NOISE        eps-tree, pred_mode "noise" (epsilonparam/...:137-152: no clamp under the square root)
  *   CDC_PRED_NOISE_XTREE  x-tree, pred_mode "noise" (xparam :155-156,165: x0 = predict_start_from_noise, .clamp(min=0))
+ *   CDC_PRED_V            x-tree, pred_mode "v"     (xparam :161-162: x0 = predict_start_from_v, :128-139; needs cdc_set_schedule_v)
  * clip: CDC_CLIP_NONE, CDC_CLIP_ALL (x-tree clip_denoised=True; eps-tree clip_noise "full"),
  *       CDC_CLIP_HALF (eps-tree clip_noise "half": only the first B/2 images, eps :142-143). */
-enum { CDC_PRED_X = 0, CDC_PRED_NOISE = 1, CDC_PRED_NOISE_XTREE = 2 };
+enum { CDC_PRED_X = 0, CDC_PRED_NOISE = 1, CDC_PRED_NOISE_XTREE = 2, CDC_PRED_V = 3 };
 enum { CDC_CLIP_NONE = 0, CDC_CLIP_ALL = 1, CDC_CLIP_HALF = 2 };
 enum { CDC_MAX_LEVELS = 8 };
 
@@ -139,6 +140,9 @@ int cdc_unet_tap(cdc_handle *h, const char *name, float *out, int64_t shape[4]);
 int cdc_set_schedule(cdc_handle *h, int steps, const float *time_in, const float *sqrt_recip,
                      const float *sqrt_recipm1, const float *sqrt_ac_prev,
                      const float *one_minus_ac_prev, const float *sigma);
+/* The two extra tables pred_mode "v" reads (xparam :99,:103 sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod; used by
+ * predict_start_from_v, :128-139).  Call after cdc_set_schedule with the same number of steps. */
+int cdc_set_schedule_v(cdc_handle *h, int steps, const float *sqrt_ac, const float *sqrt_one_minus_ac);
 
 /* One DDIM update x_t -> x_{t-1} at sample index i (x: :152-174 ; eps: :137-152).
  * clip: x-param clamp of x0 to [-1,1] (clip_denoised=True in compress, :223);

@@ -264,6 +264,8 @@ class Schedule:
         self.one_minus_alphas_cumprod_prev = (f(1.0) - acp).astype(f)
         self.sqrt_recip_alphas_cumprod = np.sqrt(f(1.0) / ac).astype(f)
         self.sqrt_recipm1_alphas_cumprod = np.sqrt(f(1.0) / ac - f(1)).astype(f)
+        self.sqrt_alphas_cumprod = np.sqrt(ac).astype(f)                             # x :99
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(f(1.0) - ac).astype(f)          # x :103
         if self.param == "x":
             # :108  sqrt(1-acp)/sqrt(1-ac) * sqrt(1 - ac/acp)
             self.sigma = (np.sqrt(f(1.0) - acp) / np.sqrt(f(1.0) - ac)
@@ -276,7 +278,7 @@ class Schedule:
 
 def ddim_step(ops, cfg, sd, sched, x, i, context, num_timesteps_for_time, clip, eta=0.0,
               noise=None, pred_mode=None):
-    """One DDIM update.  x-param: xparam/.../denoising_diffusion.py:152-174 (pred_mode "x" or "noise",
+    """One DDIM update.  x-param: xparam/.../denoising_diffusion.py:152-174 (pred_mode "x", "noise" or "v",
     embd_type "01"); eps-param: epsilonparam/.../denoising_diffusion.py:137-152 (clip "full" / "half")."""
     f = np.float32
     B = x.shape[0]
@@ -295,6 +297,13 @@ def ddim_step(ops, cfg, sd, sched, x, i, context, num_timesteps_for_time, clip, 
             x_recon = np.clip(x_recon, -1.0, 1.0)
         eps = fx                                                    # :165
         var = np.maximum(sched.one_minus_alphas_cumprod_prev[i] - sig ** 2, f(0))   # .clamp(min=0)
+    elif sched.param == "x" and pred_mode == "v":
+        # :161-162 predict_start_from_v (:128-139, eval branch): sqrt(ac) x - sqrt(1 - ac) v
+        x_recon = sched.sqrt_alphas_cumprod[i] * x - sched.sqrt_one_minus_alphas_cumprod[i] * fx
+        if clip:
+            x_recon = np.clip(x_recon, -1.0, 1.0)
+        eps = (c_recip * x - x_recon) / c_recipm1                    # :165 predict_noise_from_start
+        var = np.maximum(sched.one_minus_alphas_cumprod_prev[i] - sig ** 2, f(0))
     elif sched.param == "x":
         x_recon = fx
         if clip:

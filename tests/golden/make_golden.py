@@ -140,11 +140,12 @@ def gen_unet(name, taps=True):
     else:
         for k, v in acts.items():
             out[f"tap_{k}"] = v
-    np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **out)
-    with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
-        json.dump({"unet_kwargs": {k: (list(v) if isinstance(v, tuple) else v)
-                                   for k, v in kw.items()},
-                   "context_channels_per_level": ctxc, "manifest": man}, f)
+    if taps:          # (taps=False: a caller that only wants the loaded reference model must not overwrite the fixture)
+        np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **out)
+        with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
+            json.dump({"unet_kwargs": {k: (list(v) if isinstance(v, tuple) else v)
+                                       for k, v in kw.items()},
+                       "context_channels_per_level": ctxc, "manifest": man}, f)
     print(name, "unet ok", y.shape, float(np.abs(y).max()))
     return ref, net, kw, ctxc
 
@@ -196,7 +197,8 @@ def gen_decode_variants():
     """The sampler branches the test scripts do not take: x-tree pred_mode="noise" (xparam :155-156,165; it is the
     reference constructor's default) and eps-tree clip_noise="half" (epsilonparam :142-143, the constructor's default)."""
     out = {}
-    for name, over in (("small_x", {"pred_mode": "noise"}), ("small_eps", {"clip_noise": "half"})):
+    for key, name, over in (("small_x", "small_x", {"pred_mode": "noise"}), ("small_eps", "small_eps", {"clip_noise": "half"}),
+                            ("small_x_v", "small_x", {"pred_mode": "v"})):       # xparam :128-139,161-162
         tree, kw, ctxc, H, W, B = CONFIGS[name]
         ref, net, _, _ = gen_unet(name, taps=False)
         ctx = synth.context_pyramid(ctxc, B, H, W, seed=3)
@@ -213,9 +215,86 @@ def gen_decode_variants():
             else:
                 rec, _ = diff.compress(torch.from_numpy(images), sample_steps=3, sample_mode="ddim",
                                        bpp_return_mean=False, init=torch.from_numpy(init.copy()))
-        out[name] = rec.numpy()
-        print("variant", name, over, float(rec.abs().max()))
+        out[key] = rec.numpy()
+        print("variant", key, over, float(rec.abs().max()))
     np.savez_compressed(os.path.join(HERE, "decode_variants.npz"), **out)
+
+
+def heavy_tail_state(man, sd, gain_max, g_max, seed=31, only_normalised=False):
+    """Heavy-tailed parameters on top of the synthetic ones: the output channels of the convolutions get log-uniform gains
+    in [1 / gain_max, gain_max] (only_normalised: just those whose output a LayerNorm rescales, i.e. Block convolutions),
+    every LayerNorm gain is log-uniform in [1 / g_max, g_max] with a random sign."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k, shape in man:
+        v = np.array(sd[k], np.float32, copy=True)
+        if k.endswith(".weight") and v.ndim == 4 and "final_conv" not in k and (not only_normalised or ".block." in k):
+            co = v.shape[1] if ".up." in k or "upsample" in k.lower() else v.shape[0]
+            gains = np.exp(rng.uniform(-np.log(gain_max), np.log(gain_max), co)).astype(np.float32)
+            if v.shape[0] == co:
+                v *= gains[:, None, None, None]
+            else:
+                v *= gains[None, :, None, None]
+        elif k.endswith(".g"):
+            mag = np.exp(rng.uniform(-np.log(g_max), np.log(g_max), v.shape)).astype(np.float32)
+            v = mag * np.where(rng.random(v.shape) < 0.5, -1.0, 1.0).astype(np.float32)
+        out[k] = v
+    return out
+
+
+def heavy_tail_context(ctxc, B, H, W, lo, hi, seed=33):
+    """Context pyramid with log-uniform magnitudes in [lo, hi] and random signs."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, c in enumerate(ctxc):
+        shape = (B, c, H >> i, W >> i)
+        mag = np.exp(rng.uniform(np.log(lo), np.log(hi), shape))
+        out.append((mag * np.where(rng.random(shape) < 0.5, -1.0, 1.0)).astype(np.float32))
+    return out
+
+
+def gen_heavy_tail():
+    """evidence at a trained-weight-like dynamic range.  Two cases of the small x-param model from the
+    REAL reference: "in_range" (gains x50 on every LayerNorm-ed convolution, LN gains up to 10, context 1e-6 .. 300: a
+    large dynamic range with every convolution INPUT inside the fp16 range of CDC_ARITH_F16X2) and "overflow" (gains x50
+    on every convolution, context up to 3e4: convolution inputs of 1e11, the range guard has to act).  One U-Net forward +
+    a 3-step decode each."""
+    out = {}
+    for case, gain_max, g_max, lo, hi in (("in_range", 50.0, 10.0, 1e-6, 300.0), ("overflow", 50.0, 10.0, 1e-6, 3.0e4)):
+        tree, kw, ctxc, H, W, B = CONFIGS["small_x"]
+        ref = import_reference(tree)
+        net = ref.unet.Unet(**kw)
+        man, sd = load_synth(net, seed=0)
+        sd2 = heavy_tail_state(man, sd, gain_max, g_max, only_normalised=case == "in_range")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+        net.eval()
+        ctx = heavy_tail_context(ctxc, B, H, W, lo, hi)
+        tctx = [torch.from_numpy(c) for c in ctx]
+        x = synth.normal("x", (B, 3, H, W), seed=1, std=0.8)
+        time = np.linspace(0.1, 0.7, B, dtype=np.float32).reshape(B, 1)
+        biggest = [0.0]
+        # what the fp16 planes of CDC_ARITH_F16X2 have to hold: the INPUT of every convolution
+        hooks = [m.register_forward_hook(lambda m_, i_, o_: biggest.__setitem__(0, max(biggest[0], float(i_[0].detach().abs().max()))))
+                 for m in net.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+        with torch.no_grad():
+            y = net(torch.from_numpy(x), torch.from_numpy(time), tctx).numpy()
+        for hk in hooks:
+            hk.remove()
+        diff = ref.dd.GaussianDiffusion(denoise_fn=net, context_fn=FixedContext(tctx), ae_fn=None, **DIFF[tree])
+        diff.eval()
+        init = synth.normal("init", (B, 3, H, W), seed=1, std=0.8)
+        with torch.no_grad():
+            rec, _ = diff.compress(torch.zeros(B, 3, H, W), sample_steps=3, init=torch.from_numpy(init.copy()))
+        out[f"{case}_y"] = y
+        out[f"{case}_rec"] = rec.numpy()
+        out[f"{case}_max_conv_input"] = np.array(biggest[0], np.float64)
+        for i, c in enumerate(ctx):
+            out[f"{case}_ctx{i}"] = c
+        for k, v in sd2.items():
+            if k.endswith(".g") or (k.endswith(".weight") and v.ndim == 4 and "final_conv" not in k):
+                out[f"{case}_sd_{k}"] = v
+        print("heavy tail", case, "largest convolution input", biggest[0], "| y max", float(np.abs(y).max()), "| rec max", float(np.abs(rec.numpy()).max()))
+    np.savez_compressed(os.path.join(HERE, "heavy_tail_small_x.npz"), **out)
 
 
 def gen_schedules():
@@ -234,7 +313,7 @@ def gen_schedules():
             diff.set_sample_schedule(steps, torch.device("cpu"))
             for nm in ("alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod_prev",
                        "one_minus_alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
-                       "sqrt_recipm1_alphas_cumprod", "sigma"):
+                       "sqrt_recipm1_alphas_cumprod", "sigma", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
                 out[f"{tag}_{steps}_{nm}"] = getattr(diff, nm).numpy().copy()
             if tree == "xparam":
                 out[f"{tag}_{steps}_index"] = diff.index.numpy().copy()
@@ -546,6 +625,10 @@ def gen_kodak_eps(steps=1000):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                 # python make_golden.py gen_decode_variants gen_heavy_tail ...: only these generators
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     gen_schedules()
     gen_decode("small_x", [4, 1], eta_case=True)
     gen_decode("small_eps", [4], eta_case=True)

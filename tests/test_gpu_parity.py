@@ -3,6 +3,7 @@
 
 Tolerance: float32 path, max-abs error <= 1e-4 * max(1, max|ref|) (north_star: fp32 tolerance;
 observed reference-vs-fp64 round-off is ~7e-6, see tests/test_oracle.py)."""
+import ctypes
 import json
 import os
 
@@ -602,6 +603,12 @@ def test_kodak_crops_500_steps_match_reference():
     d = np.abs(rec.reshape(-1)[g["rec_idx"]] - g["rec_val"])
     assert d.max() < 3e-5, float(d.max())          # measured 8.4e-6 (bf16x3) / ~1e-5 (fp16x2)
     assert abs(float(rec.astype(np.float64).sum()) - float(g["rec_sum"])) < 1e-5 * rec.size
+    # north_star: "outputs within 1e-4 PSNR of the reference" -- the reference's own per-image PSNR (same definition:
+    # 10 log10(4 / mse) on [-1, 1]) is part of the fixture
+    psnr = np.array([10 * np.log10(4.0 / np.mean((rec[i].astype(np.float64) - x[i]) ** 2)) for i in range(3)])
+    assert np.abs(psnr - g["psnr"]).max() <= 1e-4, (psnr, g["psnr"])
+    # the default two-plane fp16 arithmetic did this on its own: no range fault, no silent fall-back behind a green test
+    assert un.status() == {"arith": 1, "range_faults": 0, "nonfinite_results": 0} and comp.range_faults == 0
     rec2, bpp = diff.compress(x, sample_steps=steps, bpp_return_mean=False, init=init)
     assert np.abs(bpp - g["bpp"]).max() <= 1e-5 * float(np.abs(g["bpp"]).max())
     flipped = int((np.abs(comp(x)["q_latent"] - g["q_latent"]) > 0.5).sum())
@@ -761,6 +768,46 @@ def test_sampler_variants_match_reference_golden():
     rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
     assert relerr(rec, g["small_eps"]) < TOL, relerr(rec, g["small_eps"])
     assert np.abs(rec[: x.shape[0] // 2]).max() <= np.abs(rec).max()
+    # x-tree pred_mode="v" (xparam :128-139,161-162: predict_start_from_v), through cdc_decode and through cdc_ddim_step
+    un, kw, sd, x, time, ctx, _ = make_unet("small_x")
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="v", var_schedule="cosine")
+    rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
+    assert relerr(rec, g["small_x_v"]) < TOL, relerr(rec, g["small_x_v"])
+    h = un._handle()
+    img = init.copy()
+    out = np.empty_like(img)
+    ptrs = (ctypes.c_void_p * len(ctx))(*[c.ctypes.data for c in ctx])
+    for i in reversed(range(3)):
+        _lib.check(h, _lib.lib().cdc_ddim_step(h, img.ctypes.data, i, ptrs, len(ctx), None, 0.0, out.ctypes.data, *x.shape[:1], *x.shape[2:],
+                                               _lib.CDC_PRED_V, _lib.CDC_CLIP_ALL, _lib.CDC_MEM_HOST, None))
+        img = out.copy()
+    np.testing.assert_array_equal(img, rec)
+
+
+@pytest.mark.parametrize("case", ["in_range", "overflow"])
+def test_heavy_tailed_parameters_match_reference_in_both_arithmetics(case):
+    """parity at a trained-weight-like dynamic range (per-channel gains x50, LayerNorm gains up to 10 with
+    either sign, context magnitudes 1e-6 .. 300 / 3e4), against the REAL reference (tests/golden/make_golden.py::
+    gen_heavy_tail).  "in_range": the default two-plane fp16 arithmetic has to carry it alone (no range fault);
+    "overflow" (convolution inputs up to 7e11): the range guard has to hand the call to the three-plane bf16 arithmetic.
+    Both are also run in CDC_ARITH_BF16X3 from the start."""
+    from test_oracle import heavy_tail_case
+    kw, sd, x, time, ctx, y_ref, rec_ref, biggest = heavy_tail_case(case)
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    for arith in (1, 0):
+        un = cdc.Unet(**kw)
+        un.load_state_dict(sd)
+        _lib.check(un._handle(), _lib.lib().cdc_set_arith(un._handle(), arith))
+        y = un(x, time, ctx)
+        assert relerr(y, y_ref) < 2e-4, (case, arith, relerr(y, y_ref))
+        st = un.status()
+        if arith == 1 and case == "in_range":
+            assert biggest < 65504 and st == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}, st
+        if arith == 1 and case == "overflow":
+            assert biggest > 65504 and st == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}, st
+        diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+        rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
+        assert float(np.abs(rec - rec_ref).max()) < 2e-4, (case, arith, float(np.abs(rec - rec_ref).max()))
 
 
 def test_fp16_range_overflow_falls_back_to_bf16_planes():

@@ -75,7 +75,7 @@ def test_schedules_match_reference():
             s.set_sample_schedule(steps)
             for nm in ("alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod_prev",
                        "one_minus_alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
-                       "sqrt_recipm1_alphas_cumprod", "sigma"):
+                       "sqrt_recipm1_alphas_cumprod", "sigma") + (("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod") if tag == "x" else ()):
                 ref = g[f"{tag}_{steps}_{nm}"]
                 got = getattr(s, nm)
                 assert got.dtype == np.float32 and got.shape == ref.shape
@@ -124,14 +124,40 @@ def test_sampler_variants_match_reference(O):
     """Branches the test scripts do not take but the constructors default to: x-tree pred_mode="noise"
     (xparam/modules/denoising_diffusion.py:155-156,165) and eps-tree clip_noise="half" (epsilonparam :142-143)."""
     g = np.load(os.path.join(GOLDEN, "decode_variants.npz"))
-    for name, param, T, vs, clip, pm in (("small_x", "x", 8193, "cosine", True, "noise"),
-                                         ("small_eps", "eps", 20000, "linear", "half", None)):
+    for key, name, param, T, vs, clip, pm in (("small_x", "small_x", "x", 8193, "cosine", True, "noise"),
+                                              ("small_eps", "small_eps", "eps", 20000, "linear", "half", None),
+                                              ("small_x_v", "small_x", "x", 8193, "cosine", True, "v")):   # xparam :128-139,161-162
         kw, man, sd, x, time, ctx, _ = load_case(name)
         init = synth.normal("init", x.shape, seed=1, std=0.8)
         s = om.Schedule(T, vs, param).set_sample_schedule(3)
         rec = om.p_sample_loop(O, oracle_cfg(kw), sd, s, x.shape, ctx, clip, init=init, pred_mode=pm)
-        ref = g[name]
-        assert np.abs(rec - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name
+        ref = g[key]
+        assert np.abs(rec - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
+
+
+def heavy_tail_case(case):
+    """tests/golden/heavy_tail_small_x.npz (make_golden.py::gen_heavy_tail): the small x-param model with heavy-tailed
+    channel gains / LayerNorm gains and a context pyramid of log-uniform magnitude, outputs of the real reference."""
+    g = np.load(os.path.join(GOLDEN, "heavy_tail_small_x.npz"))
+    kw, man, sd, x, time, ctx, _ = load_case("small_x")
+    sd = dict(sd)
+    for k in g.files:
+        if k.startswith(case + "_sd_"):
+            sd[k[len(case) + 4:]] = g[k]
+    ctx = [g[f"{case}_ctx{i}"] for i in range(len(ctx))]
+    return kw, sd, x, time, ctx, g[f"{case}_y"], g[f"{case}_rec"], float(g[f"{case}_max_conv_input"])
+
+
+@pytest.mark.parametrize("case", ["in_range", "overflow"])
+def test_heavy_tailed_parameters_match_reference(O, case):
+    """The restatement at a trained-weight-like dynamic range (convolution inputs up to 6e2 / 7e11)."""
+    kw, sd, x, time, ctx, y_ref, rec_ref, _ = heavy_tail_case(case)
+    y = om.unet_forward(O, oracle_cfg(kw), sd, x, time, ctx)
+    assert np.abs(y - y_ref).max() <= 2e-4 * max(1.0, np.abs(y_ref).max()), float(np.abs(y - y_ref).max())
+    init = synth.normal("init", x.shape, seed=1, std=0.8)
+    s = om.Schedule(8193, "cosine", "x").set_sample_schedule(3)
+    rec = om.p_sample_loop(O, oracle_cfg(kw), sd, s, x.shape, ctx, True, init=init)
+    assert np.abs(rec - rec_ref).max() <= 2e-4, float(np.abs(rec - rec_ref).max())
 
 
 def test_full_width_decode_matches_reference(O):
