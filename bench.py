@@ -56,7 +56,7 @@ def workload_name(param, B, S, steps, world):
             + (f" ({tag})" if tag else " (not a BASELINE configuration)"))
 
 
-def cpu_baseline(param, size, sample_steps, n_iter=2):
+def cpu_baseline(param, size, sample_steps, n_iter=4):
     """Oracle (CPU restatement of the reference, kind="port") on the host cores: B=1, n_iter DDIM
     iterations, extrapolated linearly to `sample_steps` (time is iteration-linear)."""
     from cdc_compression_amd import synth
@@ -71,15 +71,18 @@ def cpu_baseline(param, size, sample_steps, n_iter=2):
            for l, c in enumerate(cfgd["ctx"])]
     x = rng.standard_normal((1, 3, size, size)).astype(np.float32) * 0.8
     sched = om.Schedule(cfgd["T"], cfgd["vs"], param).set_sample_schedule(sample_steps)
+    x = om.ddim_step(O, cfg, sd, sched, x, sample_steps - 1, ctx, None, True if param == "x" else "none")   # (untimed: pages, threads)
     t0 = time.time()
     for i in range(n_iter):
-        x = om.ddim_step(O, cfg, sd, sched, x, sample_steps - 1 - i, ctx, None,
+        x = om.ddim_step(O, cfg, sd, sched, x, sample_steps - 2 - i, ctx, None,
                          True if param == "x" else "none")
     dt = (time.time() - t0) / n_iter
     return {"value": 1.0 / (dt * sample_steps), "unit": "images/s", "cores": os.cpu_count(),
             "kind": "port",
-            "sample": f"oracle/ (naive C+OpenMP restatement, slower than the oneDNN reference), 1 image x {n_iter} of "
-                      f"{sample_steps} DDIM iterations at {size}x{size}, {dt:.2f} s/iteration, extrapolated linearly",
+            "sample": f"oracle/ (C + OpenMP restatement of the reference's ATen calls; the stride-1 convolutions -- 93 % of the "
+                      f"multiply-adds -- as a register-tiled direct convolution, AVX2), 1 image x {n_iter} of {sample_steps} DDIM "
+                      f"iterations at {size}x{size}, {dt:.2f} s/iteration = {FULL[param]['gflop_per_image_step'] * (size / 256.0) ** 2 / dt:.0f} "
+                      f"GFLOP/s, extrapolated linearly",
             "reference_probe": REFERENCE_PROBE}
 
 
@@ -94,6 +97,7 @@ def main():
     ap.add_argument("--param", choices=["x", "eps"], default="x")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the B=1 re-decode of two output rows")
+    ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra decode in the exact bf16x3 arithmetic")
     ap.add_argument("--prof-every", type=int, default=50)
     a = ap.parse_args()
     if a.sample_steps is None:
@@ -193,14 +197,15 @@ def main():
         # dominant kernel = the launch shape with the largest total time among the matrix-core convolutions
         conv_ops = [o for o in ops if o["label"].startswith("conv 3x3 s1") and o["flops"] > 0]
         groups = {}
-        def launch_key(label):                              # shape + tile shape + which kernel + residual input
+        def launch_key(label):                              # layer shape + which kernel runs it (epilogue variants of one kernel together)
             t = label.split()
-            kern = "PF" if "PF" in t else ("PW" if "PW" in t else ("SPLIT2H" if "SPLIT2H" in t else ("SPLIT2" if "SPLIT2" in t else "CONV")))
-            return " ".join(t[:8]) + " " + kern + (" +res" if "+res" in t else "")
+            kern = next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2") if k in t), "CONV")
+            return " ".join(t[:6]) + " " + kern
         for o in conv_ops:
             key = launch_key(o["label"])
-            g = groups.setdefault(key, dict(ms=0.0, n=0, flops=o["flops"], label=o["label"]))
-            g["ms"] += o["ms"]; g["n"] += 1
+            g = groups.setdefault(key, dict(ms=0.0, n=0, flops=o["flops"], label=o["label"], labels=[], res=0))
+            g["ms"] += o["ms"]; g["n"] += 1; g["labels"].append(f'{o["ms"]:.4f} ms  {o["label"]}')
+            g["res"] += 1 if "+res" in o["label"].split() else 0
         domk, dom = max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else ("", dict(ms=0, n=1, flops=0, label=""))
         dom_ms = dom["ms"] / max(dom["n"], 1)
         ach = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -214,7 +219,7 @@ def main():
         exec_tf = exec_gflop_iter * 1e-3 / B * a.sample_steps * value
         # counter-based HBM traffic of the dominant launch shape, if a PMC pass of THIS build was committed
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "pmc_r03_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -231,7 +236,8 @@ def main():
             cout = int(dom["label"].split("->")[1].split()[0])
             # input once + output once, 4 bytes per element (+ the residual operand where the launch
             # has one: it is an input of the fused epilogue)
-            alg_bytes = 4.0 * B * pixels_out * (int(cio[0]) + cout + (cout if "+res" in dom["label"].split() else 0))
+            # (averaged over the launches of the group: `res` of its `n` launches read a residual operand)
+            alg_bytes = 4.0 * B * pixels_out * (int(cio[0]) + cout + cout * dom["res"] / max(dom["n"], 1))
         except Exception:
             alg_bytes = None
         out = {
@@ -240,7 +246,9 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": ("float32 tensors and accumulation; convolution products formed on the 16-bit matrix cores from "
-                           + ("two-plane fp16 split operands (3 MFMA products per fp32 product)" if arith == 1 else
+                           + ("two-plane fp16 split operands (3 MFMA products per fp32 product; operands carry 22-23 significant "
+                              "bits, not 24; |activation| < 65504 or the range guard repeats the call in bf16x3 -- see `range_guard`, "
+                              "`alt_arith`)" if arith == 1 else
                               "exact three-plane bf16 split operands (6 MFMA products per fp32 product)")),
             "config": {"workload": workload_name(a.param, B, S, a.sample_steps, world),
                        "batch_per_gpu": B, "global_batch": B * world, "sample_steps": a.sample_steps, "size": S,
@@ -248,9 +256,12 @@ def main():
                        "arith": "f16x2" if arith == 1 else "bf16x3"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": dom["label"], "launch_key": domk,
-                "kernel_note": "dominant launch shape (largest total time among the 3x3 Block convolutions, fused LN "
-                               "epilogue); achieved = its algorithmic flops / its hipEvent-timed average duration",
+                "kernel": dom["label"], "launch_key": domk, "launches": dom.get("labels", []),
+                "kernel_note": "dominant (layer shape, kernel) pair: largest total time among the 3x3 Block convolutions with fused "
+                               "LN epilogue; achieved = its algorithmic flops / the hipEvent-timed average duration of its launches "
+                               "(sampled inside the timed region, on the launch stream)",
+                "hbm_view": ({"algorithmic_bytes_per_launch": alg_bytes, "achieved_tb_s": alg_bytes / (dom_ms * 1e-3) / 1e12,
+                              "frac_of_8tb_s": alg_bytes / (dom_ms * 1e-3) / 8e12} if alg_bytes and dom_ms > 0 else None),
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0,
                 "peak_basis": f"2500 TFLOP/s dense 16-bit MFMA / {products} products per algorithmic fp32 product",
                 "mfma_tflops_executed": ach * products,
@@ -272,6 +283,9 @@ def main():
                 "class_ms_share": {k: (v["ms"] / tot_ms if tot_ms else 0) for k, v in classes.items()},
                 "class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
                                  for k, v in classes.items()},
+                # algorithmic bytes of the class (each op: its inputs once + its outputs once) / its time
+                "class_tb_per_s": {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
+                                   for k, v in classes.items()},
                 "class_ms_per_ddim_iter": {k: v["ms"] / n_prof_iters for k, v in classes.items()},
                 "ms_per_ddim_iter": dt / a.steps / a.sample_steps * 1e3,
             },
@@ -293,6 +307,25 @@ def main():
             out["batch1"] = {"images_per_s": len(rows) / t1, "ms_per_ddim_iter": t1 / len(rows) / a.sample_steps * 1e3,
                              "note": "one image per call, same model and step count (the reference test scripts' mode)"}
             out["config"]["finite"] = ok and out["verify"]["ok"]
+        if world == 1 and not a.no_alt_arith and arith == 1:
+            # The exact-split arithmetic on the record beside the default one: the same decode once more in
+            # CDC_ARITH_BF16X3 (three bf16 planes per operand, six MFMA products per fp32 product, full fp32 range).
+            _lib.check(h, L.cdc_set_arith(h, 0))
+            decode_fn(init, ctx, steps=2)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            rec_alt = decode_fn(init, ctx)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - ta
+            den = max(1.0, float(rec.abs().max().item()))
+            out["alt_arith"] = {"arith": "bf16x3", "value": B / tb, "unit": "images/s", "ms_per_step": tb * 1e3,
+                                "ms_per_ddim_iter": tb / a.sample_steps * 1e3, "peak_tflops": PEAK_16BIT_MFMA_TFLOPS / PRODUCTS[0],
+                                "whole_path_tflops_canonical": cfgd["gflop_per_image_step"] * scale * 1e-3 * a.sample_steps * B / tb,
+                                "max_rel_diff_vs_f16x2_decode": float((rec_alt - rec).abs().max().item()) / den,
+                                "finite": bool(torch.isfinite(rec_alt).all().item()),
+                                "note": "one timed decode of the same batch, outside `value`"}
+            _lib.check(h, L.cdc_set_arith(h, 1))
+        out["range_guard"] = _lib.handle_status(h)
         if world == 1 and a.param == "x" and S % 64 == 0:
             # informational (outside the timed region): the compressor on the GPU -- Compressor.forward (analysis
             # transform, hyper encoder/decoder, quantisers, rate estimate, synthesis transform) and decode alone

@@ -286,7 +286,8 @@ class _ContextDecoder:
         if len({a.mem for a in args}) != 1:
             raise _lib.CdcError("all inputs must live in the same memory")
         B, _, hh, wh = args[0].shape
-        if args[1].shape != (B, self.reversed_hyper_dims[-1] // 2, 4 * hh, 4 * wh) or \
+        up = 2 ** (len(self.reversed_hyper_dims) - 2)       # as in hyper_decode: one stride-2 ConvTranspose2d per hyper_dec layer but the last
+        if args[1].shape != (B, self.reversed_hyper_dims[-1] // 2, up * hh, up * wh) or \
                 args[2].shape != args[1].shape or args[3].shape != args[1].shape:
             raise _lib.CdcError(f"latent shapes {args[1].shape} do not belong to a {args[0].shape} hyper latent")
         out, po, _ = _result_like(q_hyper_latent, (B,), self.device_index)

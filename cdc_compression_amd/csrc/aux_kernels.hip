@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache) {
-        static const int pl8_max = getenv("CDC_LN_PL8_MAX") ? atoi(getenv("CDC_LN_PL8_MAX")) : 256;
+        static const int pl8_max = dev_env("CDC_LN_PL8_MAX") ? atoi(dev_env("CDC_LN_PL8_MAX")) : 256;
         // 8-pixel workgroups also wherever 32-pixel ones would leave most of the chip idle (small batches)
         const bool pl8 = a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < 1024;
         const dim3 grid((unsigned)ceil_div(a.HW, pl8 ? 8 : 32), (unsigned)B);

@@ -375,7 +375,7 @@ int pack_conv(cdc_handle *h, const float *w, const float *bias, int CoutF, int C
     int rc = upload(h, packed.data(), packed.size(), &cw->wp, pool);
     if (rc) return rc;
     cw->wsp = nullptr;
-    if (((cw->KH * cw->KW > 1 && Cin >= 16) || Cin >= 32) && !getenv("CDC_NO_SPLIT")) {
+    if (((cw->KH * cw->KW > 1 && Cin >= 16) || Cin >= 32) && !dev_env("CDC_NO_SPLIT")) {
         // exact three-way bf16 split (truncation): w = w1 + w2 + w3, laid out in MFMA A-operand order
         // [z][tap][Cin_pad/16][plane][k-half][COP][8 cin]
         const int taps = cw->KH * cw->KW, nc16 = cw->Cin_pad / 16;
@@ -473,7 +473,7 @@ int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k,
     if (hoist_cx > 0) {
         const std::string w1 = p + ".block1.block.0.weight", b1 = p + ".block1.block.0.bias";
         if ((rc = pack_named_conv(h, w1, "", 1, k / 2, false, &rb.c1x, 0, hoist_cx))) return rc;
-        if (k > 3 && hoist_cx * k <= 32 && !getenv("CDC_NO_UNFOLD")) {
+        if (k > 3 && hoist_cx * k <= 32 && !dev_env("CDC_NO_UNFOLD")) {
             // column-unfolded form of the few-channel k x k layer: w'[co][kx*cx + c][ky][0] = w[co][c][ky][kx]
             const Param &pw = h->params[h->pindex.at(w1)];
             const int co_n = (int)pw.shape[0], ci_n = (int)pw.shape[1], cu = hoist_cx * k;
@@ -633,7 +633,7 @@ void free_pool(std::vector<void *> *pool) {
 // ------------------------------------------------------------------------------------------------
 // program construction
 // ------------------------------------------------------------------------------------------------
-static int ks_target() { static const int v = getenv("CDC_KS_TARGET") ? atoi(getenv("CDC_KS_TARGET")) : 1024; return v; }
+static int ks_target() { static const int v = dev_env("CDC_KS_TARGET") ? atoi(dev_env("CDC_KS_TARGET")) : 1024; return v; }
 
 struct Builder {
     cdc_handle *h;
@@ -706,16 +706,16 @@ struct Builder {
     //   attention and Upsample outputs up to 64 x 64 (the two halves of a decoder concat: 384 -> 128 @64^2 -0.19 for
     //   +0.025); at 128^2 the two costs (+0.13) eat the gain (-0.13), the 256^2 skip has no reader at all.
     enum Site { SITE_NONE, SITE_ALWAYS, SITE_RB_CHAIN, SITE_DOWN, SITE_JOIN };
-    int pf_mode() const { const char *e = getenv("CDC_PF"); return h->arith != 1 ? 0 : (e ? atoi(e) : 3); }
+    int pf_mode() const { const char *e = dev_env("CDC_PF"); return h->arith != 1 ? 0 : (e ? atoi(e) : 3); }
     bool pf_site(Site s, int H, int W) const {
         const int m = pf_mode();
         if (m == 1) return s != SITE_NONE;
         if (m != 3) return false;
-        const long long join_max = getenv("CDC_PF_JOIN_MAXPIX") ? atoll(getenv("CDC_PF_JOIN_MAXPIX")) : 4096;
+        const long long join_max = dev_env("CDC_PF_JOIN_MAXPIX") ? atoll(dev_env("CDC_PF_JOIN_MAXPIX")) : 4096;
         return s == SITE_RB_CHAIN || s == SITE_DOWN || (s == SITE_JOIN && (long long)H * W <= join_max);
     }
     bool pf_on() const { return pf_mode() != 0; }
-    static long long pf_maxpix() { const char *e = getenv("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
+    static long long pf_maxpix() { const char *e = dev_env("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
     PfTwin *twin(const float *p) { auto it = pfmap.find(p); return it == pfmap.end() ? nullptr : &it->second; }
     void add_twin(const float *p, int C, int H, int W) {
         if (rc || !p || !pf_on() || (C % 16) || W < 32 || H < 2 || (long long)H * W > pf_maxpix()) return;
@@ -790,7 +790,7 @@ struct Builder {
         if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
         if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
         if (s1 ? (t0->C != C0 || t0->C + t1->C != w.Cin) : t0->C != w.Cin) return false;
-        static const bool pf_t = getenv("CDC_PF_TRANSPOSED") != nullptr;   // measured slower than the phase-folded split kernel
+        static const bool pf_t = dev_env("CDC_PF_TRANSPOSED") != nullptr;   // measured slower than the phase-folded split kernel
         const bool k3 = w.KH == 3 && w.KW == 3 && !w.transposed, k1 = w.KH == 1 && w.KW == 1, k2 = w.transposed && w.tk == 4 && pf_t;
         if (!(k3 || k1 || k2)) return false;
         if (!w.transposed && ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2)) return false;
@@ -861,7 +861,7 @@ struct Builder {
     bool try_pw(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W,
                 float *out, long long out_bs, const ConvOpts &o, bool need_all, int prof, const ConvShape &s) {
         if (h->arith != 1 || !w.wsh || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
-        if (getenv("CDC_NO_PW")) return false;
+        if (dev_env("CDC_NO_PW")) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0) return false;
         if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || o.no_f32) return false;
         if (o.pre_mean && o.pre_mode != 2) return false;
@@ -943,7 +943,7 @@ struct Builder {
         if (try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
-        if (!getenv("CDC_NO_KSPLIT") && !getenv("CDC_NO_KSPLIT_PLAN"))
+        if (!dev_env("CDC_NO_KSPLIT") && !dev_env("CDC_NO_KSPLIT_PLAN"))
             s.max_ksplit = o.max_ksplit > 1 ? o.max_ksplit : (linear_ep ? 4 : 1);
         if (need_all && (w.Cout % 32)) return false;
         ConvPlan plan;
@@ -954,7 +954,7 @@ struct Builder {
             return true;
         }
         last_ksplit = 1;
-        if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !getenv("CDC_NO_KSPLIT")) {
+        if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !dev_env("CDC_NO_KSPLIT")) {
             // few workgroups and a long K loop (low-resolution levels): slice K so that the chip holds
             // >= 4 workgroups per CU; the LayerNorm kernel that follows adds the slices
             const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
@@ -967,7 +967,7 @@ struct Builder {
         float *ks_scratch = nullptr;
         const long long dense_bs = (long long)w.Cout * s.Ho * s.Wo;
         if (o.max_ksplit <= 1 && plan.split == 2 && !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean &&
-            !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed && !getenv("CDC_NO_KSPLIT")) {
+            !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed && !dev_env("CDC_NO_KSPLIT")) {
             const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
                                   plan.groups;
             const int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(4, plan.nchunk / 4));
@@ -1080,8 +1080,8 @@ struct Builder {
         // the split-bf16 kernels hold at most 6 channel blocks per workgroup: wider layers run them over
         // channel groups (2x the matrix rate) and normalise in a separate pass
         // (round 2: eight blocks = 256 channels with NPW = 1, two workgroups per CU)
-        static const bool no_mb8 = getenv("CDC_NO_MB8") != nullptr;
-        if (w.wsp && w.Cout > (no_mb8 ? 192 : 256) && (W & 3) == 0 && !getenv("CDC_NO_SPLIT")) return false;
+        static const bool no_mb8 = dev_env("CDC_NO_MB8") != nullptr;
+        if (w.wsp && w.Cout > (no_mb8 ? 192 : 256) && (W & 3) == 0 && !dev_env("CDC_NO_SPLIT")) return false;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.Ho = H; s.Wo = W; s.B = B; s.lnmode = 0;
@@ -1093,7 +1093,7 @@ struct Builder {
         if (!conv_make_plan(s, &pu)) return true;
         const double wf = (double)pf.tiles_x * pf.tiles_y * B * pf.WN;
         const double wu = (double)pu.tiles_x * pu.tiles_y * B * pu.groups * pu.WN;
-        static const double thr = getenv("CDC_FUSE_MIN_WAVES") ? atof(getenv("CDC_FUSE_MIN_WAVES")) : 512;
+        static const double thr = dev_env("CDC_FUSE_MIN_WAVES") ? atof(dev_env("CDC_FUSE_MIN_WAVES")) : 512;
         if (wf >= thr) return true;              // >= half of the chip's 1024 SIMDs busy
         return wu < 1.5 * wf;
     }
@@ -1127,7 +1127,7 @@ struct Builder {
         const size_t plane_f = (size_t)B * w.Cout * H * W;
         if (!pre_add && w.wsp && w.Cout <= 8 * 48 && plane_f * 4 * 4 <= (160u << 20)) {
             // low-resolution levels: split-K partial sums into scratch, summed by the LayerNorm kernel
-            const int kmax = getenv("CDC_KMAX") ? atoi(getenv("CDC_KMAX")) : 4;
+            const int kmax = dev_env("CDC_KMAX") ? atoi(dev_env("CDC_KMAX")) : 4;
             float *part = dalloc(plane_f * kmax);
             u.max_ksplit = kmax;
             conv(w, s0, C0, bs0, s1, bs1, H, W, part, out.bs(), u, false, prof);
@@ -1150,7 +1150,7 @@ struct Builder {
         Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W, true, out_site);
         if (pf_mode() >= 2 && pf_would_plan(rb.c2, H, W)) add_twin(h1.p, rb.cout, H, W);
         // h1 feeds block2 only: when block2 runs on the pre-split operand kernel the fp32 copy is never read
-        static const bool keep_h1 = getenv("CDC_PF_KEEP_H1") != nullptr;
+        static const bool keep_h1 = dev_env("CDC_PF_KEEP_H1") != nullptr;
         const bool h1_pf_only = !keep_h1 && twin(h1.p) && pf_would_plan(rb.c2, H, W);
         if (a1 && a1_is_context && rb.hoist_cx == a0.C) {
             std::vector<Op> *saved = cur;
@@ -1182,7 +1182,7 @@ struct Builder {
             block(rb.c1x, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
                   nullptr, nullptr, prof1, h1_pf_only);
             if (rb.has_res && a0.C == 3 && rb.cresx.COP == round_up(rb.cout, 32) && prefer_fused(rb.c2, H, W) &&
-                !getenv("CDC_NO_RES3")) {
+                !dev_env("CDC_NO_RES3")) {
                 // res_conv over the 3 image channels rides in block2's epilogue; its context half (with
                 // the bias) is the hoisted tensor
                 res = pr.p; res_bs = pr.bs();
@@ -1229,10 +1229,10 @@ struct Builder {
     Act attention(const AttnW &at, Act x, float *sm, float *sr) {
         if (rc) return Act();
         const int C = at.C, H = x.H, W = x.W, N = H * W;
-        const bool fold = at.WoT && N >= 16 * C && !getenv("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
+        const bool fold = at.WoT && N >= 16 * C && !dev_env("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
         // C = 64 levels: k/v projection, row maxima and softmax(k) v^T in ONE pass over x (attn_kernels.hip)
-        const bool fused = fold && (C == 64 || (C == 128 && !getenv("CDC_NO_KVCTX128"))) &&
-                           at.kvWt && N % 2048 == 0 && !getenv("CDC_NO_KVCTX");
+        const bool fused = fold && (C == 64 || (C == 128 && !dev_env("CDC_NO_KVCTX128"))) &&
+                           at.kvWt && N % 2048 == 0 && !dev_env("CDC_NO_KVCTX");
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
         Act qkv = fused ? Act() : new_act(kvc, H, W, false);
         ConvOpts oq;                                   // LN(x) folded into the projection (LNMODE 2)
@@ -1245,7 +1245,7 @@ struct Builder {
         int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
         nsplit = std::min(nsplit, std::max(1, N / 64));
         if (fused) {        // >= 2.6 rounds of 3 workgroups per CU (C = 64) / 4 rounds of one (C = 128)
-            static const int kv64 = getenv("CDC_KV64_WGS") ? atoi(getenv("CDC_KV64_WGS")) : 2048;
+            static const int kv64 = dev_env("CDC_KV64_WGS") ? atoi(dev_env("CDC_KV64_WGS")) : 2048;
             nsplit = std::min(128, C == 64 ? ceil_div(kv64, B) : ceil_div(1024, B));   // (the fold sums the splits serially)
             while (nsplit > 1 && N % (32 * nsplit)) --nsplit;
         }
@@ -1264,7 +1264,7 @@ struct Builder {
         if (fused) {
             Op f; f.kind = Op::KVCTX; f.prof = PC_ATTN_CTX;
             f.kvc = {x.p, x.bs(), sm, sr, at.kvWt, at.kvb, at.kvWs, C, N, nsplit, S, ksum, kmaxs};
-            if (h->arith == 1 && at.kvWh && !getenv("CDC_KVCTX_BF16")) { f.kvc.Ws = at.kvWh; f.kvc.f16 = 1; f.kvc.wscale_inv = at.kv_scale_inv; }
+            if (h->arith == 1 && at.kvWh && !dev_env("CDC_KVCTX_BF16")) { f.kvc.Ws = at.kvWh; f.kvc.f16 = 1; f.kvc.wscale_inv = at.kv_scale_inv; }
             f.flops = 6.0 * B * (double)C * C * N; f.bytes = 4.0 * B * C * N;
             emit(f);
         } else {
@@ -1274,17 +1274,17 @@ struct Builder {
             emit(p);
         }
         // folded output as one streaming pass (lnconv_kernel) where the level is wide enough to be bandwidth-bound
-        const bool stream_out = fold && (C == 64 || C == 192 || (C == 128 && getenv("CDC_LNCONV128"))) && N >= 4096 && N % 1024 == 0 &&
-                                !getenv("CDC_NO_LNCONV");
+        const bool stream_out = fold && (C == 64 || C == 192 || (C == 128 && dev_env("CDC_LNCONV128"))) && N >= 4096 && N % 1024 == 0 &&
+                                !dev_env("CDC_NO_LNCONV");
         // folded output as a 1x1 split convolution with per-image planes (C % 16 == 0, planes layout = the A-operand
         // layout of conv_split2_kernel with COP == C): replaces the f32-MFMA kernel and, where faster, lnconv_kernel
-        const bool no_pic = getenv("CDC_NO_PERIMAGE_SPLIT") != nullptr;
+        const bool no_pic = dev_env("CDC_NO_PERIMAGE_SPLIT") != nullptr;
         // (measured, batch 32: 0.41 -> 0.31 ms at C = 64 / 256^2, 0.30 -> 0.20 at C = 128 / 128^2, 0.18 -> 0.10 at C = 192 / 64^2:
         //  faster than the streaming lnconv_kernel everywhere, which stays as the CDC_NO_PERIMAGE_SPLIT fallback)
         const bool split_out = fold && !no_pic && (C % 32) == 0 && (W & 3) == 0;
         // few-pixel levels (not folded): the per-image product out = ctx^T q as a split convolution as well (planes from
         // ctx_reduce_kernel) -- it was the last user of the fp32 -> bf16x3 register-staged kernel on the decode path
-        const bool split_ctxq = !fold && !no_pic && h->arith == 1 && (C % 32) == 0 && (W & 3) == 0 && !getenv("CDC_NO_CTXQ_SPLIT");
+        const bool split_ctxq = !fold && !no_pic && h->arith == 1 && (C % 32) == 0 && (W & 3) == 0 && !dev_env("CDC_NO_CTXQ_SPLIT");
         const bool planes_f16 = (split_out && h->arith == 1) || split_ctxq;
         unsigned short *Ws = (stream_out || split_out || split_ctxq) ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
@@ -1434,7 +1434,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
             // from the epilogue when one workgroup owns all channels
             // ... or, better, apply that LayerNorm right there (every phase workgroup owns all channels of
             // its pixels): the final convolution then reads an already normalised tensor
-            if (!getenv("CDC_NO_FINAL_LN_FUSE")) {
+            if (!dev_env("CDC_NO_FINAL_LN_FUSE")) {
                 Builder::ConvOpts ol;
                 ol.ln_g = h->fin_g; ol.ln_b = h->fin_b;
                 done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ol, true, PC_UP);
@@ -1615,7 +1615,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, B, st));
             break;
         case Op::CTXP: {
-            const bool ctxp_f32 = getenv("CDC_CTXP_F32") != nullptr;
+            const bool ctxp_f32 = dev_env("CDC_CTXP_F32") != nullptr;
             HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
                                           op.at.S, op.at.ksum, op.at.nsplit, B, st, h->arith == 1 && !ctxp_f32));
             break;
@@ -2014,7 +2014,7 @@ int cdc_finalize_weights(cdc_handle *h) {
         const std::string p = "downs." + std::to_string(i);
         const int dout = h->dims[i + 1];
         const int cin0 = down_in_channels(h, i);
-        const int hoist_cx = (cin0 != h->dims[i] && !getenv("CDC_NO_HOIST")) ? h->dims[i] : 0;
+        const int hoist_cx = (cin0 != h->dims[i] && !dev_env("CDC_NO_HOIST")) ? h->dims[i] : 0;
         if ((rc = pack_resblock(h, p + ".0", cin0, dout, i == 0 ? 7 : 3, &shift_off, hoist_cx)))
             return rc;
         if ((rc = pack_resblock(h, p + ".1", dout, dout, 3, &shift_off))) return rc;
@@ -3042,7 +3042,7 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
     bd.ln(ax.p, nullptr, C, H * W, nullptr, nullptr, 0, nullptr, nullptr, sm, sr);   // statistics only
     Act ay = bd.attention(at, ax, sm, sr);
     if (bd.rc) return bd.rc;
-    if (const char *tap = getenv("CDC_ATTN_TAP")) {          // debugging aid: return an intermediate
+    if (const char *tap = dev_env("CDC_ATTN_TAP")) {          // debugging aid: return an intermediate
         const size_t idx = (size_t)atoi(tap);
         if (idx < bd.dbg_taps.size()) {
             const size_t n = std::min(bd.dbg_taps[idx].second, (size_t)B * C * H * W);

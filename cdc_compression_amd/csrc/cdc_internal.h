@@ -1,5 +1,6 @@
 // cdc_internal.h -- host-side declarations shared by the translation units of libcdc_hip.so.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -59,6 +60,16 @@ bool pw_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
 hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long long dst_bs, int C, int H, int W, int B,
                           hipStream_t st);
+
+// Development switches -- the ~45 CDC_* launch-plan / kernel-selection A/B knobs of the planners -- are honoured only in a
+// process started with CDC_DEV=1 (the test-suite and the tuning tools set it).  Every other process runs the default
+// plans whatever else is in its environment: two processes of one build agree on every launch plan, which is what the
+// entropy coder's "the decoder reproduces the encoder's hyper-decoder output" contract needs (include/cdc_hip.h).
+// User-level variables stay plain getenv: CDC_ARITH, CDC_NO_RANGE_GUARD, CDC_GRAPH, CDC_DEBUG_PLAN, CDC_PROF_OPS.
+inline const char *dev_env(const char *name) {
+    static const bool on = [] { const char *e = ::getenv("CDC_DEV"); return e && atoi(e) != 0; }();
+    return on ? ::getenv(name) : nullptr;
+}
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

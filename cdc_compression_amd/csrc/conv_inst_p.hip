@@ -37,7 +37,7 @@ static const PfCand kCands[] = {
 bool pf_make_plan(const PfShape &s, PfPlan *p) {
     if (s.Cout % 32 || s.Cin % 16 || (s.C0 % 16)) return false;
     if (s.Wo < 32) return false;                              // 32-pixel blocks are rows of the image (lognbw = 5)
-    static const char *force = getenv("CDC_PF_PLAN");         // tuning aid: "MB,NPW,WM,WP"
+    static const char *force = dev_env("CDC_PF_PLAN");         // tuning aid: "MB,NPW,WM,WP"
     int f[4] = {0, 0, 0, 0};
     if (force) sscanf(force, "%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3]);
     double best = -1;
@@ -60,7 +60,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         // Few workgroups (small batches at the 64^2 / 32^2 levels): the register-staged kernel with split-K fills the
         // chip better (batch 1: 192->192 @64^2 0.032 ms against 0.09 here; 128->128 @128^2 with 128 workgroups: 0.07
         // against 0.038 -- the threshold sits between the two)
-        static const double min_waves = getenv("CDC_PF_MIN_WAVES") ? atof(getenv("CDC_PF_MIN_WAVES")) : 256.0;
+        static const double min_waves = dev_env("CDC_PF_MIN_WAVES") ? atof(dev_env("CDC_PF_MIN_WAVES")) : 256.0;
         if (wgs * NW < min_waves) continue;
         const double fill = std::min(1.0, wgs * NW / 2048.0);
         const double reads = (3.0 * c.MB + 2.0 * c.NPW) / (3.0 * c.MB * c.NPW);   // ds_read_b128 per MFMA
@@ -82,14 +82,14 @@ hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW);
     if (!fn) return hipErrorInvalidValue;
     a.lognbw = 5;
-    { static const char *e = getenv("CDC_PF_DBG"); a.dbg = e ? atoi(e) : 0; }
+    { static const char *e = dev_env("CDC_PF_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
-    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
+    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
     hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
     return hipGetLastError();
 }

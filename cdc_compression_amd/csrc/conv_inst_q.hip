@@ -27,7 +27,7 @@ static int device_cus() {
 
 // Takes a fully described stride-1 3x3 layer (the PfArgs of conv_pf_kernel) and decides whether conv_pf3_kernel runs it.
 bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *p) {
-    static const bool off = getenv("CDC_NO_PF3") != nullptr;
+    static const bool off = dev_env("CDC_NO_PF3") != nullptr;
     p->pf3_epv = 0;
     if (off || a.KH != 3 || a.KW != 3 || nz != 1) return false;
     if (a.pad_y[0] != 1 || a.pad_x[0] != 1) return false;

@@ -30,7 +30,7 @@ bool pw_make_plan(const PfShape &s, PfPlan *p) {
     // maps narrower than 32 pixels: 32-pixel blocks of the flattened image, a workgroup may span images ("linear" tiles)
     const bool lin = s.Wo < 32;
     if (lin && ((s.Ho * s.Wo) % 32)) return false;
-    const double min_waves = getenv("CDC_PW_MIN_WAVES") ? atof(getenv("CDC_PW_MIN_WAVES")) : 512.0;   // (per call: tests switch it)
+    const double min_waves = dev_env("CDC_PW_MIN_WAVES") ? atof(dev_env("CDC_PW_MIN_WAVES")) : 512.0;   // (per call: tests switch it)
     double best = -1;
     for (const PwCand &c : kPwCands) {
         const int COPT = c.WM * c.MB * 32, NW = c.WM * c.WP;
@@ -72,7 +72,7 @@ hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
     }
     a.lin = p.lin;
     dim3 grid((unsigned)(p.lin ? p.tiles_x : p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
-    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
+    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
     hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
     return hipGetLastError();
 }

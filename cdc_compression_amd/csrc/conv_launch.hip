@@ -51,7 +51,7 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     // 16-byte input pieces: tile origins are multiples of 4 columns, so the patch of phase z starts
     // (-pad_x[z]) mod 4 columns after a 16-byte boundary; widen it to start ON the boundary.
     const bool xvec = s.Win > 0 && (s.Win & 3) == 0 && s.lnmode != 1 && ((NBW * s.stride) & 3) == 0 &&
-                      !getenv("CDC_NO_XVEC");
+                      !dev_env("CDC_NO_XVEC");
     int xshift[4] = {0, 0, 0, 0};
     if (xvec) {
         int mx = 0;
@@ -118,7 +118,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // small feature maps (one or two 32-pixel row blocks per wave cover the image): pack several images
     // into the workgroup so the weight stages are still shared by four waves
     int ipw = 1;
-    if (allow_ipw && !s.per_image_w && s.Wo <= NBW && WN <= 2 && s.B >= 2 && !getenv("CDC_NO_IPW")) { ipw = 4 / WN; WN = 4; }
+    if (allow_ipw && !s.per_image_w && s.Wo <= NBW && WN <= 2 && s.B >= 2 && !dev_env("CDC_NO_IPW")) { ipw = 4 / WN; WN = 4; }
     const int wpi = WN / ipw;
     const int nthr = 64 * WN;
     const int TH = wpi * NPW * NBH;
@@ -136,7 +136,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     if (lds2 > 80 * 1024) { tg = 1; lds2 = lds_tap; }
     // a third workgroup per CU (+12 % measured on 64->64 @256^2) when single-tap stages bring the LDS
     // footprint under 160/3 KiB and the kernel's registers allow three waves per SIMD
-    if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !getenv("CDC_NO_TG1"))
+    if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !dev_env("CDC_NO_TG1"))
         if (conv_kernel_fn f = lookup2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
             if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
     // Few workgroups (low-resolution levels): the chip cannot hide the weight-stage latency by occupancy,
@@ -147,14 +147,14 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
         const long long wgs = (long long)(ipw > 1 ? ceil_div(s.B, ipw) : ceil_div(s.Wo, NBW) * ceil_div(s.Ho, TH) * s.B) *
                               (nblocks / MB) * s.nz;
         const size_t lds_all = sizeof(float) * ((size_t)ipw * xpl * plane + (size_t)2 * taps * 24 * COPT);
-        static const char *force = getenv("CDC_TGALL");
+        static const char *force = dev_env("CDC_TGALL");
         const bool few = wgs <= 3 * 256 && lds_all <= 72 * 1024;
         if (taps > tg && ((force && atoi(force) && lds_all <= 150 * 1024) || (!force && few))) { tg = taps; lds2 = lds_all; }
     }
     // patch units per thread: stride 2 always runs the two-unit / parity-plane variant
     const int xu = s.stride == 2 ? 2 : 1;
     const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && lookup2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
-                    (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && !getenv("CDC_NO_XU2_SMALL"))) && !getenv("CDC_NO_XU2"))) && !getenv("CDC_NO_SPLIT2");
+                    (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && !dev_env("CDC_NO_XU2_SMALL"))) && !dev_env("CDC_NO_XU2"))) && !dev_env("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
     if (!v2 && s.per_image_w) return false;          // only the register-staged variant takes per-image planes
     if (!v2 && ar) { ConvShape s0 = s; s0.arith = 0; return try_plan_split(s0, MB, NPW, lognbw, p, allow_ipw); }
@@ -199,13 +199,13 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     double best_score = -1;
     // tuning aid: CDC_PLAN="MB,NPW,KC" (0 = free) restricts the candidates
     int f_mb = 0, f_npw = 0, f_kc = 0;
-    if (const char *e = getenv("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
+    if (const char *e = dev_env("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
     // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
     // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
     const bool split_ok = s.allow_split && (s.lnmode == 0 || s.lnmode == 1 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
                           s.Cin >= (s.KH * s.KW > 1 ? 16 : 32) && (s.C0 % 16) == 0 &&
                           s.Win > 0 && (s.Win & 3) == 0 && (((1 << lognbw) * s.stride) & 3) == 0 &&
-                          !getenv("CDC_NO_SPLIT");
+                          !dev_env("CDC_NO_SPLIT");
     if (split_ok) {
         for (int MB : mbs) {
             if (f_mb && !s.need_all_cout && MB != f_mb) continue;
@@ -213,7 +213,7 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                 if (MB * NPW > 8 || MB > 8) continue;
                 if (NPW > 1 && NPW > nb_rows) continue;
                 if (f_npw && NPW != f_npw) continue;
-                if (s.KH == 7 && s.KW == 1 && getenv("CDC_71_NPW") && NPW != atoi(getenv("CDC_71_NPW"))) continue;
+                if (s.KH == 7 && s.KW == 1 && dev_env("CDC_71_NPW") && NPW != atoi(dev_env("CDC_71_NPW"))) continue;
                 ConvPlan p;
                 p.split = 0;
                 if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
@@ -277,7 +277,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     conv_kernel_fn fn = p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
 #ifdef CDC_WITH_ABLATIONS      // tuning build only (make ABL=1): compile-time ablated kernels, wrong results
-    static const int ablate = getenv("CDC_ABLATE") ? atoi(getenv("CDC_ABLATE")) : 0;
+    static const int ablate = dev_env("CDC_ABLATE") ? atoi(dev_env("CDC_ABLATE")) : 0;
     if (ablate && p.split == 1)
         if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;
     if (ablate && p.lnmode == 0 && !p.split)
@@ -293,8 +293,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
               (unsigned)(nz * a.ksplit));
     a.zfold = 0;
-    a.xcd_remap = (p.split != 1 && p.ipw == 1 && grid.x % 8 == 0 && grid.x >= 64 && !getenv("CDC_NO_XCD")) ? 1 : 0;
-    if (p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0 && !getenv("CDC_NO_ZFOLD")) {
+    a.xcd_remap = (p.split != 1 && p.ipw == 1 && grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+    if (p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0 && !dev_env("CDC_NO_ZFOLD")) {
         a.zfold = 1; grid.x *= 4; grid.z = 1;
     }
     dim3 block(64 * p.WN);

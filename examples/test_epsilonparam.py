@@ -9,7 +9,7 @@ from _common import load_checkpoint, run_folder, synthetic_state
 
 import cdc_compression_amd as cdc
 
-parser = argparse.ArgumentParser(description="values from bash script")
+parser = argparse.ArgumentParser(description="epsilon-parameterisation: decode a directory of images with the HIP path (reference counterpart: epsilonparam/test_epsilonparam.py)")
 parser.add_argument("--ckpt", type=str, required=True)               # ckpt path, or "synthetic"
 parser.add_argument("--gamma", type=float, default=0.8)
 parser.add_argument("--n_denoise_step", type=int, default=200)

@@ -13,7 +13,7 @@ from _common import ema_model_state, load_checkpoint, run_folder, synthetic_stat
 
 import cdc_compression_amd as cdc
 
-parser = argparse.ArgumentParser(description="values from bash script")
+parser = argparse.ArgumentParser(description="x-parameterisation: decode a directory of images with the HIP path (reference counterpart: xparam/test_xparam.py)")
 parser.add_argument("--ckpt", type=str, required=True)               # ckpt path, or "synthetic"
 parser.add_argument("--gamma", type=float, default=0.8)              # noise intensity for decoding
 parser.add_argument("--n_denoise_step", type=int, default=65)        # number of denoising steps

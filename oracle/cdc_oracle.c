@@ -18,6 +18,8 @@
  * tight checker used to measure fp32 round-off of both the reference and the HIP path).
  */
 #include <math.h>
+#include <omp.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,11 +33,87 @@ typedef ORC_ACC acc_t;
 
 /* y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[b,ci,oy*s+ky-p,ox*s+kx-p]
  * (torch.nn.functional.conv2d semantics; reference call sites listed above). */
+/* Stride-1 layers (93 % of the multiply-adds of the path): same arithmetic as the loop nest below -- y = bias + sum over
+ * (ci, ky, kx) in that order, one accumulator per output -- as a register-tiled direct convolution: the input is copied
+ * once into a zero-padded buffer, the weights of a block of 8 output channels into [ci][ky][kx][8] order, and a task owns
+ * 8 channels x one output row, walked in tiles of 16 pixels whose 8 x 16 accumulators stay in registers over the whole
+ * (ci, ky, kx) loop.  (The CPU baseline of bench.py runs through this; it is what makes the oracle a CPU path someone
+ * would accept as a baseline rather than a naive loop nest.) */
+#define CB 8
+#define TW 16
+static void conv2d_s1_tiled(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int H, int W,
+                            int Cout, int KH, int KW, int pad)
+{
+    const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad + TW;                 /* + slack: the last tile reads past the row */
+    const int ncb = (Cout + CB - 1) / CB, taps = KH * KW;
+    float *xp = (float *)calloc((size_t)B * Cin * Hp * Wp + TW, sizeof(float));
+    float *wp = (float *)calloc((size_t)ncb * Cin * taps * CB, sizeof(float));
+    double t0 = getenv("ORC_TIME") ? omp_get_wtime() : 0, t1 = 0, t2 = 0;
+#pragma omp parallel
+    {
+#pragma omp for collapse(2) schedule(static)
+        for (int bc = 0; bc < B * Cin; ++bc)
+            for (int iy = 0; iy < H; ++iy)
+                memcpy(xp + ((size_t)bc * Hp + iy + pad) * Wp + pad, x + ((size_t)bc * H + iy) * W, sizeof(float) * W);
+#pragma omp for schedule(static)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    for (int j = 0; j < CB; ++j)
+                        if (cb * CB + j < Cout)
+                            wp[(((size_t)cb * Cin + ci) * taps + t) * CB + j] = w[((size_t)(cb * CB + j) * Cin + ci) * taps + t];
+#pragma omp single
+        t1 = omp_get_wtime();
+#pragma omp for collapse(3) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int cb = 0; cb < ncb; ++cb)
+                for (int oy = 0; oy < Ho; ++oy) {
+                    const int co0 = cb * CB;
+                    const int nco = (Cout - co0) < CB ? (Cout - co0) : CB;
+                    const float *wb = wp + (size_t)cb * Cin * taps * CB;
+                    for (int ox0 = 0; ox0 < Wo; ox0 += TW) {
+                        acc_t acc[CB][TW];
+                        for (int j = 0; j < CB; ++j) {
+                            const acc_t bv = (bias && j < nco) ? (acc_t)bias[co0 + j] : (acc_t)0;
+                            for (int i = 0; i < TW; ++i) acc[j][i] = bv;
+                        }
+                        for (int ci = 0; ci < Cin; ++ci) {
+                            const float *xc = xp + (((size_t)b * Cin + ci) * Hp + oy) * Wp + ox0;
+                            const float *wc = wb + (size_t)ci * taps * CB;
+                            for (int ky = 0; ky < KH; ++ky)
+                                for (int kx = 0; kx < KW; ++kx) {
+                                    const float *xs = xc + (size_t)ky * Wp + kx;
+                                    const float *wt = wc + (ky * KW + kx) * CB;
+                                    for (int j = 0; j < CB; ++j) {
+                                        const acc_t wv = (acc_t)wt[j];
+#pragma omp simd
+                                        for (int i = 0; i < TW; ++i) acc[j][i] += wv * (acc_t)xs[i];
+                                    }
+                                }
+                        }
+                        const int nw = (Wo - ox0) < TW ? (Wo - ox0) : TW;
+                        for (int j = 0; j < nco; ++j) {
+                            float *yr = y + (((size_t)b * Cout + co0 + j) * Ho + oy) * Wo + ox0;
+                            for (int i = 0; i < nw; ++i) yr[i] = (float)acc[j][i];
+                        }
+                    }
+                }
+    }
+    if (t0 != 0) { t2 = omp_get_wtime(); fprintf(stderr, "[orc] prep %.1f ms  main %.1f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3); }
+    free(xp);
+    free(wp);
+}
+
 void orc_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cin,
                 int H, int W, int Cout, int KH, int KW, int stride, int pad)
 {
     const int Ho = (H + 2 * pad - KH) / stride + 1;
     const int Wo = (W + 2 * pad - KW) / stride + 1;
+    if (stride == 1 && Ho > 0 && Wo > 0) {
+        conv2d_s1_tiled(x, w, bias, y, B, Cin, H, W, Cout, KH, KW, pad);
+        return;
+    }
 #pragma omp parallel
     {
         acc_t *acc = (acc_t *)malloc(sizeof(acc_t) * CO_BLK * Wo);

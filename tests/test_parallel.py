@@ -64,3 +64,64 @@ def test_sharded_decode_gathers_full_batch_world2(B):
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(ok for _, ok, _ in res)
     assert all(shape == (B, 3, 8, 8) for _, _, shape in res)
+
+
+# ---- the REAL decode through the sharded path (one GPU: the ranks share it, the gather runs over gloo) ---------------
+
+def _gpu_worker(rank, world, port, B, q):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cdc_compression_amd as cdc
+        from cdc_compression_amd import synth
+        from helpers import load_case
+        kw, man, sd, x, time, ctx, _ = load_case("small_x")
+        un = cdc.Unet(**kw)
+        un.load_state_dict(sd)
+        diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+        H, W = x.shape[2:]
+        dev = torch.device("cuda", 0)
+        init = torch.from_numpy(synth.normal("init", (B, 3, H, W), seed=1, std=0.8)).to(dev)
+        cfull = [torch.from_numpy(synth.normal(f"c{l}", (B, c.shape[1], c.shape[2], c.shape[3]), seed=3, std=0.5)).to(dev)
+                 for l, c in enumerate(ctx)]
+
+        def decode_fn(i, c):
+            return diff.decompress(c, (c[0].shape[0], 3, H, W), sample_steps=3, init=i)
+
+        out = sharded_decode(decode_fn, init, cfull, world, rank, dist)              # global_batch=None: slices the batch itself
+        ref = decode_fn(init, cfull)                                               # the unsharded decode of the whole batch
+        lo, hi = shard_bounds(B, world, rank)
+        err = float((out - ref).abs().max().item())
+        q.put((rank, tuple(out.shape), err, hi - lo, un.range_faults, None))
+    except Exception as e:                                                         # noqa: BLE001
+        q.put((rank, None, None, None, None, repr(e)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_real_decode_through_ragged_shards_world2_on_one_gpu():
+    """`sharded_decode` driving the REAL HIP decode (cdc_decode through the C-ABI) with a ragged batch
+    (5 images -> shards of 3 and 2) on two ranks; every rank ends up with the whole batch, equal to the unsharded
+    decode up to the launch-plan difference between batch sizes.  (Two ranks on the one GPU of a test box: RCCL refuses
+    duplicate devices, so the gather of the CUDA tensors runs over gloo here; bench.py under torchrun covers the RCCL
+    group, test_bench_under_torchrun_one_rank_nccl.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[5] is None for r in res), [r[5] for r in res]
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert sorted(r[3] for r in res) == [2, 3]                       # ragged shards
+    for rank, shape, err, n, faults, _ in res:
+        assert shape == (5, 3, 32, 32) and err < 2e-5 and faults == 0, (rank, shape, err, faults)
