@@ -361,6 +361,14 @@ def main():
                                          "finite": bool(torch.isfinite(fo["bpp"]).all().item()),
                                          "note": "Compressor.forward = encode + bpp + decode (SURVEY 8f rows 1-3), "
                                                  "once per image, not in `value`"}
+            ms_ana, _ = timed(lambda: comp.analysis(img), 3)
+            ms_enc, streams = timed(lambda: comp.compress_to_bytes(img), 3)
+            ms_ent, ql = timed(lambda: comp.decompress_from_bytes(streams, like=img), 3)
+            out["entropy_coder"] = {"encode_ms_per_batch": ms_enc - ms_ana, "decode_ms_per_batch": ms_ent, "analysis_ms_per_batch": ms_ana,
+                                    "batch": B, "bytes_per_image": sum(len(x) for x in streams) / B,
+                                    "max_abs_diff_vs_forward_q_latent": float((ql - fo["q_latent"]).abs().max().item()),
+                                    "note": "64-lane interleaved rANS on the GPU (SURVEY 8f row 4): symbols + hyper_dec + coder + "
+                                            "container, host bytes in/out; synthetic parameters, so the sizes say nothing about rate"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
         print(json.dumps(out), flush=True)

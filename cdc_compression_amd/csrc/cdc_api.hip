@@ -110,6 +110,7 @@ struct cdc_handle {
     float *d_prior = nullptr;     // kind 2: FlexiblePrior per channel, 44 floats (softplus / tanh applied), or null
     std::vector<double> h_prior;  // kind 2: the same in float64 (probability tables of the entropy coder)
     std::unique_ptr<cdc::EntropyModel> ent;   // kind 2: entropy coder tables (built on first use)
+    uint32_t ent_model_hash = 0;
     std::vector<int> rev_dims;    // kind 1: [dim*m for m in rev_mults] + [out_channels]
     int up_index = 1;
     std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
@@ -137,6 +138,7 @@ struct cdc_handle {
     int shift_bs = 0;
     // program
     int pB = 0, pH = 0, pW = 0;
+    bool p_batch1_plan = false;   // the program was planned as for one image (entropy coder contract, entropy.hip)
     std::vector<Op> ops;          // per DDIM iteration (depends on x_t and t)
     std::vector<Op> pre_ops;      // depends on the context pyramid only: once per decode / forward
     std::vector<void *> act_allocs;
@@ -640,6 +642,8 @@ struct Builder {
     int B;
     std::vector<void *> *pool;      // where device allocations are recorded
     int rc = CDC_OK;
+    int planB = 0;                  // > 0: choose every kernel variant / K split as for this batch (buffers and grids still use B)
+    int pb() const { return planB > 0 ? planB : B; }
     std::vector<Op> *cur = nullptr; // op list being emitted to (h->ops unless set)
 
     void emit(Op op) {
@@ -776,7 +780,7 @@ struct Builder {
         if (!((w.KH == 3 && w.KW == 3) || (w.KH == 1 && w.KW == 1))) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2) return false;
         PfShape ps;
-        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = w.KH; ps.KW = w.KW; ps.Ho = H; ps.Wo = W; ps.B = B; ps.need_all_cout = true;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = w.KH; ps.KW = w.KW; ps.Ho = H; ps.Wo = W; ps.B = pb(); ps.need_all_cout = true;
         PfPlan plan;
         return (w.Cin % 16) == 0 && pf_make_plan(ps, &plan);
     }
@@ -796,7 +800,7 @@ struct Builder {
         if (!w.transposed && ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2)) return false;
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = w.KH; ps.KW = w.KW; ps.nz = w.nz;
-        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = B; ps.need_all_cout = need_all;
+        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = need_all;
         PfPlan plan;
         if (!pf_make_plan(ps, &plan)) return false;
         Op op;
@@ -868,7 +872,7 @@ struct Builder {
         if (o.w_bs && !o.wsp_bs) return false;              // per-image weights without planes
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = 1; ps.KW = 1; ps.nz = 1;
-        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = B; ps.need_all_cout = false;
+        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = false;
         PfPlan plan;
         if (!pw_make_plan(ps, &plan)) return false;
         if (plan.lin && (o.shift || o.wsp_bs || (long long)w.Cout * s.Ho * s.Wo != out_bs)) return false;   // tiles span images
@@ -937,7 +941,7 @@ struct Builder {
             s.Ho = (H + 2 * pad_y - w.KH) / w.stride + 1;
             s.Wo = (W + 2 * pad_x - w.KW) / w.stride + 1;
         }
-        s.B = B; s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
+        s.B = pb(); s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
         if (try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
         if (try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
@@ -957,7 +961,7 @@ struct Builder {
         if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !dev_env("CDC_NO_KSPLIT")) {
             // few workgroups and a long K loop (low-resolution levels): slice K so that the chip holds
             // >= 4 workgroups per CU; the LayerNorm kernel that follows adds the slices
-            const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
+            const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(pb(), plan.ipw) : plan.tiles_x * plan.tiles_y * pb()) *
                                   plan.groups * w.nz;
             int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(o.max_ksplit, plan.nchunk / 4));
             if (ks > 1) { plan.ksplit = ks; last_ksplit = ks; }
@@ -968,10 +972,10 @@ struct Builder {
         const long long dense_bs = (long long)w.Cout * s.Ho * s.Wo;
         if (o.max_ksplit <= 1 && plan.split == 2 && !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean &&
             !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed && !dev_env("CDC_NO_KSPLIT")) {
-            const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(B, plan.ipw) : plan.tiles_x * plan.tiles_y * B) *
+            const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(pb(), plan.ipw) : plan.tiles_x * plan.tiles_y * pb()) *
                                   plan.groups;
             const int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(4, plan.nchunk / 4));
-            if (ks > 1 && (size_t)B * dense_bs * 4 * ks <= (64u << 20)) {
+            if (ks > 1 && (planB > 0 || (size_t)B * dense_bs * 4 * ks <= (64u << 20))) {
                 plan.ksplit = ks;
                 ks_scratch = dalloc((size_t)ks * B * dense_bs);
             }
@@ -1084,7 +1088,7 @@ struct Builder {
         if (w.wsp && w.Cout > (no_mb8 ? 192 : 256) && (W & 3) == 0 && !dev_env("CDC_NO_SPLIT")) return false;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
-        s.Ho = H; s.Wo = W; s.B = B; s.lnmode = 0;
+        s.Ho = H; s.Wo = W; s.B = pb(); s.lnmode = 0;
         s.Win = W; s.pad_x[0] = w.pad;
         ConvPlan pf, pu;
         s.need_all_cout = true;
@@ -1350,6 +1354,7 @@ void free_program(cdc_handle *h) {
     h->dec_outs.clear();
     h->act_bytes = 0;
     h->pB = h->pH = h->pW = 0;
+    h->p_batch1_plan = false;
     h->time_steps_B = 0;
 }
 
@@ -1521,10 +1526,12 @@ int build_encoder_program(cdc_handle *h, int B, int H, int W) {
 }
 
 // Launch program of Compressor.hyper_dec (compress_modules.py:54-60) for q_hyper_latent [B][dims[0]][hh][wh].
-int build_hyperdec_program(cdc_handle *h, int B, int hh, int wh) {
-    if (h->pB == B && h->pH == hh && h->pW == wh) return CDC_OK;
+// batch1_plan: every image runs the kernels a batch-1 call would run (the entropy coder's contract, entropy.hip)
+int build_hyperdec_program(cdc_handle *h, int B, int hh, int wh, bool batch1_plan = false) {
+    if (h->pB == B && h->pH == hh && h->pW == wh && h->p_batch1_plan == batch1_plan) return CDC_OK;
     free_program(h);
     Builder bd{h, B, &h->act_allocs};
+    if (batch1_plan) bd.planB = 1;
     h->in_x = bd.dalloc((size_t)B * h->hyper_dims[0] * hh * wh);
     if (bd.rc) return bd.rc;
     Act x; x.p = h->in_x; x.C = h->hyper_dims[0]; x.H = hh; x.W = wh;
@@ -1542,6 +1549,7 @@ int build_hyperdec_program(cdc_handle *h, int B, int hh, int wh) {
     h->dec_outs.clear();
     h->dec_outs.push_back(x);
     h->pB = B; h->pH = hh; h->pW = wh;
+    h->p_batch1_plan = batch1_plan;
     return CDC_OK;
 }
 
@@ -1799,6 +1807,20 @@ bool guard_escalate(cdc_handle *h, int *rc) {
     return *rc == CDC_OK;
 }
 struct RetryScope { cdc_handle *h; explicit RetryScope(cdc_handle *h_) : h(h_) { h->in_retry = true; } ~RetryScope() { h->in_retry = false; } };
+}  // namespace
+
+namespace {
+// device scratch of one entropy call, released on every exit path
+struct DevPool {
+    std::vector<void *> v;
+    ~DevPool() { for (void *p : v) (void)hipFree(p); }
+    template <class T> hipError_t get(T **p, size_t n) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) { v.push_back(q); *p = (T *)q; }
+        return e;
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -2241,8 +2263,9 @@ int cdc_hyperdec_decode(cdc_handle *h, const float *q_hyper_latent, float *mean,
 
 // ---- entropy coder (entropy.hip) ---------------------------------------------------------
 namespace {
-constexpr int kStreamVersion = 2;
-constexpr int kStreamHeader = 26;     // 'C' 'D' 'C' 2 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 | model hash u32 | symbol hash u32
+constexpr int kStreamVersion = 3;
+// 'C' 'D' 'C' 3 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 | model hash u32 | symbol checksum u32 | hyper escapes u32 | latent escapes u32
+constexpr int kStreamHeader = 34;
 
 int ensure_entropy(cdc_handle *h, const float *medians) {
     if (h->kind != 2) return fail(h, CDC_ERR_STATE, "handle is not a hyper decoder");
@@ -2250,52 +2273,41 @@ int ensure_entropy(cdc_handle *h, const float *medians) {
     const int C = h->hyper_dims[0];
     if (!h->ent) h->ent.reset(new cdc::EntropyModel);
     cdc::entropy_init(h->ent.get());
-    if ((int)h->ent->medians.size() != C || memcmp(h->ent->medians.data(), medians, sizeof(float) * C) != 0)
+    if ((int)h->ent->medians.size() != C || memcmp(h->ent->medians.data(), medians, sizeof(float) * C) != 0) {
         cdc::entropy_build_hyper(h->ent.get(), h->h_prior.data(), medians, C);
+        h->ent->dev_stale = true;
+    }
     if (!h->ent->d_edges) {
         int rc = upload(h, h->ent->edges, cdc::kEntropyBins, &h->ent->d_edges, &h->weight_allocs);
         if (rc) return rc;
     }
+    if (h->ent->dev_stale) {
+        HIP_TRY(h, hipDeviceSynchronize());                   // nothing in flight may still read the tables being replaced
+        HIP_TRY(h, cdc::entropy_upload(h->ent.get(), &h->weight_allocs));
+        h->ent_model_hash = cdc::entropy_model_hash(h->ent.get());
+    }
     return CDC_OK;
 }
 
-// hyper_dec on ONE image (the batch-1 launch program, see the contract in entropy.hip): q_hyper (host) -> device mean / scale
-// (escalate: the encoder may leave CDC_ARITH_F16X2 when hyper_dec overflows its range -- the stream header records the
-// arithmetic that was finally used; the decoder runs what the header says)
-int hyperdec_one(cdc_handle *h, const float *qh_host, int hh, int wh, hipStream_t st, const float **mean, const float **scale,
-                 long long *nl, bool escalate = false) {
-    int rc = build_hyperdec_program(h, 1, hh, wh);
-    if (rc) return rc;
-    const size_t nh = (size_t)h->hyper_dims[0] * hh * wh;
-    HIP_TRY(h, hipMemcpyAsync(h->in_x, qh_host, nh * sizeof(float), hipMemcpyHostToDevice, st));
-    const bool guard = escalate && guard_enabled(h) && !h->in_retry;
+inline uint32_t get_u32(const unsigned char *s) { uint32_t v = 0; for (int i = 0; i < 4; ++i) v |= (uint32_t)s[i] << (8 * i); return v; }
+constexpr int kMaxHyperPositions = 1 << 22;       // hh * wh of a 131072 x 131072 image; bounds every allocation of the decoder
+inline long long section_cap(long long n) { return (2 * n + 256 + 15) & ~15ll; }   // <= 2 renormalisation bytes per symbol + 64 states
+
+// hyper_dec over the batch through the batch-1 launch plan: h->in_x (filled by the caller) -> dec_outs[0] = (mean | scale).
+// *fault: results left the F16X2 range (checked only when `guard`).
+int hyperdec_batch(cdc_handle *h, int B, hipStream_t st, bool guard, int *fault) {
+    int rc;
     if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
     h->prof_now = false;
     for (const Op &op : h->ops)
-        if ((rc = run_op(h, op, 1, st))) return rc;
+        if ((rc = run_op(h, op, B, st))) return rc;
     const Act &o = h->dec_outs[0];
     const long long half = (long long)(o.C / 2) * o.H * o.W;
-    if (guard) {
-        int fault = 0;
-        if ((rc = guard_check(h, {{o.p, o.bs(), 2 * half}}, 1, st, &fault))) return rc;
-        if (fault && guard_escalate(h, &rc)) { RetryScope r(h); return hyperdec_one(h, qh_host, hh, wh, st, mean, scale, nl, false); }
-        if (rc) return rc;
-    }
-    HIP_TRY(h, clamp_min_launch(o.p + half, o.bs(), half, 0.1f, 1, st));       // scale.clamp(min=0.1), compress_modules.py:59
-    *mean = o.p; *scale = o.p + half; *nl = half;
+    *fault = 0;
+    if (guard && (rc = guard_check(h, {{o.p, o.bs(), 2 * half}}, B, st, fault))) return rc;
+    if (!*fault) HIP_TRY(h, clamp_min_launch(o.p + half, o.bs(), half, 0.1f, B, st));   // scale.clamp(min=0.1), compress_modules.py:59
     return CDC_OK;
 }
-}  // namespace
-
-namespace {
-// device scratch of one entropy call, released on every exit path
-struct EntScratch {
-    void *sym = nullptr, *bin = nullptr, *buf = nullptr, *bad = nullptr;
-    ~EntScratch() { for (void *p : {sym, bin, buf, bad}) if (p) (void)hipFree(p); }
-};
-inline void put_u32(unsigned char *o, uint32_t v) { for (int i = 0; i < 4; ++i) o[i] = (unsigned char)(v >> (8 * i)); }
-inline uint32_t get_u32(const unsigned char *s) { uint32_t v = 0; for (int i = 0; i < 4; ++i) v |= (uint32_t)s[i] << (8 * i); return v; }
-constexpr int kMaxHyperPositions = 1 << 22;       // hh * wh of a 131072 x 131072 image; bounds every allocation of the decoder
 
 int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
                         int hh, int wh, unsigned char *out, size_t cap, size_t *offsets, int mem, void *stream) {
@@ -2305,73 +2317,65 @@ int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_l
         (long long)hh * wh > kMaxHyperPositions)
         return fail(h, CDC_ERR_INVALID, "null/invalid argument");
     if ((rc = ensure_entropy(h, medians))) return rc;
-    hipStream_t st = h->own_stream;                       // synchronous entry point: the coder runs on the host
+    hipStream_t st = h->own_stream;                       // synchronous entry point
     if (mem == CDC_MEM_DEVICE) HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
-    const int Ch = h->hyper_dims[0];
-    const size_t nh = (size_t)Ch * hh * wh;
-    const uint32_t model = cdc::entropy_model_hash(h->ent.get());
-    std::vector<float> hl(nh), qh(nh);
-    std::vector<int32_t> sh(nh), sl;
-    std::vector<uint8_t> bins, bytes_h, bytes_l;
-    std::vector<const cdc::EntropyTable *> tabs;
-    EntScratch d;
-    size_t pos = 0;
-    offsets[0] = 0;
-    for (int b = 0; b < B; ++b) {
-        if (mem == CDC_MEM_DEVICE) { HIP_TRY(h, hipMemcpy(hl.data(), hyper_latent + (size_t)b * nh, nh * sizeof(float), hipMemcpyDeviceToHost)); }
-        else memcpy(hl.data(), hyper_latent + (size_t)b * nh, nh * sizeof(float));
-        for (int c = 0; c < Ch; ++c)
-            for (int i = 0; i < hh * wh; ++i) {
-                const size_t k = (size_t)c * hh * wh + i;
-                const float r = rintf(hl[k] - medians[c]);          // quantize(x, "dequantize", medians) (utils.py:72-85)
-                if (!(fabsf(r) < 2.0e9f)) return fail(h, CDC_ERR_INVALID, "image %d: non-finite / out-of-range hyper-latent", b);
-                sh[k] = (int32_t)r;
-                qh[k] = r + medians[c];
-            }
-        const float *dmean, *dscale;
-        long long nl;
-        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl, true))) return rc;
-        if (!d.sym) {
-            HIP_TRY(h, hipMalloc(&d.sym, nl * sizeof(int32_t)));
-            HIP_TRY(h, hipMalloc(&d.bin, nl));
-            HIP_TRY(h, hipMalloc(&d.bad, sizeof(int)));
-            if (mem == CDC_MEM_HOST) HIP_TRY(h, hipMalloc(&d.buf, nl * sizeof(float)));
-        }
-        const float *dl = latent + (size_t)b * nl;
-        if (mem == CDC_MEM_HOST) {
-            HIP_TRY(h, hipMemcpyAsync(d.buf, dl, nl * sizeof(float), hipMemcpyHostToDevice, st));
-            dl = (const float *)d.buf;
-        }
-        HIP_TRY(h, hipMemsetAsync(d.bad, 0, sizeof(int), st));
-        HIP_TRY(h, cdc::latent_symbols_launch(dl, dmean, dscale, h->ent->d_edges, nl, (int32_t *)d.sym, (uint8_t *)d.bin, (int *)d.bad, st));
-        sl.resize(nl); bins.resize(nl);
-        int bad = 0;
-        HIP_TRY(h, hipMemcpyAsync(sl.data(), d.sym, nl * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipMemcpyAsync(bins.data(), d.bin, nl, hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipMemcpyAsync(&bad, d.bad, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
-        if (bad) return fail(h, CDC_ERR_INVALID, "image %d: non-finite latent, mean or scale (nothing to code)", b);
-        tabs.resize(nh);
-        for (int c = 0; c < Ch; ++c)
-            for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
-        cdc::entropy_encode_symbols(sh.data(), nh, tabs, &bytes_h);
-        tabs.resize(nl);
-        for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
-        cdc::entropy_encode_symbols(sl.data(), (size_t)nl, tabs, &bytes_l);
-        const size_t need = kStreamHeader + bytes_h.size() + bytes_l.size();
-        if (pos + need > cap) return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: image %d needs %zu bytes at offset %zu of %zu", b, need, pos, cap);
-        unsigned char *o = out + pos;
-        o[0] = 'C'; o[1] = 'D'; o[2] = 'C'; o[3] = kStreamVersion; o[4] = (unsigned char)h->arith; o[5] = 0;
-        o[6] = (unsigned char)(hh & 255); o[7] = (unsigned char)(hh >> 8); o[8] = (unsigned char)(wh & 255); o[9] = (unsigned char)(wh >> 8);
-        put_u32(o + 10, (uint32_t)bytes_h.size());
-        put_u32(o + 14, (uint32_t)bytes_l.size());
-        put_u32(o + 18, model);
-        put_u32(o + 22, cdc::entropy_symbol_hash(sh.data(), nh, sl.data(), (size_t)nl));
-        memcpy(o + kStreamHeader, bytes_h.data(), bytes_h.size());
-        memcpy(o + kStreamHeader + bytes_h.size(), bytes_l.data(), bytes_l.size());
-        pos += need;
-        offsets[b + 1] = pos;
+    const int Ch = h->hyper_dims[0], per = hh * wh;
+    const long long nh = (long long)Ch * per;
+    if ((rc = build_hyperdec_program(h, B, hh, wh, true))) return rc;
+    const Act &o = h->dec_outs[0];
+    const long long nl = (long long)(o.C / 2) * o.H * o.W;
+    if (nh > (1ll << 30) || nl > (1ll << 30)) return fail(h, CDC_ERR_INVALID, "image too large for one coder section");
+    DevPool d;
+    const float *d_hl = hyper_latent, *d_lat = latent;
+    if (mem != CDC_MEM_DEVICE) {
+        float *a, *b;
+        HIP_TRY(h, d.get(&a, (size_t)B * nh)); HIP_TRY(h, d.get(&b, (size_t)B * nl));
+        HIP_TRY(h, hipMemcpyAsync(a, hyper_latent, (size_t)B * nh * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(b, latent, (size_t)B * nl * sizeof(float), hipMemcpyHostToDevice, st));
+        d_hl = a; d_lat = b;
     }
+    int32_t *symh, *syml;
+    uint8_t *bin, *sec_h, *sec_l, *packed;
+    uint32_t *sf, *ew, *esc_h, *esc_l;
+    int *bad;
+    cdc::RansMeta *meta;
+    long long *d_off;
+    const long long cap_h = section_cap(nh), cap_l = section_cap(nl);
+    const long long pack_cap = (long long)B * (kStreamHeader + cap_h + 4 * nh + cap_l + 4 * nl);
+    HIP_TRY(h, d.get(&symh, (size_t)B * nh)); HIP_TRY(h, d.get(&syml, (size_t)B * nl)); HIP_TRY(h, d.get(&bin, (size_t)B * nl));
+    HIP_TRY(h, d.get(&sf, (size_t)B * std::max(nh, nl))); HIP_TRY(h, d.get(&ew, (size_t)B * std::max(nh, nl)));
+    HIP_TRY(h, d.get(&sec_h, (size_t)B * cap_h)); HIP_TRY(h, d.get(&sec_l, (size_t)B * cap_l));
+    HIP_TRY(h, d.get(&esc_h, (size_t)B * nh)); HIP_TRY(h, d.get(&esc_l, (size_t)B * nl));
+    HIP_TRY(h, d.get(&bad, 1)); HIP_TRY(h, d.get(&meta, 2 * (size_t)B)); HIP_TRY(h, d.get(&d_off, (size_t)B + 1));
+    HIP_TRY(h, hipMemsetAsync(bad, 0, sizeof(int), st));
+    // hyper symbols; their dequantised values are hyper_dec's input (quantize(.., "dequantize", medians), utils.py:72-85)
+    HIP_TRY(h, cdc::hyper_symbols_launch(d_hl, h->ent->d_medians, Ch, per, B, symh, h->in_x, bad, st));
+    int fault = 0;
+    if ((rc = hyperdec_batch(h, B, st, guard_enabled(h) && !h->in_retry, &fault))) return rc;
+    if (fault) {
+        // the encoder may leave CDC_ARITH_F16X2 when hyper_dec overflows its range: the stream header records the arithmetic
+        // that was finally used and the decoder runs what the header says
+        if (guard_escalate(h, &rc)) { RetryScope r(h); return entropy_encode_impl(h, latent, hyper_latent, medians, B, hh, wh, out, cap, offsets, mem, stream); }
+        if (rc) return rc;
+    }
+    HIP_TRY(h, cdc::latent_symbols_launch(d_lat, nl, o.p, o.p + nl, o.bs(), h->ent->d_edges, nl, B, syml, bin, bad, st));
+    const cdc::EntropyDev T = h->ent->dev();
+    HIP_TRY(h, cdc::rans_encode_launch(T, symh, nh, nullptr, 0, per, 0, (int)nh, 0u, B, sf, ew, sec_h, cap_h, esc_h, nh, meta, st));
+    HIP_TRY(h, cdc::rans_encode_launch(T, syml, nl, bin, nl, 0, Ch, (int)nl, 1u, B, sf, ew, sec_l, cap_l, esc_l, nl, meta + B, st));
+    const long long dev_cap = (long long)std::min<unsigned long long>((unsigned long long)cap, (unsigned long long)pack_cap);
+    HIP_TRY(h, d.get(&packed, (size_t)dev_cap));
+    cdc::RansPack P{sec_h, sec_l, esc_h, esc_l, meta, meta + B, cap_h, cap_l, nh, nl, dev_cap, packed, d_off, h->ent_model_hash, h->arith, hh, wh};
+    HIP_TRY(h, cdc::rans_pack_launch(P, B, st));
+    int hbad = 0;
+    std::vector<long long> hoff((size_t)B + 1);
+    HIP_TRY(h, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(hoff.data(), d_off, sizeof(long long) * ((size_t)B + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (hbad) return fail(h, CDC_ERR_INVALID, "non-finite or out-of-range latent, hyper-latent, mean or scale (nothing to code)");
+    if ((unsigned long long)hoff[B] > (unsigned long long)cap)
+        return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: %d image(s) need %lld bytes of %zu", B, hoff[B], cap);
+    HIP_TRY(h, hipMemcpy(out, packed, (size_t)hoff[B], hipMemcpyDeviceToHost));
+    for (int b = 0; b <= B; ++b) offsets[b] = (size_t)hoff[b];
     return CDC_OK;
 }
 
@@ -2385,59 +2389,93 @@ int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *of
     // the outputs may be device buffers that queued work of the caller's stream still uses
     if (mem == CDC_MEM_DEVICE) HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     const int Ch = h->hyper_dims[0];
-    const int arith_in = h->arith;
     // the decoder runs hyper_dec in the encoder's arithmetic (see the contract in entropy.hip); the handle's own mode comes back
-    struct Restore { cdc_handle *h; int a; ~Restore() { if (h->arith != a) (void)cdc_set_arith(h, a); } } restore{h, arith_in};
-    std::vector<int32_t> sh, sl;
-    std::vector<float> qh;
-    std::vector<uint8_t> bins;
-    std::vector<const cdc::EntropyTable *> tabs;
-    EntScratch d;
+    struct Restore { cdc_handle *h; int a; ~Restore() { if (h->arith != a) (void)cdc_set_arith(h, a); } } restore{h, h->arith};
+    // ---- headers: everything that sizes an allocation is validated here ----
+    struct Hdr { int hh, wh, ar; uint32_t nbh, nbl, sum, eh, el; };
+    std::vector<Hdr> hd((size_t)B);
     for (int b = 0; b < B; ++b) {
         if (offsets[b + 1] < offsets[b]) return fail(h, CDC_ERR_INVALID, "image %d: offsets decrease", b);
         const unsigned char *s = in + offsets[b];
         const size_t n = offsets[b + 1] - offsets[b];
-        int hh, wh, ar;
-        if (cdc_entropy_peek(s, n, &hh, &wh, &ar)) return fail(h, CDC_ERR_INVALID, "image %d: not a CDC bitstream (version %d container)", b, kStreamVersion);
-        if (hh < 1 || wh < 1 || (long long)hh * wh > kMaxHyperPositions) return fail(h, CDC_ERR_INVALID, "image %d: implausible hyper-latent size %d x %d", b, hh, wh);
-        if (ar != CDC_ARITH_BF16X3 && ar != CDC_ARITH_F16X2) return fail(h, CDC_ERR_INVALID, "image %d: unknown arithmetic %d", b, ar);
-        const uint32_t nbh = get_u32(s + 10), nbl = get_u32(s + 14);
-        if ((size_t)kStreamHeader + nbh + nbl != n) return fail(h, CDC_ERR_INVALID, "image %d: truncated bitstream", b);
-        if (get_u32(s + 18) != cdc::entropy_model_hash(h->ent.get()))
+        Hdr &q = hd[b];
+        if (cdc_entropy_peek(s, n, &q.hh, &q.wh, &q.ar)) return fail(h, CDC_ERR_INVALID, "image %d: not a CDC bitstream (version %d container)", b, kStreamVersion);
+        if (q.hh < 1 || q.wh < 1 || (long long)q.hh * q.wh > kMaxHyperPositions) return fail(h, CDC_ERR_INVALID, "image %d: implausible hyper-latent size %d x %d", b, q.hh, q.wh);
+        if (q.ar != CDC_ARITH_BF16X3 && q.ar != CDC_ARITH_F16X2) return fail(h, CDC_ERR_INVALID, "image %d: unknown arithmetic %d", b, q.ar);
+        q.nbh = get_u32(s + 10); q.nbl = get_u32(s + 14); q.sum = get_u32(s + 22); q.eh = get_u32(s + 26); q.el = get_u32(s + 30);
+        if ((unsigned long long)kStreamHeader + q.nbh + q.nbl != n) return fail(h, CDC_ERR_INVALID, "image %d: truncated bitstream", b);
+        if (get_u32(s + 18) != h->ent_model_hash)
             return fail(h, CDC_ERR_INVALID, "image %d: the stream was coded with other probability tables (prior parameters, medians, library build or libm differ)", b);
-        if (ar != h->arith && (rc = cdc_set_arith(h, ar))) return rc;
-        const size_t nh = (size_t)Ch * hh * wh;
-        sh.resize(nh); qh.resize(nh); tabs.resize(nh);
-        for (int c = 0; c < Ch; ++c)
-            for (int i = 0; i < hh * wh; ++i) tabs[(size_t)c * hh * wh + i] = &h->ent->hyper[c];
-        if (!cdc::entropy_decode_symbols(s + kStreamHeader, nbh, nh, tabs, sh.data())) return fail(h, CDC_ERR_INVALID, "image %d: corrupt hyper stream", b);
-        for (int c = 0; c < Ch; ++c)
-            for (int i = 0; i < hh * wh; ++i) { const size_t k = (size_t)c * hh * wh + i; qh[k] = (float)sh[k] + medians[c]; }
-        const float *dmean, *dscale;
-        long long nl;
-        if ((rc = hyperdec_one(h, qh.data(), hh, wh, st, &dmean, &dscale, &nl))) return rc;
-        if (!d.sym) {
-            HIP_TRY(h, hipMalloc(&d.sym, nl * sizeof(int32_t)));
-            HIP_TRY(h, hipMalloc(&d.bin, nl));
-            HIP_TRY(h, hipMalloc(&d.buf, nl * sizeof(float)));
+        if (4ull * q.eh + 256 > q.nbh || 4ull * q.el + 256 > q.nbl) return fail(h, CDC_ERR_INVALID, "image %d: corrupt section sizes", b);
+        if (q.hh != hd[0].hh || q.wh != hd[0].wh)
+            return fail(h, CDC_ERR_INVALID, "image %d: %d x %d hyper-latent in a batch of %d x %d (one call decodes one image size)", b, q.hh, q.wh, hd[0].hh, hd[0].wh);
+    }
+    const int hh = hd[0].hh, wh = hd[0].wh, per = hh * wh;
+    const long long nh = (long long)Ch * per;
+    // the whole input goes to the device once (+ slack: nothing reads past the end, but sections are addressed by offset)
+    const size_t total = offsets[B] - offsets[0];
+    DevPool d;
+    uint8_t *d_in;
+    HIP_TRY(h, d.get(&d_in, total + 16));
+    HIP_TRY(h, hipMemcpyAsync(d_in, in + offsets[0], total, hipMemcpyHostToDevice, st));
+    // images that share an arithmetic decode together (normally all of them)
+    for (int b0 = 0; b0 < B;) {
+        int b1 = b0 + 1;
+        while (b1 < B && hd[b1].ar == hd[b0].ar) ++b1;
+        const int nb = b1 - b0;
+        if (hd[b0].ar != h->arith && (rc = cdc_set_arith(h, hd[b0].ar))) return rc;
+        if ((rc = build_hyperdec_program(h, nb, hh, wh, true))) return rc;
+        const Act &o = h->dec_outs[0];
+        const long long nl = (long long)(o.C / 2) * o.H * o.W;
+        std::vector<long long> off(2 * (size_t)nb);
+        std::vector<int> len(2 * (size_t)nb), esc(2 * (size_t)nb);
+        for (int b = b0; b < b1; ++b) {
+            const long long base = (long long)(offsets[b] - offsets[0]) + kStreamHeader;
+            off[b - b0] = base; len[b - b0] = (int)hd[b].nbh; esc[b - b0] = (int)hd[b].eh;
+            off[nb + b - b0] = base + hd[b].nbh; len[nb + b - b0] = (int)hd[b].nbl; esc[nb + b - b0] = (int)hd[b].el;
         }
-        HIP_TRY(h, cdc::latent_symbols_launch(nullptr, dmean, dscale, h->ent->d_edges, nl, nullptr, (uint8_t *)d.bin, nullptr, st));
-        bins.resize(nl); sl.resize(nl); tabs.resize(nl);
-        HIP_TRY(h, hipMemcpyAsync(bins.data(), d.bin, nl, hipMemcpyDeviceToHost, st));
+        long long *d_off;
+        int *d_len, *d_esc;
+        int32_t *symh, *syml;
+        uint8_t *bin;
+        cdc::RansMeta *meta;
+        float *ql = nullptr, *qh = nullptr;
+        HIP_TRY(h, d.get(&d_off, 2 * (size_t)nb)); HIP_TRY(h, d.get(&d_len, 2 * (size_t)nb)); HIP_TRY(h, d.get(&d_esc, 2 * (size_t)nb));
+        HIP_TRY(h, d.get(&symh, (size_t)nb * nh)); HIP_TRY(h, d.get(&syml, (size_t)nb * nl)); HIP_TRY(h, d.get(&bin, (size_t)nb * nl));
+        HIP_TRY(h, d.get(&meta, 2 * (size_t)nb));
+        HIP_TRY(h, hipMemcpyAsync(d_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(d_len, len.data(), sizeof(int) * len.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(d_esc, esc.data(), sizeof(int) * esc.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemsetAsync(meta, 0, sizeof(cdc::RansMeta) * 2 * nb, st));
+        const cdc::EntropyDev T = h->ent->dev();
+        HIP_TRY(h, cdc::rans_decode_launch(T, d_in, d_off, d_len, d_esc, nullptr, 0, per, 0, (int)nh, 0u, nb, symh, nh, meta, st));
+        HIP_TRY(h, cdc::symbols_to_hyper_launch(symh, h->ent->d_medians, Ch, per, nb, h->in_x, st));
+        int fault = 0;
+        if ((rc = hyperdec_batch(h, nb, st, false, &fault))) return rc;
+        HIP_TRY(h, cdc::latent_symbols_launch(nullptr, 0, o.p, o.p + nl, o.bs(), h->ent->d_edges, nl, nb, nullptr, bin, nullptr, st));
+        HIP_TRY(h, cdc::rans_decode_launch(T, d_in, d_off + nb, d_len + nb, d_esc + nb, bin, nl, 0, Ch, (int)nl, 1u, nb, syml, nl, meta + nb, st));
+        std::vector<cdc::RansMeta> hm(2 * (size_t)nb);
+        HIP_TRY(h, hipMemcpyAsync(hm.data(), meta, sizeof(cdc::RansMeta) * hm.size(), hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipStreamSynchronize(st));
-        for (long long i = 0; i < nl; ++i) tabs[i] = &h->ent->gauss[bins[i]];
-        if (!cdc::entropy_decode_symbols(s + kStreamHeader + nbh, nbl, (size_t)nl, tabs, sl.data())) return fail(h, CDC_ERR_INVALID, "image %d: corrupt latent stream", b);
-        if (get_u32(s + 22) != cdc::entropy_symbol_hash(sh.data(), nh, sl.data(), (size_t)nl))
-            return fail(h, CDC_ERR_INVALID, "image %d: symbol checksum mismatch -- this decoder's hyper-decoder output differs from the encoder's "
-                                           "(other library build, launch-plan switches or GPU), or the payload is corrupt", b);
-        HIP_TRY(h, hipMemcpyAsync(d.sym, sl.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(h, cdc::symbols_to_latent_launch((const int32_t *)d.sym, dmean, nl, (float *)d.buf, st));
-        HIP_TRY(h, hipMemcpyAsync(q_latent + (size_t)b * nl, d.buf, nl * sizeof(float),
-                                  mem == CDC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-        if (q_hyper_latent)
-            HIP_TRY(h, hipMemcpyAsync(q_hyper_latent + (size_t)b * nh, qh.data(), nh * sizeof(float),
-                                      mem == CDC_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, st));
+        for (int b = b0; b < b1; ++b) {
+            if (hm[b - b0].bad) return fail(h, CDC_ERR_INVALID, "image %d: corrupt hyper stream", b);
+            if (hm[nb + b - b0].bad)
+                return fail(h, CDC_ERR_INVALID, "image %d: corrupt latent stream (or this decoder's hyper-decoder output differs from the encoder's)", b);
+            if (hm[b - b0].checksum + hm[nb + b - b0].checksum != hd[b].sum)
+                return fail(h, CDC_ERR_INVALID, "image %d: symbol checksum mismatch -- this decoder's hyper-decoder output differs from the encoder's "
+                                               "(other library build, development switches or GPU), or the payload is corrupt", b);
+        }
+        float *dst_l = q_latent + (size_t)b0 * nl, *dst_h = q_hyper_latent ? q_hyper_latent + (size_t)b0 * nh : nullptr;
+        if (mem != CDC_MEM_DEVICE) { HIP_TRY(h, d.get(&ql, (size_t)nb * nl)); }
+        HIP_TRY(h, cdc::symbols_to_latent_launch(syml, o.p, o.bs(), nl, nb, mem == CDC_MEM_DEVICE ? dst_l : ql, st));
+        if (mem != CDC_MEM_DEVICE) HIP_TRY(h, hipMemcpyAsync(dst_l, ql, (size_t)nb * nl * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (dst_h) {
+            (void)qh;
+            HIP_TRY(h, hipMemcpyAsync(dst_h, h->in_x, (size_t)nb * nh * sizeof(float),
+                                      mem == CDC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        }
         HIP_TRY(h, hipStreamSynchronize(st));
+        b0 = b1;
     }
     return CDC_OK;
 }

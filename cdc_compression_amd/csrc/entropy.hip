@@ -9,16 +9,17 @@
 // with a byte-wise range-ANS coder (32-bit state, 16-bit probabilities).  The specification of the integer tables
 // (below) is restated independently by the CPU checker of the test tree; streams must agree byte for byte.
 //
-// Division of labour: everything per-element and data-parallel runs on the GPU (quantisation against the mean, scale ->
-// table index, symbols -> dequantised latent, and of course hyper_dec itself); the probability tables are a few
-// thousand doubles evaluated once per model on the host in float64 with libm (so that encoder and decoder, product
-// and the CPU checker, all hold the SAME integers -- device transcendentals are not bit-reproducible across toolchains); the
-// coder proper is inherently sequential and runs on the host over ~70 k symbols per 256x256 image (< 1 ms).
+// Division of labour: everything per-symbol runs on the GPU -- quantisation against the medians / the mean, scale ->
+// table index, hyper_dec itself, and the coder proper (below: 64 interleaved range-ANS states per section = one wave per
+// section, all 2 B sections of a batch in two launches) -- only the probability tables are evaluated on the host, a few
+// thousand doubles once per model in float64 with libm (so that encoder and decoder, product and the CPU checker, all hold
+// the SAME integers -- device transcendentals are not bit-reproducible across toolchains), and uploaded as integers.
 //
 // CONTRACT (the one real hazard of learned codecs): the decoder must reproduce the encoder's `scale` bit for bit or
-// the table index of a latent may differ and everything after it is garbage.  Both sides therefore run hyper_dec
-// through the SAME launch program -- one image at a time (batch-1 plan, whatever batch the caller passes) in the
-// arithmetic recorded in the stream header -- on integer-valued inputs that the stream reproduces exactly.
+// the table index of a latent may differ and everything after it is garbage.  Both sides therefore run hyper_dec through
+// the SAME launch program -- planned as for ONE image whatever the batch (cdc_api.hip: Builder::planB; the kernels never
+// mix images, so image b of a batch-B run holds the bits of a batch-1 run; tests/test_entropy.py holds that) -- in the
+// arithmetic recorded in the stream header, on integer-valued inputs that the stream reproduces exactly.
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -41,8 +42,7 @@ namespace cdc {
 //   Hyper tables: per channel, support [-K, K] with K the smallest of 8, 16, 32, ... , 1024 whose mass exceeds 1 - 2^-20
 //       (1024 if none); p(k) = |sigmoid(s U) - sigmoid(s L)|, L, U = logits(m + k -/+ 0.5), s = -sign(L + U)
 //       (network_components.py:372-378), logits = the 1-3-3-3-1 softplus / tanh chain of FlexiblePrior.cdf in float64.
-//   Escape payload: w = ((|k| - K - 1) << 1) | (k < 0), written as base-4096 digits, least significant first, each as
-//       one 13-bit uniform symbol (bit 12 = another digit follows).
+//   Escape payload: w = ((|k| - K - 1) << 1) | (k < 0) as one u32 in the section's payload list (forward symbol order).
 constexpr int kPrec = 16;
 constexpr uint32_t kTot = 1u << kPrec;
 constexpr uint32_t kRansL = 1u << 23;
@@ -63,9 +63,6 @@ static void make_freqs(const std::vector<double> &p, EntropyTable *t) {
     }
     t->freq[best] += kTot - sum;
     for (int j = 0; j < n; ++j) t->start[j + 1] = t->start[j] + t->freq[j];
-    t->lut.assign(kTot, 0);
-    for (int j = 0; j < n; ++j)
-        for (uint32_t s = t->start[j]; s < t->start[j + 1]; ++s) t->lut[s] = (uint16_t)j;
 }
 
 void entropy_scale_edges(float *e) {
@@ -139,95 +136,7 @@ void entropy_init(EntropyModel *m) {
     if (m->gauss.empty()) build_gauss(m);
 }
 
-// ---- range-ANS (byte-wise renormalisation, state in [2^23, 2^31)) ----------------------------------------------------
-struct RansEnc {
-    std::vector<uint8_t> buf;     // filled back to front
-    size_t pos;
-    uint32_t x = kRansL;
-    explicit RansEnc(size_t cap) : buf(cap), pos(cap) {}
-    void put(uint32_t start, uint32_t freq) {
-        const uint32_t xmax = ((kRansL >> kPrec) << 8) * freq;
-        while (x >= xmax) {
-            if (pos == 0) { buf.insert(buf.begin(), buf.size(), 0); pos = buf.size() / 2; }
-            buf[--pos] = (uint8_t)(x & 0xff);
-            x >>= 8;
-        }
-        x = ((x / freq) << kPrec) + (x % freq) + start;
-    }
-    void put_bits(uint32_t v, int nbits) { put(v << (kPrec - nbits), 1u << (kPrec - nbits)); }
-};
-
-struct RansDec {
-    const uint8_t *p, *end;
-    uint32_t x = 0;
-    bool bad = false;
-    RansDec(const uint8_t *b, size_t n) : p(b), end(b + n) {
-        for (int i = 0; i < 4; ++i) x = (x << 8) | next();
-    }
-    uint32_t next() { if (p < end) return *p++; bad = true; return 0; }
-    uint32_t peek() const { return x & (kTot - 1); }
-    void advance(uint32_t start, uint32_t freq) {
-        x = freq * (x >> kPrec) + (x & (kTot - 1)) - start;
-        while (x < kRansL) x = (x << 8) | next();
-    }
-    uint32_t get_bits(int nbits) {
-        const uint32_t v = peek() >> (kPrec - nbits);
-        advance(v << (kPrec - nbits), 1u << (kPrec - nbits));
-        return v;
-    }
-};
-
-// symbols are coded in REVERSE by the encoder so that the decoder reads them forward
-static void encode_symbol_rev(RansEnc &e, const EntropyTable &t, int k) {
-    const int K = t.K;
-    if (k >= -K && k <= K) { e.put(t.start[k + K], t.freq[k + K]); return; }
-    // escape: the decoder sees the ESCAPE entry first, then the digits least significant first -> encode in reverse
-    uint32_t w = ((uint32_t)((k < 0 ? -k : k) - K - 1) << 1) | (k < 0 ? 1u : 0u);
-    uint32_t digits[4];
-    int nd = 0;
-    do { digits[nd++] = w & 4095u; w >>= 12; } while (w);
-    for (int d = nd - 1; d >= 0; --d) e.put_bits(digits[d] | (d < nd - 1 ? 4096u : 0u), 13);
-    e.put(t.start[2 * K + 1], t.freq[2 * K + 1]);
-}
-
-static int decode_symbol(RansDec &d, const EntropyTable &t) {
-    const int K = t.K;
-    const uint32_t s = d.peek();
-    const int j = t.lut[s];
-    d.advance(t.start[j], t.freq[j]);
-    if (j <= 2 * K) return j - K;
-    uint32_t w = 0;
-    for (int sh = 0; sh < 36; sh += 12) {             // the encoder writes at most three 12-bit digits (w < 2^32)
-        const uint32_t dg = d.get_bits(13);
-        w |= (dg & 4095u) << sh;                      // (the third digit's upper bits fall off: a corrupt stream, caught below)
-        if (!(dg & 4096u)) break;
-        if (sh == 24) d.bad = true;                   // a fourth continuation digit cannot come from the encoder
-    }
-    const int mag = (int)(w >> 1) + K + 1;
-    return (w & 1u) ? -mag : mag;
-}
-
-// tables[i] selects the table of symbol i (per-channel for the hyper symbols, per-scale-bin for the latents)
-void entropy_encode_symbols(const int32_t *sym, size_t n, const std::vector<const EntropyTable *> &tables, std::vector<uint8_t> *out) {
-    RansEnc e(n / 2 + 64);
-    for (size_t i = n; i-- > 0;) encode_symbol_rev(e, *tables[i], sym[i]);
-    // final state, most significant byte first in the stream
-    for (int i = 0; i < 4; ++i) {
-        if (e.pos == 0) { e.buf.insert(e.buf.begin(), e.buf.size(), 0); e.pos = e.buf.size() / 2; }
-        e.buf[--e.pos] = (uint8_t)(e.x & 0xff);
-        e.x >>= 8;
-    }
-    out->assign(e.buf.begin() + e.pos, e.buf.end());
-}
-
-bool entropy_decode_symbols(const uint8_t *in, size_t nbytes, size_t n, const std::vector<const EntropyTable *> &tables, int32_t *sym) {
-    if (nbytes < 4) return false;
-    RansDec d(in, nbytes);
-    for (size_t i = 0; i < n && !d.bad; ++i) sym[i] = decode_symbol(d, *tables[i]);     // stop at the first read past the end
-    return !d.bad;
-}
-
-// ---- fingerprints carried by the stream header (include/cdc_hip.h): FNV-1a, 32 bit --------------------------------------
+// ---- fingerprint of the tables carried by the stream header (include/cdc_hip.h): FNV-1a, 32 bit ---------------------------
 static inline uint32_t fnv_u32(uint32_t h, uint32_t v) {
     for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
     return h;
@@ -242,11 +151,36 @@ uint32_t entropy_model_hash(const EntropyModel *m) {
         }
     return h;
 }
-uint32_t entropy_symbol_hash(const int32_t *a, size_t na, const int32_t *b, size_t nb) {
-    uint32_t h = 2166136261u;
-    for (size_t i = 0; i < na; ++i) h = fnv_u32(h, (uint32_t)a[i]);
-    for (size_t i = 0; i < nb; ++i) h = fnv_u32(h, (uint32_t)b[i]);
-    return h;
+
+hipError_t entropy_upload(EntropyModel *m, std::vector<void *> *allocs) {
+    std::vector<uint32_t> cum;
+    std::vector<int> off, K;
+    for (const std::vector<EntropyTable> *v : {&m->hyper, &m->gauss})
+        for (const EntropyTable &t : *v) {
+            off.push_back((int)cum.size());
+            K.push_back(t.K);
+            cum.insert(cum.end(), t.start.begin(), t.start.end());
+        }
+    auto drop = [&](void *p) {
+        if (!p) return;
+        (void)hipFree(p);
+        allocs->erase(std::remove(allocs->begin(), allocs->end(), p), allocs->end());
+    };
+    drop(m->d_cum); drop(m->d_off); drop(m->d_K); drop(m->d_medians);
+    m->d_cum = nullptr; m->d_off = nullptr; m->d_K = nullptr; m->d_medians = nullptr;
+    auto up = [&](const void *src, size_t bytes, void **dst) {
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        allocs->push_back(*dst);
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e;
+    if ((e = up(cum.data(), cum.size() * 4, (void **)&m->d_cum)) != hipSuccess) return e;
+    if ((e = up(off.data(), off.size() * 4, (void **)&m->d_off)) != hipSuccess) return e;
+    if ((e = up(K.data(), K.size() * 4, (void **)&m->d_K)) != hipSuccess) return e;
+    if ((e = up(m->medians.data(), m->medians.size() * 4, (void **)&m->d_medians)) != hipSuccess) return e;
+    m->dev_stale = false;
+    return hipSuccess;
 }
 
 // ---- device side: the per-element work ---------------------------------------------------------------------------------
@@ -260,33 +194,298 @@ __device__ __forceinline__ int scale_bin(const float *edges, float s) {
 }
 
 // *bad is set when a value cannot be coded: a non-finite latent / mean / scale, or a symbol beyond the int32 range
-__global__ void __launch_bounds__(256) latent_symbols_kernel(const float *latent, const float *mean, const float *scale,
-                                                             const float *edges, long long n, int32_t *sym, uint8_t *bin, int *bad) {
+__global__ void __launch_bounds__(256) latent_symbols_kernel(const float *latent, long long latent_bs, const float *mean, const float *scale,
+                                                             long long ms_bs, const float *edges, long long n, int32_t *sym, uint8_t *bin, int *bad) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    bool ok = isfinite(scale[i]) && isfinite(mean[i]);
+    const long long b = blockIdx.y;
+    const float m = mean[b * ms_bs + i], s = scale[b * ms_bs + i];
+    bool ok = isfinite(s) && isfinite(m);
     if (latent) {
-        const float r = rintf(latent[i] - mean[i]);                  // quantize(x, "dequantize", mean) - mean (utils.py:72-85)
+        const float r = rintf(latent[b * latent_bs + i] - m);        // quantize(x, "dequantize", mean) - mean (utils.py:72-85)
         ok = ok && isfinite(r) && fabsf(r) < 2.0e9f;
-        sym[i] = ok ? (int32_t)r : 0;
+        sym[b * n + i] = ok ? (int32_t)r : 0;
     }
-    bin[i] = (uint8_t)scale_bin(edges, ok ? scale[i] : 1.0f);
+    bin[b * n + i] = (uint8_t)scale_bin(edges, ok ? s : 1.0f);
     if (!ok && bad) atomicOr(bad, 1);
 }
 
-__global__ void __launch_bounds__(256) symbols_to_latent_kernel(const int32_t *sym, const float *mean, long long n, float *q) {
+__global__ void __launch_bounds__(256) symbols_to_latent_kernel(const int32_t *sym, const float *mean, long long mean_bs, long long n, float *q) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) q[i] = (float)sym[i] + mean[i];
+    const long long b = blockIdx.y;
+    if (i < n) q[b * n + i] = (float)sym[b * n + i] + mean[b * mean_bs + i];
 }
 
-hipError_t latent_symbols_launch(const float *latent, const float *mean, const float *scale, const float *edges, long long n,
-                                 int32_t *sym, uint8_t *bin, int *bad, hipStream_t st) {
-    hipLaunchKernelGGL(latent_symbols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latent, mean, scale, edges, n, sym, bin, bad);
+// quantize(hyper_latent, "dequantize", medians) (utils.py:72-85): symbol = round(x - median[c]), value = symbol + median[c]
+__global__ void __launch_bounds__(256) hyper_symbols_kernel(const float *hyper, const float *medians, int per, long long n, int32_t *sym,
+                                                            float *q, int *bad) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long k = (long long)blockIdx.y * n + i;
+    const float med = medians[i / per];
+    if (hyper) {
+        const float r = rintf(hyper[k] - med);
+        const bool ok = isfinite(r) && fabsf(r) < 2.0e9f;
+        sym[k] = ok ? (int32_t)r : 0;
+        q[k] = r + med;
+        if (!ok) atomicOr(bad, 1);
+    } else {
+        q[k] = (float)sym[k] + med;
+    }
+}
+
+hipError_t latent_symbols_launch(const float *latent, long long latent_bs, const float *mean, const float *scale, long long ms_bs,
+                                 const float *edges, long long n, int B, int32_t *sym, uint8_t *bin, int *bad, hipStream_t st) {
+    hipLaunchKernelGGL(latent_symbols_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, latent, latent_bs, mean, scale,
+                       ms_bs, edges, n, sym, bin, bad);
     return hipGetLastError();
 }
 
-hipError_t symbols_to_latent_launch(const int32_t *sym, const float *mean, long long n, float *q, hipStream_t st) {
-    hipLaunchKernelGGL(symbols_to_latent_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sym, mean, n, q);
+hipError_t symbols_to_latent_launch(const int32_t *sym, const float *mean, long long mean_bs, long long n, int B, float *q, hipStream_t st) {
+    hipLaunchKernelGGL(symbols_to_latent_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, sym, mean, mean_bs, n, q);
+    return hipGetLastError();
+}
+
+hipError_t hyper_symbols_launch(const float *hyper, const float *medians, int C, int per, int B, int32_t *sym, float *q, int *bad, hipStream_t st) {
+    const long long n = (long long)C * per;
+    hipLaunchKernelGGL(hyper_symbols_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, hyper, medians, per, n, sym, q, bad);
+    return hipGetLastError();
+}
+
+hipError_t symbols_to_hyper_launch(const int32_t *sym, const float *medians, int C, int per, int B, float *q, hipStream_t st) {
+    const long long n = (long long)C * per;
+    hipLaunchKernelGGL(hyper_symbols_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, (const float *)nullptr, medians, per,
+                       n, const_cast<int32_t *>(sym), q, (int *)nullptr);
+    return hipGetLastError();
+}
+
+// ---- the coder: 64-lane interleaved range-ANS ---------------------------------------------------------------------------------
+// A section codes symbols i = 0 .. N-1; symbol i belongs to lane i % 64, which owns a 32-bit state in [2^23, 2^31) with
+// byte-wise renormalisation.  The byte stream is shared: in decoding order (iteration j = i / 64 ascending) the lanes that
+// must refill take their bytes in lane order, so that one wave decodes a section with a ballot + popcount per iteration
+// and a CPU checker decodes it with one loop over i.  Section layout:
+//     64 x u32 LE final encoder states (lane 0 first) | renormalisation bytes | escape payloads (u32 LE, forward order)
+// The encoder walks the iterations backwards (states start at 2^23) and fills its buffer from the end; a second,
+// fully parallel kernel looks the (start, frequency) pairs up beforehand so that the serial wave only divides and stores.
+// After the last symbol every decoder lane must be back at 2^23 with every byte and payload consumed.
+__device__ __forceinline__ uint32_t sym_mix(uint32_t sect, uint32_t i, int32_t k) {     // include/cdc_hip.h: symbol checksum
+    uint32_t v = (i + 1u) * 0x9E3779B1u + sect * 0x7F4A7C15u;
+    v ^= (uint32_t)k * 0x85EBCA77u;
+    v ^= v >> 15; v *= 0x2C1B3C6Du; v ^= v >> 12; v *= 0x297A2D39u; v ^= v >> 15;
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// (start | freq << 16) and the escape payload of every symbol, plus the section's checksum (atomicAdd: commutative)
+__global__ void __launch_bounds__(256) rans_prepare_kernel(EntropyDev T, const int32_t *sym, long long sym_bs, const uint8_t *bin, long long bin_bs,
+                                                           int per, int tab0, int N, uint32_t sect, uint32_t *sf, uint32_t *ew, RansMeta *meta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const long long b = blockIdx.y;
+    uint32_t mix = 0;
+    if (i < N) {
+        const int k = sym[b * sym_bs + i];
+        const int t = tab0 + (per ? i / per : (int)bin[b * bin_bs + i]);
+        const int K = T.K[t];
+        const uint32_t *c = T.cum + T.off[t];
+        const bool in = k >= -K && k <= K;
+        const int en = in ? k + K : 2 * K + 1;
+        const uint32_t st = c[en], f = c[en + 1] - st;
+        sf[b * N + i] = st | (f << 16);                       // f <= 65535: every table has >= 2 entries of frequency >= 1
+        const long long mag = k < 0 ? -(long long)k : (long long)k;
+        ew[b * N + i] = in ? 0u : ((uint32_t)(mag - K - 1) << 1) | (k < 0 ? 1u : 0u);
+        mix = sym_mix(sect, (uint32_t)i, k);
+    }
+    mix = wave_sum(mix);
+    if ((threadIdx.x & 63) == 0 && mix) atomicAdd(&meta[b].checksum, mix);
+}
+
+__global__ void __launch_bounds__(64) rans_encode_kernel(const uint32_t *sf, const uint32_t *ew, int N, uint8_t *out, long long out_bs,
+                                                         uint32_t *esc, long long esc_bs, RansMeta *meta) {
+    const int lane = threadIdx.x;
+    const long long b = blockIdx.x;
+    sf += b * N; ew += b * N;
+    uint8_t *o = out + b * out_bs;
+    uint32_t *eo = esc + b * esc_bs;
+    const uint64_t above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull), below = (1ull << lane) - 1ull;
+    uint32_t x = 1u << 23;
+    long long pos = out_bs, epos = esc_bs;
+    const int nit = (N + 63) / 64;
+    constexpr int U = 8;                                      // iterations whose table entries are fetched together
+    for (int jc = nit; jc > 0; jc -= U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jc - 1 - u;
+            const long long i = (long long)j * 64 + lane;
+            v[u] = (j >= 0 && i < N) ? sf[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jc - 1 - u;
+            if (j < 0) break;
+            const long long i = (long long)j * 64 + lane;
+            const bool act = v[u] != 0u;                      // (freq >= 1 for every coded symbol)
+            const uint32_t st = v[u] & 0xffffu, f = act ? v[u] >> 16 : 1u;
+            const uint32_t xmax = f << 15;                    // ((2^23 >> 16) << 8) * f
+            uint32_t xx = x, b0 = 0, b1 = 0;
+            int nb = 0;
+            if (act && xx >= xmax) { b0 = xx & 255u; xx >>= 8; nb = 1; if (xx >= xmax) { b1 = xx & 255u; xx >>= 8; nb = 2; } }
+            const uint64_t m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
+            const long long endp = pos - (__popcll(m1 & above) + __popcll(m2 & above));   // lane 63 is coded first = highest addresses
+            if (nb >= 1) o[endp - 1] = (uint8_t)b0;
+            if (nb == 2) o[endp - 2] = (uint8_t)b1;
+            pos -= __popcll(m1) + __popcll(m2);
+            if (act) x = ((xx / f) << 16) + (xx % f) + st;
+            const bool isesc = act && st + f == 65536u;       // the escape symbol is the last entry of its table
+            const uint64_t me = __ballot(isesc);
+            if (me) {
+                const int ne = __popcll(me);
+                if (isesc) eo[epos - ne + __popcll(me & below)] = ew[i];
+                epos -= ne;
+            }
+        }
+    }
+    pos -= 256;
+    for (int k = 0; k < 4; ++k) o[pos + 4 * lane + k] = (uint8_t)(x >> (8 * k));
+    if (lane == 0) { meta[b].start = (int)pos; meta[b].esc_start = (int)epos; }
+}
+
+__global__ void __launch_bounds__(64) rans_decode_kernel(EntropyDev T, const uint8_t *in, const long long *in_off, const int *in_len, const int *in_esc,
+                                                         const uint8_t *bin, long long bin_bs, int per, int tab0, int N, uint32_t sect,
+                                                         int32_t *sym, long long sym_bs, RansMeta *meta) {
+    const int lane = threadIdx.x;
+    const long long b = blockIdx.x;
+    const uint8_t *s = in + in_off[b];
+    const long long nbytes = in_len[b], ne = (uint32_t)in_esc[b];
+    if (nbytes < 256 + 4 * ne) { if (lane == 0) { meta[b].bad = 1; meta[b].checksum = 0; } return; }
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t x = (uint32_t)s[4 * lane] | ((uint32_t)s[4 * lane + 1] << 8) | ((uint32_t)s[4 * lane + 2] << 16) | ((uint32_t)s[4 * lane + 3] << 24);
+    long long p = 256, eidx = 0;
+    const long long end = nbytes - 4 * ne;
+    const uint8_t *ep = s + end;
+    bin += b * bin_bs; sym += b * sym_bs;
+    bool bad = false;
+    uint32_t csum = 0;
+    const int nit = (N + 63) / 64;
+    constexpr int U = 4;                                      // iterations whose table descriptors are fetched together
+    for (int j0 = 0; j0 < nit && !bad; j0 += U) {
+        int tK[U], tO[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = (long long)(j0 + u) * 64 + lane;
+            const bool act = i < N;
+            const int t = tab0 + (act ? (per ? (int)(i / per) : (int)bin[i]) : 0);
+            tK[u] = act ? T.K[t] : -1;
+            tO[u] = T.off[t];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = (long long)(j0 + u) * 64 + lane;
+            if (j0 + u >= nit) break;
+            const bool act = tK[u] >= 0;
+            const int K = tK[u];
+            const uint32_t *c = T.cum + tO[u];
+            const uint32_t slot = x & 0xffffu;
+            int lo = 0, hi = act ? 2 * K + 1 : 0;               // largest entry with c[entry] <= slot
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c[mid] <= slot) lo = mid; else hi = mid - 1; }
+            uint32_t xn = x;
+            int need = 0;
+            if (act) {
+                const uint32_t st = c[lo], f = c[lo + 1] - st;
+                xn = f * (x >> 16) + slot - st;
+                need = xn < (1u << 15) ? 2 : (xn < (1u << 23) ? 1 : 0);
+            }
+            const uint64_t m1 = __ballot(need >= 1), m2 = __ballot(need == 2);
+            const long long q = p + __popcll(m1 & below) + __popcll(m2 & below);
+            bool lb = q + need > end;
+            if (!lb && need >= 1) xn = (xn << 8) | s[q];
+            if (!lb && need == 2) xn = (xn << 8) | s[q + 1];
+            p += __popcll(m1) + __popcll(m2);
+            x = xn;
+            const bool isesc = act && lo == 2 * K + 1;
+            const uint64_t me = __ballot(isesc);
+            int k = lo - K;
+            if (me) {
+                const long long e = eidx + __popcll(me & below);
+                if (isesc) {
+                    if (e >= ne) lb = true;
+                    else {
+                        const uint8_t *w8 = ep + 4 * e;
+                        const uint32_t w = (uint32_t)w8[0] | ((uint32_t)w8[1] << 8) | ((uint32_t)w8[2] << 16) | ((uint32_t)w8[3] << 24);
+                        const long long mag = (long long)(w >> 1) + K + 1;
+                        k = (int32_t)((w & 1u) ? -mag : mag);
+                    }
+                }
+                eidx += __popcll(me);
+            }
+            if (act && !lb) { sym[i] = k; csum += sym_mix(sect, (uint32_t)i, k); }
+            if (__ballot(lb)) { bad = true; break; }
+        }
+    }
+    if (!bad) bad = p != end || eidx != ne || __ballot(x != (1u << 23)) != 0;
+    csum = wave_sum(csum);
+    if (lane == 0) { meta[b].bad = bad ? 1 : 0; meta[b].checksum = csum; }
+}
+
+hipError_t rans_encode_launch(EntropyDev T, const int32_t *sym, long long sym_bs, const uint8_t *bin, long long bin_bs, int per, int tab0,
+                              int N, uint32_t sect, int B, uint32_t *sf, uint32_t *ew, uint8_t *out, long long out_bs, uint32_t *esc,
+                              long long esc_bs, RansMeta *meta, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(meta, 0, sizeof(RansMeta) * B, st);
+    if (e != hipSuccess) return e;
+    if (N > 0)
+        hipLaunchKernelGGL(rans_prepare_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st, T, sym, sym_bs, bin, bin_bs, per,
+                           tab0, N, sect, sf, ew, meta);
+    hipLaunchKernelGGL(rans_encode_kernel, dim3((unsigned)B), dim3(64), 0, st, sf, ew, N, out, out_bs, esc, esc_bs, meta);
+    return hipGetLastError();
+}
+
+hipError_t rans_decode_launch(EntropyDev T, const uint8_t *in, const long long *in_off, const int *in_len, const int *in_esc,
+                              const uint8_t *bin, long long bin_bs, int per, int tab0, int N, uint32_t sect, int B, int32_t *sym,
+                              long long sym_bs, RansMeta *meta, hipStream_t st) {
+    hipLaunchKernelGGL(rans_decode_kernel, dim3((unsigned)B), dim3(64), 0, st, T, in, in_off, in_len, in_esc, bin, bin_bs, per, tab0, N, sect, sym,
+                       sym_bs, meta);
+    return hipGetLastError();
+}
+
+// B streams in their final layout (include/cdc_hip.h, version 3), packed back to back: one workgroup per image
+__global__ void __launch_bounds__(256) rans_pack_kernel(RansPack P) {
+    const int b = blockIdx.x;
+    auto sizes = [&](int i, uint32_t *nh, uint32_t *nl, uint32_t *eh, uint32_t *el) {
+        *eh = (uint32_t)(P.esc_bs_h - P.meta_h[i].esc_start); *el = (uint32_t)(P.esc_bs_l - P.meta_l[i].esc_start);
+        *nh = (uint32_t)(P.out_bs_h - P.meta_h[i].start) + 4u * *eh; *nl = (uint32_t)(P.out_bs_l - P.meta_l[i].start) + 4u * *el;
+    };
+    uint32_t nh, nl, eh, el;
+    long long off = 0;
+    for (int i = 0; i < b; ++i) { sizes(i, &nh, &nl, &eh, &el); off += 34 + (long long)nh + nl; }
+    sizes(b, &nh, &nl, &eh, &el);
+    if (threadIdx.x == 0) {
+        P.offsets[b] = off;
+        if (b == (int)gridDim.x - 1) P.offsets[b + 1] = off + 34 + (long long)nh + nl;
+    }
+    if (off + 34 + (long long)nh + nl > P.cap) return;          // the host sees the total in offsets[B] and reports it
+    uint8_t *o = P.out + off;
+    if (threadIdx.x == 0) {
+        const uint32_t w[6] = {nh, nl, P.model, P.meta_h[b].checksum + P.meta_l[b].checksum, eh, el};
+        o[0] = 'C'; o[1] = 'D'; o[2] = 'C'; o[3] = 3; o[4] = (uint8_t)P.arith; o[5] = 0;
+        o[6] = (uint8_t)(P.hh & 255); o[7] = (uint8_t)(P.hh >> 8); o[8] = (uint8_t)(P.wh & 255); o[9] = (uint8_t)(P.wh >> 8);
+        for (int k = 0; k < 6; ++k) for (int q = 0; q < 4; ++q) o[10 + 4 * k + q] = (uint8_t)(w[k] >> (8 * q));
+    }
+    o += 34;
+    const uint8_t *sh = P.sec_h + (long long)b * P.out_bs_h + P.meta_h[b].start, *sl = P.sec_l + (long long)b * P.out_bs_l + P.meta_l[b].start;
+    const uint32_t *xh = P.esc_h + (long long)b * P.esc_bs_h + P.meta_h[b].esc_start, *xl = P.esc_l + (long long)b * P.esc_bs_l + P.meta_l[b].esc_start;
+    const uint32_t bh = nh - 4u * eh, bl = nl - 4u * el;
+    for (uint32_t i = threadIdx.x; i < bh; i += 256) o[i] = sh[i];
+    for (uint32_t i = threadIdx.x; i < 4u * eh; i += 256) o[bh + i] = (uint8_t)(xh[i >> 2] >> (8 * (i & 3)));
+    o += nh;
+    for (uint32_t i = threadIdx.x; i < bl; i += 256) o[i] = sl[i];
+    for (uint32_t i = threadIdx.x; i < 4u * el; i += 256) o[bl + i] = (uint8_t)(xl[i >> 2] >> (8 * (i & 3)));
+}
+
+hipError_t rans_pack_launch(const RansPack &P, int B, hipStream_t st) {
+    hipLaunchKernelGGL(rans_pack_kernel, dim3((unsigned)B), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 

@@ -241,22 +241,31 @@ int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, c
  * Codes exactly the symbols Compressor.bpp prices (compress_modules.py:76-90) with exactly its two models:
  *   q_hyper_latent - medians   under FlexiblePrior.likelihood (network_components.py:372-378), one table per channel;
  *   q_latent - mean            under NormalDistribution(mean, scale).likelihood (utils.py:147-159), tables by scale,
- * byte-wise range-ANS, 16-bit probabilities (table specification: csrc/entropy.hip; restated in oracle/entropy_oracle.c,
- * streams agree byte for byte).  Entry points of a hyper-decoder handle (cdc_hyperdec_create) that has the prior.* tensors.
+ * 64-lane interleaved byte-wise range-ANS, 16-bit probabilities, coded and decoded ON THE GPU -- one wave per section, the
+ * 2 B sections of a batch in two launches (format and table specification: csrc/entropy.hip; restated in
+ * oracle/entropy_oracle.c and, as a second structurally different decoder, in tests/test_entropy.py; streams agree byte for
+ * byte).  Entry points of a hyper-decoder handle (cdc_hyperdec_create) that has the prior.* tensors.
  * latent / hyper_latent are the UNquantised encoder outputs (cdc_encoder_encode); medians [dims[0]] is a host array.
  * out receives B concatenated streams, image b at [offsets[b], offsets[b+1]) (offsets has B+1 entries).  Each stream:
- *   'C' 'D' 'C' 2 | arith u8 | 0 | h_hyper u16 | w_hyper u16 | n_hyper u32 | n_latent u32 | model u32 | symbols u32 |
- *   hyper bytes | latent bytes                                                        (version 2, 26-byte header).
+ *   'C' 'D' 'C' 3 | arith u8 | 0 | h_hyper u16 | w_hyper u16 | n_hyper u32 | n_latent u32 | model u32 | symbols u32 |
+ *   esc_hyper u32 | esc_latent u32 | hyper section | latent section                   (version 3, 34-byte header, little endian)
+ * section = 64 x u32 final lane states | renormalisation bytes | escape payloads (u32 each, symbol order); n_* = section bytes.
  * model   = FNV-1a over every integer of the probability tables (per table K, then its 2K+2 frequencies; the per-channel
  *           hyper tables, then the 128 scale tables): a decoder whose tables differ (other prior.* parameters or medians,
  *           another build, another libm) refuses the stream instead of decoding garbage;
- * symbols = FNV-1a over the int32 symbols (hyper, then latent): the decoder checks it after decoding.
- * Encoder and decoder run hyper_dec one image at a time (batch-1 launch plan) in the arithmetic the header records, so
- * that the decoder reproduces the encoder's scale bins bit for bit -- the contract every learned codec has.  LIMITS: same
- * library build, same launch-plan switches (the CDC_* development variables), same GPU architecture on both sides; a
- * decoder whose hyper_dec output lands in other scale bins decodes other symbols and fails the `symbols` check loudly.
+ * symbols = sum over both sections of mix(section, index, symbol) mod 2^32 (csrc/entropy.hip: sym_mix; order-independent,
+ *           so the lanes accumulate it in parallel): the decoder checks it after decoding.  The coder's own end
+ *           conditions (every lane back at 2^23, every byte and payload consumed) catch most corruption before that.
+ * Encoder and decoder run hyper_dec for the whole batch through the launch plan of ONE image (no kernel mixes images,
+ * so image b of a batch holds the bits of a batch-1 call; a batch encode returns the batch-1 streams byte for byte) in
+ * the arithmetic the header records, so that the decoder reproduces the encoder's scale bins bit for bit -- the contract
+ * every learned codec has.  One cdc_entropy_decode call takes streams of one image size; their arithmetics may differ.
+ * LIMITS: same library build and same GPU architecture on both sides (the CDC_* development switches, honoured only under
+ * CDC_DEV=1, change launch plans and void this); a decoder whose hyper_dec output lands in other scale bins decodes other
+ * symbols and fails the end conditions or the `symbols` check loudly.
  * cdc_entropy_decode leaves the handle's own arithmetic as it found it.  hh, wh >= 1 and hh * wh <= 2^22 are enforced
- * before anything is sized by them; no C++ exception crosses this boundary (CDC_ERR_NOMEM / CDC_ERR_INVALID instead).
+ * before anything is sized by them; section sizes and escape counts are checked against the stream length; no C++ exception
+ * crosses this boundary (CDC_ERR_NOMEM / CDC_ERR_INVALID instead).
  * cdc_entropy_encode refuses non-finite latents / means / scales (CDC_ERR_INVALID).
  * Synchronous; latent / hyper_latent / q_latent / q_hyper_latent follow `mem`, in / out / offsets / medians are host. */
 int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,

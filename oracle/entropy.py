@@ -19,12 +19,13 @@ def lib():
         L = ctypes.CDLL(os.path.join(_HERE, "libcdc_entropy_oracle.so"))
         vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
         L.orc_entropy_edges.argtypes = [vp]
-        L.orc_entropy_encode_hyper.argtypes = [vp, i, i, vp, vp, vp, sz]
+        u32 = ctypes.c_uint32
+        L.orc_entropy_encode_hyper.argtypes = [vp, i, i, vp, vp, vp, sz, ctypes.POINTER(u32)]
         L.orc_entropy_encode_hyper.restype = sz
-        L.orc_entropy_decode_hyper.argtypes = [vp, sz, i, i, vp, vp, vp]
-        L.orc_entropy_encode_latent.argtypes = [vp, vp, ctypes.c_longlong, vp, sz]
+        L.orc_entropy_decode_hyper.argtypes = [vp, sz, u32, i, i, vp, vp, vp]
+        L.orc_entropy_encode_latent.argtypes = [vp, vp, ctypes.c_longlong, vp, sz, ctypes.POINTER(u32)]
         L.orc_entropy_encode_latent.restype = sz
-        L.orc_entropy_decode_latent.argtypes = [vp, sz, vp, ctypes.c_longlong, vp]
+        L.orc_entropy_decode_latent.argtypes = [vp, sz, u32, vp, ctypes.c_longlong, vp]
         L.orc_entropy_ideal_bits_latent.argtypes = [vp, vp, ctypes.c_longlong]
         L.orc_entropy_ideal_bits_latent.restype = ctypes.c_double
         L.orc_entropy_model_hash.argtypes = [i, vp, vp]
@@ -59,22 +60,23 @@ def edges():
 
 
 def encode_hyper(sym, prior44, medians):
-    """sym [C, h, w] int32 -> bytes."""
+    """sym [C, h, w] int32 -> (section bytes, number of escape payloads) in the 64-lane interleaved format."""
     sym = np.ascontiguousarray(sym, np.int32)
     C, per = sym.shape[0], int(np.prod(sym.shape[1:]))
-    cap = 64 + 8 * sym.size
+    cap = 512 + 8 * sym.size
     out = np.zeros(cap, np.uint8)
+    ne = ctypes.c_uint32(0)
     p, m = np.ascontiguousarray(prior44, np.float32), np.ascontiguousarray(medians, np.float32).reshape(-1)
-    n = lib().orc_entropy_encode_hyper(sym.ctypes.data, C, per, p.ctypes.data, m.ctypes.data, out.ctypes.data, cap)
+    n = lib().orc_entropy_encode_hyper(sym.ctypes.data, C, per, p.ctypes.data, m.ctypes.data, out.ctypes.data, cap, ctypes.byref(ne))
     assert n > 0
-    return out[:n].tobytes()
+    return out[:n].tobytes(), int(ne.value)
 
 
-def decode_hyper(data, C, per, prior44, medians):
+def decode_hyper(data, n_esc, C, per, prior44, medians):
     buf = np.frombuffer(data, np.uint8).copy()
     sym = np.zeros(C * per, np.int32)
     p, m = np.ascontiguousarray(prior44, np.float32), np.ascontiguousarray(medians, np.float32).reshape(-1)
-    bad = lib().orc_entropy_decode_hyper(buf.ctypes.data, buf.size, C, per, p.ctypes.data, m.ctypes.data, sym.ctypes.data)
+    bad = lib().orc_entropy_decode_hyper(buf.ctypes.data, buf.size, n_esc, C, per, p.ctypes.data, m.ctypes.data, sym.ctypes.data)
     assert not bad
     return sym
 
@@ -82,20 +84,23 @@ def decode_hyper(data, C, per, prior44, medians):
 def encode_latent(sym, scale):
     sym = np.ascontiguousarray(sym, np.int32).reshape(-1)
     scale = np.ascontiguousarray(scale, np.float32).reshape(-1)
-    cap = 64 + 8 * sym.size
+    cap = 512 + 8 * sym.size
     out = np.zeros(cap, np.uint8)
-    n = lib().orc_entropy_encode_latent(sym.ctypes.data, scale.ctypes.data, sym.size, out.ctypes.data, cap)
+    ne = ctypes.c_uint32(0)
+    n = lib().orc_entropy_encode_latent(sym.ctypes.data, scale.ctypes.data, sym.size, out.ctypes.data, cap, ctypes.byref(ne))
     assert n > 0
-    return out[:n].tobytes()
+    return out[:n].tobytes(), int(ne.value)
 
 
-def decode_latent(data, scale):
+def decode_latent(data, n_esc, scale, check=True):
     buf = np.frombuffer(data, np.uint8).copy()
     scale = np.ascontiguousarray(scale, np.float32).reshape(-1)
     sym = np.zeros(scale.size, np.int32)
-    bad = lib().orc_entropy_decode_latent(buf.ctypes.data, buf.size, scale.ctypes.data, scale.size, sym.ctypes.data)
-    assert not bad
-    return sym
+    bad = lib().orc_entropy_decode_latent(buf.ctypes.data, buf.size, n_esc, scale.ctypes.data, scale.size, sym.ctypes.data)
+    if check:
+        assert not bad
+        return sym
+    return sym, bool(bad)
 
 
 def ideal_bits_latent(sym, scale):
@@ -122,11 +127,13 @@ def gauss_table(bin_index):
     return K, f[:2 * K + 2].copy()
 
 
-HEADER = 26
+HEADER = 34
 
 
-def stream(arith, hh, wh, hyper_bytes, latent_bytes, model, symbols):
-    """The version-2 container of include/cdc_hip.h: 'CDC' 2 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 |
-    model hash u32 | symbol hash u32 | payloads."""
+def stream(arith, hh, wh, hyper, latent, model, symbols):
+    """The version-3 container of include/cdc_hip.h: 'CDC' 3 | arith | 0 | hh u16 | wh u16 | n_hyper u32 | n_latent u32 |
+    model hash u32 | symbol checksum u32 | hyper escapes u32 | latent escapes u32 | hyper section | latent section.
+    hyper / latent = (section bytes, escape count) as returned by encode_hyper / encode_latent."""
     import struct
-    return b"CDC\x02" + struct.pack("<BBHHIIII", arith, 0, hh, wh, len(hyper_bytes), len(latent_bytes), model, symbols) + hyper_bytes + latent_bytes
+    (hb, he), (lb, le) = hyper, latent
+    return b"CDC\x03" + struct.pack("<BBHHIIIIII", arith, 0, hh, wh, len(hb), len(lb), model, symbols, he, le) + hb + lb

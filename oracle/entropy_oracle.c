@@ -121,103 +121,127 @@ static void hyper_table(const float *raw, float median, table_t *t) {
     free(p);
 }
 
-/* ---- range-ANS, encoder writing backwards ---------------------------------------------------------------------- */
-typedef struct { uint8_t *buf; size_t cap, pos; uint32_t x; int overflow; } enc_t;
-static void enc_byte(enc_t *e, uint8_t b) { if (e->pos == 0) { e->overflow = 1; return; } e->buf[--e->pos] = b; }
-static void enc_put(enc_t *e, uint32_t start, uint32_t freq) {
-    const uint32_t xmax = ((RANS_L >> PREC) << 8) * freq;
-    while (e->x >= xmax) { enc_byte(e, (uint8_t)(e->x & 0xff)); e->x >>= 8; }
-    e->x = ((e->x / freq) << PREC) + (e->x % freq) + start;
-}
-static void enc_symbol(enc_t *e, const table_t *t, int k) {
-    const int K = t->K;
-    if (k >= -K && k <= K) { enc_put(e, t->c[k + K], t->f[k + K]); return; }
-    uint32_t w = ((uint32_t)((k < 0 ? -k : k) - K - 1) << 1) | (k < 0 ? 1u : 0u), dig[4];
-    int nd = 0;
-    do { dig[nd++] = w & 4095u; w >>= 12; } while (w);
-    for (int d = nd - 1; d >= 0; --d) {                 /* reverse order: the decoder reads digit 0 first */
-        const uint32_t v = dig[d] | (d < nd - 1 ? 4096u : 0u);
-        enc_put(e, v << (PREC - 13), 1u << (PREC - 13));
+/* ---- 64-way interleaved range-ANS (container version 3) -----------------------------------------------------------------
+ * Symbol i belongs to lane i % 64; every lane is an independent byte-wise rANS coder (state in [2^23, 2^31), 16-bit
+ * frequencies).  A section of N symbols is
+ *     states: 64 x u32 LE (what the decoder's lanes start from) | renormalisation bytes | escape payloads: u32 LE each
+ * Decoder, iteration j = 0, 1, ...: lane l decodes symbol 64 j + l from its state, then the lanes pull the bytes they need to
+ * get back above 2^23 (0, 1 or 2 each) from the byte stream IN LANE ORDER.  An out-of-support symbol is the table's ESCAPE
+ * entry (2K + 1); its payload w = ((|k| - K - 1) << 1) | (k < 0) is the next unread u32 of the escape list (symbol order).
+ * The encoder is the mirror image: iterations from the last to the first, lanes from 63 to 0, bytes written back to front.
+ * (This is how the GPU coder runs -- one wave per section, a prefix sum over the lanes' byte counts per iteration; the
+ * loop below restates it sequentially.) */
+#define LANES 64
+typedef struct { uint8_t *buf; size_t cap, pos; int overflow; } ebuf_t;
+static void eb_put(ebuf_t *e, uint8_t b) { if (e->pos == 0) { e->overflow = 1; return; } e->buf[--e->pos] = b; }
+
+/* tab(i) -> table of symbol i.  Returns the section size (0 on overflow); *n_esc = escape payload count. */
+typedef const table_t *(*tab_fn)(long long i, void *ctx);
+static size_t section_encode(const int32_t *sym, long long N, tab_fn tab, void *ctx, uint8_t *out, size_t cap, uint32_t *n_esc) {
+    uint32_t x[LANES];
+    for (int l = 0; l < LANES; ++l) x[l] = RANS_L;
+    ebuf_t e = {(uint8_t *)malloc(cap), cap, cap, 0};
+    uint32_t *esc = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(N > 0 ? N : 1));
+    long long ne = 0;
+    for (long long i = 0; i < N; ++i) {                                  /* escape payloads: forward symbol order */
+        const table_t *t = tab(i, ctx);
+        const int k = sym[i];
+        if (k < -t->K || k > t->K) esc[ne++] = ((uint32_t)((k < 0 ? -(long long)k : (long long)k) - t->K - 1) << 1) | (k < 0 ? 1u : 0u);
     }
-    enc_put(e, t->c[2 * K + 1], t->f[2 * K + 1]);
-}
-static size_t enc_finish(enc_t *e, uint8_t *out) {      /* final state, most significant byte first */
-    for (int i = 0; i < 4; ++i) { enc_byte(e, (uint8_t)(e->x & 0xff)); e->x >>= 8; }
-    const size_t n = e->cap - e->pos;
-    memcpy(out, e->buf + e->pos, n);
+    const long long nit = (N + LANES - 1) / LANES;
+    for (long long j = nit - 1; j >= 0; --j)
+        for (int l = LANES - 1; l >= 0; --l) {
+            const long long i = j * LANES + l;
+            if (i >= N) continue;
+            const table_t *t = tab(i, ctx);
+            const int k = sym[i];
+            const int en = (k >= -t->K && k <= t->K) ? k + t->K : 2 * t->K + 1;
+            const uint32_t start = t->c[en], freq = t->f[en];
+            const uint32_t xmax = ((RANS_L >> PREC) << 8) * freq;
+            while (x[l] >= xmax) { eb_put(&e, (uint8_t)(x[l] & 0xff)); x[l] >>= 8; }
+            x[l] = ((x[l] / freq) << PREC) + (x[l] % freq) + start;
+        }
+    for (int l = LANES - 1; l >= 0; --l)                                  /* u32 LE per lane, lane 0 first */
+        for (int b = 3; b >= 0; --b) eb_put(&e, (uint8_t)(x[l] >> (8 * b)));
+    size_t n = e.cap - e.pos;
+    if (e.overflow || n + 4 * (size_t)ne > cap) n = 0;
+    else {
+        memcpy(out, e.buf + e.pos, n);
+        for (long long q = 0; q < ne; ++q) for (int b = 0; b < 4; ++b) out[n + 4 * q + b] = (uint8_t)(esc[q] >> (8 * b));
+        n += 4 * (size_t)ne;
+    }
+    *n_esc = (uint32_t)ne;
+    free(e.buf); free(esc);
     return n;
 }
-
-typedef struct { const uint8_t *p, *end; uint32_t x; int bad; } dec_t;
-static uint32_t dec_next(dec_t *d) { if (d->p < d->end) return *d->p++; d->bad = 1; return 0; }
-static void dec_init(dec_t *d, const uint8_t *in, size_t n) {
-    d->p = in; d->end = in + n; d->x = 0; d->bad = 0;
-    for (int i = 0; i < 4; ++i) d->x = (d->x << 8) | dec_next(d);
-}
-static void dec_advance(dec_t *d, uint32_t start, uint32_t freq) {
-    d->x = freq * (d->x >> PREC) + (d->x & (TOT - 1)) - start;
-    while (d->x < RANS_L) d->x = (d->x << 8) | dec_next(d);
-}
-static int dec_symbol(dec_t *d, const table_t *t) {
-    const uint32_t slot = d->x & (TOT - 1);
-    int lo = 0, hi = t->n - 1;                          /* largest j with c[j] <= slot */
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t->c[mid] <= slot) lo = mid; else hi = mid - 1; }
-    dec_advance(d, t->c[lo], t->f[lo]);
-    if (lo <= 2 * t->K) return lo - t->K;
-    uint32_t w = 0;
-    for (int sh = 0; sh < 48; sh += 12) {
-        const uint32_t v = (d->x & (TOT - 1)) >> (PREC - 13);
-        dec_advance(d, v << (PREC - 13), 1u << (PREC - 13));
-        w |= (v & 4095u) << sh;
-        if (!(v & 4096u)) break;
+/* returns nonzero on a corrupt section */
+static int section_decode(const uint8_t *in, size_t nbytes, uint32_t n_esc, long long N, tab_fn tab, void *ctx, int32_t *sym) {
+    if (nbytes < 4 * LANES + 4 * (size_t)n_esc) return 1;
+    uint32_t x[LANES];
+    for (int l = 0; l < LANES; ++l) x[l] = (uint32_t)in[4 * l] | ((uint32_t)in[4 * l + 1] << 8) | ((uint32_t)in[4 * l + 2] << 16) | ((uint32_t)in[4 * l + 3] << 24);
+    const uint8_t *p = in + 4 * LANES, *end = in + nbytes - 4 * (size_t)n_esc, *ep = end;
+    uint32_t eidx = 0;
+    int bad = 0;
+    for (long long i = 0; i < N; ++i) {
+        const int l = (int)(i % LANES);
+        const table_t *t = tab(i, ctx);
+        const uint32_t slot = x[l] & (TOT - 1);
+        int lo = 0, hi = t->n - 1;                          /* largest j with c[j] <= slot */
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t->c[mid] <= slot) lo = mid; else hi = mid - 1; }
+        x[l] = t->f[lo] * (x[l] >> PREC) + slot - t->c[lo];
+        while (x[l] < RANS_L) { if (p >= end) { bad = 1; break; } x[l] = (x[l] << 8) | *p++; }
+        if (bad) break;
+        if (lo <= 2 * t->K) sym[i] = lo - t->K;
+        else {
+            if (eidx >= n_esc) { bad = 1; break; }
+            const uint32_t w = (uint32_t)ep[4 * eidx] | ((uint32_t)ep[4 * eidx + 1] << 8) | ((uint32_t)ep[4 * eidx + 2] << 16) | ((uint32_t)ep[4 * eidx + 3] << 24);
+            ++eidx;
+            const long long mag = (long long)(w >> 1) + t->K + 1;
+            sym[i] = (int32_t)((w & 1u) ? -mag : mag);
+        }
     }
-    const int mag = (int)(w >> 1) + t->K + 1;
-    return (w & 1u) ? -mag : mag;
+    if (!bad) {
+        if (p != end || eidx != n_esc) bad = 1;             /* every byte and every payload is consumed ... */
+        for (int l = 0; l < LANES; ++l) if (x[l] != RANS_L) bad = 1;   /* ... and every lane is back at the encoder's initial state */
+    }
+    return bad;
 }
 
 /* ---- entry points (ctypes) ------------------------------------------------------------------------------------------- */
 void orc_entropy_edges(float *edges) { gauss_tables(); memcpy(edges, g_edges, sizeof g_edges); }
 
-/* hyper symbols [C][per] with per-channel tables -> bytes; returns the byte count (0 on overflow) */
+typedef struct { table_t *tabs; int per; } hyper_ctx;
+static const table_t *hyper_tab(long long i, void *c) { const hyper_ctx *h = (const hyper_ctx *)c; return &h->tabs[i / h->per]; }
+static const table_t *gauss_tab(long long i, void *c) { return &g_gauss[scale_bin(((const float *)c)[i])]; }
+
+/* hyper symbols [C][per] with per-channel tables -> section bytes; returns the byte count (0 on overflow) */
 size_t orc_entropy_encode_hyper(const int32_t *sym, int C, int per, const float *raw_prior, const float *medians,
-                                uint8_t *out, size_t cap) {
-    table_t *tabs = (table_t *)malloc(sizeof(table_t) * C);
-    for (int c = 0; c < C; ++c) hyper_table(raw_prior + (size_t)c * 44, medians[c], &tabs[c]);
-    enc_t e = {(uint8_t *)malloc(cap), cap, cap, RANS_L, 0};
-    for (long long i = (long long)C * per - 1; i >= 0; --i) enc_symbol(&e, &tabs[i / per], sym[i]);
-    size_t n = enc_finish(&e, out);
-    if (e.overflow) n = 0;
-    free(e.buf);
-    for (int c = 0; c < C; ++c) table_free(&tabs[c]);
-    free(tabs);
+                                uint8_t *out, size_t cap, uint32_t *n_esc) {
+    hyper_ctx h = {(table_t *)malloc(sizeof(table_t) * C), per};
+    for (int c = 0; c < C; ++c) hyper_table(raw_prior + (size_t)c * 44, medians[c], &h.tabs[c]);
+    const size_t n = section_encode(sym, (long long)C * per, hyper_tab, &h, out, cap, n_esc);
+    for (int c = 0; c < C; ++c) table_free(&h.tabs[c]);
+    free(h.tabs);
     return n;
 }
-int orc_entropy_decode_hyper(const uint8_t *in, size_t n, int C, int per, const float *raw_prior, const float *medians, int32_t *sym) {
-    table_t *tabs = (table_t *)malloc(sizeof(table_t) * C);
-    for (int c = 0; c < C; ++c) hyper_table(raw_prior + (size_t)c * 44, medians[c], &tabs[c]);
-    dec_t d; dec_init(&d, in, n);
-    for (long long i = 0; i < (long long)C * per; ++i) sym[i] = dec_symbol(&d, &tabs[i / per]);
-    for (int c = 0; c < C; ++c) table_free(&tabs[c]);
-    free(tabs);
-    return d.bad;
+int orc_entropy_decode_hyper(const uint8_t *in, size_t n, uint32_t n_esc, int C, int per, const float *raw_prior, const float *medians, int32_t *sym) {
+    hyper_ctx h = {(table_t *)malloc(sizeof(table_t) * C), per};
+    for (int c = 0; c < C; ++c) hyper_table(raw_prior + (size_t)c * 44, medians[c], &h.tabs[c]);
+    const int bad = section_decode(in, n, n_esc, (long long)C * per, hyper_tab, &h, sym);
+    for (int c = 0; c < C; ++c) table_free(&h.tabs[c]);
+    free(h.tabs);
+    return bad;
 }
-/* latent symbols with per-element scale -> bytes */
-size_t orc_entropy_encode_latent(const int32_t *sym, const float *scale, long long n, uint8_t *out, size_t cap) {
+/* latent symbols with per-element scale -> section bytes */
+size_t orc_entropy_encode_latent(const int32_t *sym, const float *scale, long long n, uint8_t *out, size_t cap, uint32_t *n_esc) {
     gauss_tables();
-    enc_t e = {(uint8_t *)malloc(cap), cap, cap, RANS_L, 0};
-    for (long long i = n - 1; i >= 0; --i) enc_symbol(&e, &g_gauss[scale_bin(scale[i])], sym[i]);
-    size_t nb = enc_finish(&e, out);
-    if (e.overflow) nb = 0;
-    free(e.buf);
-    return nb;
+    return section_encode(sym, n, gauss_tab, (void *)scale, out, cap, n_esc);
 }
-int orc_entropy_decode_latent(const uint8_t *in, size_t nbytes, const float *scale, long long n, int32_t *sym) {
+int orc_entropy_decode_latent(const uint8_t *in, size_t nbytes, uint32_t n_esc, const float *scale, long long n, int32_t *sym) {
     gauss_tables();
-    dec_t d; dec_init(&d, in, nbytes);
-    for (long long i = 0; i < n; ++i) sym[i] = dec_symbol(&d, &g_gauss[scale_bin(scale[i])]);
-    return d.bad;
+    return section_decode(in, nbytes, n_esc, n, gauss_tab, (void *)scale, sym);
 }
-/* ---- fingerprints of the version-2 container (include/cdc_hip.h): FNV-1a, 32 bit, over little-endian u32 words ---- */
+/* ---- fingerprints of the version-3 container (include/cdc_hip.h): FNV-1a, 32 bit, over little-endian u32 words ---- */
 static uint32_t fnv_u32(uint32_t h, uint32_t v) {
     for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
     return h;
@@ -239,10 +263,17 @@ uint32_t orc_entropy_model_hash(int C, const float *raw_prior, const float *medi
     }
     return h;
 }
+/* order-independent checksum of a section's symbols (the GPU coder accumulates it per lane): sum of mix(section, i, symbol) */
+static uint32_t sym_mix(uint32_t sect, uint32_t i, int32_t k) {
+    uint32_t v = (i + 1u) * 0x9E3779B1u + sect * 0x7F4A7C15u;
+    v ^= (uint32_t)k * 0x85EBCA77u;
+    v ^= v >> 15; v *= 0x2C1B3C6Du; v ^= v >> 12; v *= 0x297A2D39u; v ^= v >> 15;
+    return v;
+}
 uint32_t orc_entropy_symbol_hash(const int32_t *a, size_t na, const int32_t *b, size_t nb) {
-    uint32_t h = 2166136261u;
-    for (size_t i = 0; i < na; ++i) h = fnv_u32(h, (uint32_t)a[i]);
-    for (size_t i = 0; i < nb; ++i) h = fnv_u32(h, (uint32_t)b[i]);
+    uint32_t h = 0;
+    for (size_t i = 0; i < na; ++i) h += sym_mix(0u, (uint32_t)i, a[i]);
+    for (size_t i = 0; i < nb; ++i) h += sym_mix(1u, (uint32_t)i, b[i]);
     return h;
 }
 /* the integer table of one scale bin / one hyper channel, for checkers written elsewhere (tests/test_entropy.py) */
@@ -261,9 +292,7 @@ double orc_entropy_ideal_bits_latent(const int32_t *sym, const float *scale, lon
         const int k = sym[i];
         if (k >= -t->K && k <= t->K) bits += 16.0 - log2((double)t->f[k + t->K]);
         else {
-            uint32_t w = ((uint32_t)((k < 0 ? -k : k) - t->K - 1) << 1);
-            int nd = 0; do { ++nd; w >>= 12; } while (w);
-            bits += 16.0 - log2((double)t->f[2 * t->K + 1]) + 13.0 * nd;
+            bits += 16.0 - log2((double)t->f[2 * t->K + 1]) + 32.0;      /* escape entry + its u32 payload */
         }
     }
     return bits;

@@ -35,12 +35,19 @@ def test_latent_round_trip_with_escapes_and_every_scale_bin():
     scale = np.exp(rng.uniform(np.log(0.1), np.log(3000.0), n)).astype(np.float32)
     sym = np.rint(rng.standard_normal(n) * scale).astype(np.int32)
     sym[::997] = rng.integers(-200000, 200000, sym[::997].shape)          # far outside every table: escape payloads
-    data = oe.encode_latent(sym, scale)
-    back = oe.decode_latent(data, scale)
+    data, ne = oe.encode_latent(sym, scale)
+    assert ne >= int(np.count_nonzero(np.abs(sym[::997]) > 8200))           # those are beyond every table (K <= 1023)
+    back = oe.decode_latent(data, ne, scale)
     np.testing.assert_array_equal(back, sym)
-    for empty in (np.zeros(0, np.int32),):
-        d0 = oe.encode_latent(empty, np.zeros(0, np.float32))
-        assert len(d0) == 4 and oe.decode_latent(d0, np.zeros(0, np.float32)).size == 0
+    for n_small in (0, 1, 63, 64, 65):                                       # no symbols / partial / exact / just-over lane groups
+        d0, e0 = oe.encode_latent(sym[:n_small], scale[:n_small])
+        assert len(d0) >= 256 and (n_small or len(d0) == 256)                # 64 lane states, nothing else for an empty section
+        np.testing.assert_array_equal(oe.decode_latent(d0, e0, scale[:n_small]), sym[:n_small])
+    # a corrupt section is noticed: flipped payload byte, truncated tail, wrong escape count
+    broken = bytearray(data); broken[300] ^= 0x40
+    assert oe.decode_latent(bytes(broken), ne, scale, check=False)[1]
+    assert oe.decode_latent(data[:-3], ne, scale, check=False)[1]
+    assert oe.decode_latent(data, ne + 1, scale, check=False)[1]
 
 
 def test_hyper_round_trip():
@@ -52,8 +59,9 @@ def test_hyper_round_trip():
     sym = np.rint(rng.standard_normal((C, 4, 5)) * 6).astype(np.int32)
     sym[3, 1, 2] = 5000
     sym[7, 0, 0] = -77777
-    data = oe.encode_hyper(sym, prior, med)
-    np.testing.assert_array_equal(oe.decode_hyper(data, C, 20, prior, med).reshape(sym.shape), sym)
+    data, ne = oe.encode_hyper(sym, prior, med)
+    assert ne >= 2
+    np.testing.assert_array_equal(oe.decode_hyper(data, ne, C, 20, prior, med).reshape(sym.shape), sym)
 
 
 def test_code_length_tracks_the_gaussian_rate_estimate():
@@ -70,8 +78,8 @@ def test_code_length_tracks_the_gaussian_rate_estimate():
         up = 0.5 * erfc(-(2 ** -0.5) * ((0.5 - x) / s)); lo = 0.5 * erfc(-(2 ** -0.5) * ((-0.5 - x) / s))
         est += -log2(max(up - lo, 1e-9))
     ideal = oe.ideal_bits_latent(sym, scale)
-    coded = 8 * len(oe.encode_latent(sym, scale))
-    assert abs(coded - ideal) <= 64                      # the coder itself wastes < 8 bytes
+    coded = 8 * len(oe.encode_latent(sym, scale)[0])
+    assert 0 <= coded - ideal <= 64 * 32 + 64 * 8        # 64 lane states (32 bits each) + < 1 byte of renormalisation slack per lane
     assert ideal <= est * 1.01 and ideal >= est * 0.999, (ideal, est)
 
 
@@ -112,10 +120,10 @@ def test_hyper_code_length_tracks_the_prior_rate_estimate():
         draw = rng.choice(ks, size=per, p=p / p.sum())
         sym[c] = draw
         est += float(-np.log2(np.maximum(p[draw + 300], 1e-9)).sum())
-    coded = 8 * len(oe.encode_hyper(sym.reshape(C, per, 1), prior, med))
-    assert coded <= est * 1.01 + 64 and coded >= est * 0.995, (coded, est)
-    np.testing.assert_array_equal(oe.decode_hyper(oe.encode_hyper(sym.reshape(C, per, 1), prior, med), C, per, prior, med),
-                                  sym.reshape(-1))
+    data, ne = oe.encode_hyper(sym.reshape(C, per, 1), prior, med)
+    coded = 8 * len(data)
+    assert coded <= est * 1.01 + 64 * 40 and coded >= est * 0.995, (coded, est)
+    np.testing.assert_array_equal(oe.decode_hyper(data, ne, C, per, prior, med), sym.reshape(-1))
 
 
 # ---- a second, structurally different checker: the specification in pure Python (floats + big integers) -------------
@@ -141,44 +149,38 @@ def _py_gauss_table(edge):
     return K, f
 
 
-def _py_rans_decode(data, tables, n):
-    """Byte-wise range-ANS decoder on Python integers: state in [2^23, 2^31), 16-bit frequencies, escape = entry 2K+1
-    followed by 13-bit groups (12 data bits, least significant group first, bit 12 = another group follows)."""
-    pos, x = 4, int.from_bytes(data[:4], "big")
-
-    def advance(start, freq):
-        nonlocal x, pos
-        x = freq * (x >> 16) + (x & 65535) - start
-        while x < (1 << 23):
-            x = (x << 8) | data[pos]
-            pos += 1
-
-    out = []
+def _py_section_decode(data, n_esc, tables, n):
+    """The 64-lane interleaved range-ANS section of container version 3 on Python integers: 64 u32 LE lane states, then
+    the renormalisation bytes (per iteration, the lanes pull what they need in lane order), then the u32 LE escape
+    payloads.  Returns (symbols, everything consumed and every lane back at 2^23)."""
+    lanes = 64
+    x = [int.from_bytes(data[4 * l: 4 * l + 4], "little") for l in range(lanes)]
+    pos, end = 4 * lanes, len(data) - 4 * n_esc
+    esc = [int.from_bytes(data[end + 4 * q: end + 4 * q + 4], "little") for q in range(n_esc)]
+    out, eidx = [], 0
     for i in range(n):
+        l = i % lanes
         K, f, cum = tables[i]
-        slot = x & 65535
+        slot = x[l] & 65535
         j = int(np.searchsorted(cum, slot, side="right")) - 1
-        advance(int(cum[j]), int(f[j]))
+        x[l] = int(f[j]) * (x[l] >> 16) + slot - int(cum[j])
+        while x[l] < (1 << 23):
+            x[l] = (x[l] << 8) | data[pos]
+            pos += 1
         if j <= 2 * K:
             out.append(j - K)
-            continue
-        w, sh = 0, 0
-        while True:
-            dg = (x & 65535) >> 3
-            advance(dg << 3, 8)
-            w |= (dg & 4095) << sh
-            sh += 12
-            if not dg & 4096:
-                break
-        mag = (w >> 1) + K + 1
-        out.append(-mag if w & 1 else mag)
-    return out, pos
+        else:
+            w = esc[eidx]
+            eidx += 1
+            mag = (w >> 1) + K + 1
+            out.append(-mag if w & 1 else mag)
+    return out, pos == end and eidx == n_esc and all(v == (1 << 23) for v in x)
 
 
 def test_pure_python_checker_agrees_with_the_c_coder():
     """The C restatement (which the product must match byte for byte) against the specification written a third time in
-    pure Python: (1) every integer of a sample of the scale tables, (2) a pure-Python decoder recovers the symbols
-    from the C encoder's bytes and consumes exactly all of them, (3) the stream length against the exact information
+    pure Python: (1) every integer of a sample of the scale tables, (2) a pure-Python decoder of the 64-lane interleaved format recovers the
+    symbols from the C encoder's bytes, consumes exactly all of them and leaves every lane at its initial state, (3) the stream length against the exact information
     content of the symbols under the integer tables (big-integer arithmetic, no floating point)."""
     e = oe.edges()
     for b in (0, 1, 17, 40, 63, 64, 100, 127):
@@ -189,9 +191,9 @@ def test_pure_python_checker_agrees_with_the_c_coder():
     n = 6000
     scale = np.exp(rng.uniform(np.log(0.1), np.log(40.0), n)).astype(np.float32)
     sym = np.rint(rng.standard_normal(n) * scale).astype(np.int32)
-    sym[::997] *= 9                                                   # a few escapes, two-digit ones included
+    sym[::997] *= 9                                                   # a few escapes
     sym[5] = 70000
-    data = oe.encode_latent(sym, scale)
+    data, ne = oe.encode_latent(sym, scale)
     bins = np.minimum(np.searchsorted(e, scale, side="left"), 127)    # smallest i with s <= e_i
     cache = {}
     tabs = []
@@ -200,23 +202,18 @@ def test_pure_python_checker_agrees_with_the_c_coder():
             K, f = _py_gauss_table(e[int(b)])
             cache[int(b)] = (K, np.asarray(f, np.int64), np.concatenate([[0], np.cumsum(f)]).astype(np.int64))
         tabs.append(cache[int(b)])
-    got, used = _py_rans_decode(data, tabs, n)
-    assert got == [int(v) for v in sym] and used == len(data)
-    # exact information content: prod(65536 / f) over the coded entries (escape digits: 13 bits each) as a rational number
+    got, clean = _py_section_decode(data, ne, tabs, n)
+    assert got == [int(v) for v in sym] and clean
+    # exact information content: prod(65536 / f) over the coded entries (an escape: its entry + a 32-bit payload) as a
+    # rational number; the section may exceed it by the 64 lane states and < 1 byte of renormalisation slack per lane
     num, den = 1, 1
     for k, (K, f, _) in zip(sym.tolist(), tabs):
         if -K <= k <= K:
             num, den = num << 16, den * int(f[k + K])
         else:
-            w, nd = (abs(k) - K - 1) << 1, 0
-            while True:
-                nd += 1
-                w >>= 12
-                if not w:
-                    break
-            num, den = num << (16 + 13 * nd), den * int(f[2 * K + 1])
+            num, den = num << (16 + 32), den * int(f[2 * K + 1])
     ideal_bits = (num // den).bit_length()                            # ceil(log2) to within one bit
-    assert 0 <= 8 * len(data) - ideal_bits <= 64, (8 * len(data), ideal_bits)   # 32-bit final state + renormalisation slack
+    assert 0 <= 8 * len(data) - ideal_bits <= 64 * 32 + 64 * 8, (8 * len(data), ideal_bits)
 
 
 # ---- GPU: product vs oracle ------------------------------------------------------------------------------------------
@@ -234,7 +231,8 @@ def _full_compressor():
 def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
     """Kodak fixture crops: the product's streams (GPU analysis transform + cdc_entropy_encode) equal the oracle coder's
     on the same symbols byte for byte; decoding returns exactly the encoder's dequantised latents; the coded size is
-    within 1 % (+ the 26-byte container) of the reference's own bpp estimate for these images."""
+    within 1 % (+ the container header) of the reference's own bpp estimate for these images.  The batch call and the
+    per-image calls must produce the same bytes (hyper_dec runs every image through the batch-1 launch plan)."""
     g = np.load(os.path.join(GOLDEN, "kodak_x_500.npz"))
     comp, sd = _full_compressor()
     x = (g["crops"].astype(np.float32).transpose(0, 3, 1, 2) / 255.0 * 2.0 - 1.0).astype(np.float32)
@@ -264,9 +262,10 @@ def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
         coded_bits = 8 * (len(streams[b]) - oe.HEADER)
         assert coded_bits <= est_bits * 1.01 + 64, (b, coded_bits, est_bits)
         ideal = oe.ideal_bits_latent(sym_l, scale[0])
-        lat_bits = 8 * (len(streams[b]) - oe.HEADER - len(oe.encode_hyper(sym_h, prior, med)))
-        assert abs(lat_bits - ideal) <= 64, (lat_bits, ideal)
-    # whole batch in one call == per-image calls (each image is coded through the batch-1 program)
+        lat_bits = 8 * (len(streams[b]) - oe.HEADER - len(oe.encode_hyper(sym_h, prior, med)[0]))
+        assert 0 <= lat_bits - ideal <= 64 * 32 + 64, (lat_bits, ideal)     # 64 lane states of 32 bits on top of the ideal length
+        assert comp.compress_to_bytes(xb)[0] == streams[b]          # batch-3 call == batch-1 call, byte for byte
+    # whole batch in one call == per-image calls
     q_all = comp.decompress_from_bytes(streams)
     q_ref = np.concatenate([comp.decompress_from_bytes([s]) for s in streams])
     np.testing.assert_array_equal(q_all, q_ref)
@@ -313,9 +312,45 @@ def test_corrupt_stream_is_rejected():
     # a stream coded with other probability tables (model fingerprint) fails loudly, not silently
     with pytest.raises(_lib.CdcError, match="probability tables"):
         comp.decompress_from_bytes([s[:18] + bytes([s[18] ^ 1]) + s[19:]])
-    # a flipped payload byte is caught by the symbol checksum (or by the coder running off the end)
-    with pytest.raises(_lib.CdcError):
-        comp.decompress_from_bytes([s[:40] + bytes([s[40] ^ 0x10]) + s[41:]])
+    # a flipped byte anywhere in the payload -- lane states, renormalisation bytes, the last byte -- is caught by the coder's
+    # end conditions (all lanes back at 2^23, every byte consumed) or by the symbol checksum
+    for at in (oe.HEADER + 5, oe.HEADER + 256 + 9, len(s) // 2, len(s) - 1):
+        with pytest.raises(_lib.CdcError):
+            comp.decompress_from_bytes([s[:at] + bytes([s[at] ^ 0x10]) + s[at + 1:]])
+    # a wrong escape count / symbol checksum in the header
+    for at in (22, 26, 30):
+        with pytest.raises(_lib.CdcError):
+            comp.decompress_from_bytes([s[:at] + bytes([s[at] ^ 1]) + s[at + 1:]])
     # the handle's own arithmetic survives decoding a stream recorded in the other one
     other = comp.compress_to_bytes(x)[0]
     assert comp.decompress_from_bytes([other]).shape[0] == 1
+
+
+@pytest.mark.gpu
+def test_batch_calls_hold_the_bits_of_single_image_calls_and_mixed_arithmetics_decode_together():
+    """The determinism contract of the coder (csrc/entropy.hip): hyper_dec is planned as for one image whatever the batch,
+    so a batch-7 encode produces the seven batch-1 streams byte for byte and a batch decode returns the per-image
+    results exactly -- also when the streams of one call were recorded in different arithmetics."""
+    import cdc_compression_amd as cdc
+    comp, sd = _full_compressor()
+    x = synth.normal("img", (7, 3, 64, 128), seed=9, std=0.5)
+    x[3] *= 2.5                                                    # (another dynamic range: other scale bins, escapes)
+    streams = comp.compress_to_bytes(x)
+    singles = [comp.compress_to_bytes(x[b:b + 1])[0] for b in range(7)]
+    assert streams == singles
+    q_all, h_all = comp.decompress_from_bytes(streams, return_hyper=True)
+    for b in range(7):
+        ql, qh = comp.decompress_from_bytes([streams[b]], return_hyper=True)
+        np.testing.assert_array_equal(q_all[b:b + 1], ql)
+        np.testing.assert_array_equal(h_all[b:b + 1], qh)
+    # streams recorded in the exact arithmetic, decoded in one call with F16X2 ones
+    from cdc_compression_amd import _lib
+    L, hy = _lib.lib(), comp._hyper_handle()
+    _lib.check(hy, L.cdc_set_arith(hy, 0))                          # CDC_ARITH_BF16X3
+    exact = comp.compress_to_bytes(x[:2])
+    _lib.check(hy, L.cdc_set_arith(hy, 1))                          # CDC_ARITH_F16X2
+    assert exact[0][4] == 0 and streams[0][4] == 1
+    mixed = [streams[0], exact[0], exact[1], streams[4]]
+    q_mixed = comp.decompress_from_bytes(mixed)
+    for i, s1 in enumerate(mixed):
+        np.testing.assert_array_equal(q_mixed[i:i + 1], comp.decompress_from_bytes([s1]))

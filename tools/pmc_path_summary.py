@@ -39,6 +39,7 @@ for f in glob.glob(os.path.join(out, "t", "**", "*kernel_stats.csv"), recursive=
     for r in csv.DictReader(open(f)):
         stats[short(r["Name"])] = dict(calls=int(r["Calls"]), total_ns=float(r["TotalDurationNs"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"]))
 A, nA = counters("a")
+Wc, nW = counters("w")
 Bc, nB = counters("b")
 C, nC = counters("c")
 tot_ns = sum(v["total_ns"] for v in stats.values())
@@ -50,7 +51,7 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
         continue
     a, b, c = A.get(k, {}), Bc.get(k, {}), C.get(k, {})
     na, nb, nc = max(nA.get(k, 0), 1), max(nB.get(k, 0), 1), max(nC.get(k, 0), 1)
-    fetch, write = a.get("FETCH_SIZE", 0) / na * 1024, a.get("WRITE_SIZE", 0) / na * 1024
+    fetch, write = a.get("FETCH_SIZE", 0) / na * 1024, Wc.get(k, {}).get("WRITE_SIZE", 0) / max(nW.get(k, 0), 1) * 1024
     corr, raw = 2 * fetch + write, fetch + write
     busy = b.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / b["SQ_BUSY_CYCLES"] if b.get("SQ_BUSY_CYCLES") else float("nan")
     # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD, SQ_BUSY_CYCLES per SQ (4 SIMDs): normalise to "share of SIMD-busy time"
@@ -62,7 +63,7 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
     print(f"{k:<112} {s['calls']:>6} {s['avg_ns'] / 1e3:>9.1f} {s['pct']:>7.2f} {corr / 1e6:>16.1f} | {raw / 1e6:>11.1f} {tbs:>6.2f} {busy:>10.3f} {b.get('SQ_INSTS_MFMA', 0) / nb:>11.0f} {confl:>9.3f}")
 # whole path: every dispatch of the pass / number of DDIM iterations (the 2-iteration build decode and the context pre-pass are in: upper bound)
 tot_fetch = sum(v.get("FETCH_SIZE", 0) for v in A.values()) * 1024
-tot_write = sum(v.get("WRITE_SIZE", 0) for v in A.values()) * 1024
+tot_write = sum(v.get("WRITE_SIZE", 0) for v in Wc.values()) * 1024
 iters = steps + 2
 per_iter_corr, per_iter_raw = (2 * tot_fetch + tot_write) / iters, (tot_fetch + tot_write) / iters
 print(f"\nwhole path: FETCH {tot_fetch / 1e9:.2f} GB (raw) + WRITE {tot_write / 1e9:.2f} GB over {iters} DDIM iterations of {B} images")
