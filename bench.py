@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the B=1 re-decode of two output rows")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra decode in the exact bf16x3 arithmetic")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational compressor / entropy coder legs (profiling runs)")
     ap.add_argument("--prof-every", type=int, default=50)
     a = ap.parse_args()
     if a.sample_steps is None:
@@ -326,7 +327,7 @@ def main():
                                 "note": "one timed decode of the same batch, outside `value`"}
             _lib.check(h, L.cdc_set_arith(h, 1))
         out["range_guard"] = _lib.handle_status(h)
-        if world == 1 and a.param == "x" and S % 64 == 0:
+        if world == 1 and a.param == "x" and S % 64 == 0 and not a.no_extras:
             # informational (outside the timed region): the compressor on the GPU -- Compressor.forward (analysis
             # transform, hyper encoder/decoder, quantisers, rate estimate, synthesis transform) and decode alone
             comp = cdc.ResnetCompressor(dim=64, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1],

@@ -403,13 +403,13 @@ class _ContextDecoder:
         al, ah = _Arg(latent, self.device_index), _Arg(hyper, self.device_index)
         B, _, hh, wh = ah.shape
         nsym = int(np.prod(al.shape[1:])) + int(np.prod(ah.shape[1:]))
-        cap = B * (64 + 4 * nsym)
-        buf = (ctypes.c_ubyte * cap)()
+        cap = B * (64 + 2 * 320 + 6 * nsym)              # <= 2 renormalisation bytes + a 4-byte escape payload per symbol
+        buf = np.empty(cap, dtype=np.uint8)
         offs = (ctypes.c_size_t * (B + 1))()
         med = self._median_vector()
-        _lib.check(h, L.cdc_entropy_encode(h, al.ptr, ah.ptr, med.ctypes.data, B, hh, wh, buf, cap, offs, al.mem,
+        _lib.check(h, L.cdc_entropy_encode(h, al.ptr, ah.ptr, med.ctypes.data, B, hh, wh, buf.ctypes.data, cap, offs, al.mem,
                                            _current_stream(al.mem)))
-        raw = bytes(buf[: offs[B]])
+        raw = buf[: offs[B]].tobytes()
         return [raw[offs[b]: offs[b + 1]] for b in range(B)]
 
     def decompress_from_bytes(self, streams, like=None, return_hyper=False):

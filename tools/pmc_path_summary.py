@@ -53,9 +53,9 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
     na, nb, nc = max(nA.get(k, 0), 1), max(nB.get(k, 0), 1), max(nC.get(k, 0), 1)
     fetch, write = a.get("FETCH_SIZE", 0) / na * 1024, Wc.get(k, {}).get("WRITE_SIZE", 0) / max(nW.get(k, 0), 1) * 1024
     corr, raw = 2 * fetch + write, fetch + write
-    busy = b.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / b["SQ_BUSY_CYCLES"] if b.get("SQ_BUSY_CYCLES") else float("nan")
-    # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD, SQ_BUSY_CYCLES per SQ (4 SIMDs): normalise to "share of SIMD-busy time"
-    busy /= 4.0
+    # SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe cycles summed over the chip's 1024 SIMDs (32 per v_mfma_f32_32x32x16); GRBM_GUI_ACTIVE =
+    # busy cycles summed over the 8 XCDs: share of the chip's matrix-pipe time = MFMA_BUSY / (1024 * GUI_ACTIVE / 8)
+    busy = b.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (128.0 * b["GRBM_GUI_ACTIVE"]) if b.get("GRBM_GUI_ACTIVE") else float("nan")
     confl = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else float("nan")
     tbs = corr / (s["avg_ns"] * 1e-9) / 1e12
     rows.append(dict(kernel=k, calls=s["calls"], avg_us=s["avg_ns"] / 1e3, pct=s["pct"], hbm_mb_corr=corr / 1e6, hbm_mb_raw=raw / 1e6,
