@@ -171,34 +171,38 @@ void orc_conv_transpose2d(const float *x, const float *w, const float *bias, flo
 {
     const int Ho = (H - 1) * stride - 2 * pad + KH + outpad;
     const int Wo = (W - 1) * stride - 2 * pad + KW + outpad;
+    /* one output row per task (a batch-1 call still fills the machine); per output element the terms are added in the
+     * order (ci, ky, kx), exactly as a scatter over (ci, ky, kx, iy, ix) would */
+    /* the columns of an output row split into `stride` phases (ox = j * stride + ph): per (ky, kx) the update of a phase row
+     * is a contiguous axpy over ix */
+    const int PW = W + KW + pad + 2, SH0 = pad + 1;
 #pragma omp parallel
     {
-        acc_t *acc = (acc_t *)malloc(sizeof(acc_t) * (size_t)Ho * Wo);
-#pragma omp for collapse(2) schedule(static)
+        acc_t *acc = (acc_t *)malloc(sizeof(acc_t) * (size_t)stride * PW);
+#pragma omp for collapse(3) schedule(static)
         for (int b = 0; b < B; ++b)
-            for (int co = 0; co < Cout; ++co) {
-                const acc_t bv = bias ? (acc_t)bias[co] : (acc_t)0;
-                for (int i = 0; i < Ho * Wo; ++i) acc[i] = bv;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float *xp = x + ((size_t)b * Cin + ci) * H * W;
-                    const float *wp = w + ((size_t)ci * Cout + co) * KH * KW;
-                    for (int ky = 0; ky < KH; ++ky)
-                        for (int kx = 0; kx < KW; ++kx) {
-                            const acc_t wv = (acc_t)wp[ky * KW + kx];
-                            for (int iy = 0; iy < H; ++iy) {
-                                const int oy = iy * stride - pad + ky;
-                                if (oy < 0 || oy >= Ho) continue;
-                                for (int ix = 0; ix < W; ++ix) {
-                                    const int ox = ix * stride - pad + kx;
-                                    if (ox < 0 || ox >= Wo) continue;
-                                    acc[oy * Wo + ox] += wv * (acc_t)xp[iy * W + ix];
-                                }
+            for (int co = 0; co < Cout; ++co)
+                for (int oy = 0; oy < Ho; ++oy) {
+                    const acc_t bv = bias ? (acc_t)bias[co] : (acc_t)0;
+                    for (int i = 0; i < stride * PW; ++i) acc[i] = bv;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float *xp = x + ((size_t)b * Cin + ci) * H * W;
+                        const float *wp = w + ((size_t)ci * Cout + co) * KH * KW;
+                        for (int ky = 0; ky < KH; ++ky) {
+                            const int t = oy + pad - ky;
+                            if (t < 0 || (t % stride) != 0 || t / stride >= H) continue;
+                            const float *xr = xp + (size_t)(t / stride) * W;
+                            for (int kx = 0; kx < KW; ++kx) {
+                                const acc_t wv = (acc_t)wp[ky * KW + kx];
+                                const int q = kx - pad, ph = ((q % stride) + stride) % stride, sh = (q - ph) / stride;
+                                acc_t *ar = acc + (size_t)ph * PW + sh + SH0;
+                                for (int ix = 0; ix < W; ++ix) ar[ix] += wv * (acc_t)xr[ix];
                             }
                         }
+                    }
+                    float *yp = y + (((size_t)b * Cout + co) * Ho + oy) * Wo;
+                    for (int ox = 0; ox < Wo; ++ox) yp[ox] = (float)acc[(size_t)(ox % stride) * PW + ox / stride + SH0];
                 }
-                float *yp = y + ((size_t)b * Cout + co) * Ho * Wo;
-                for (int i = 0; i < Ho * Wo; ++i) yp[i] = (float)acc[i];
-            }
         free(acc);
     }
 }
@@ -236,15 +240,17 @@ void orc_chan_layernorm(const float *x, const float *g, const float *bb, float *
  *   context[d,e] = sum_n k[d,n] v[e,n];  out[e,n] = sum_d context[d,e] q[d,n]       */
 void orc_linear_attention_core(const float *qkv, float *out, int B, int C, int N, float scale)
 {
+    /* threads split the rows / (d, e) pairs of ONE image (a batch-1 call still fills the machine); every sum keeps its order */
+    float *ks = (float *)malloc(sizeof(float) * (size_t)C * N);
+    acc_t *ctx = (acc_t *)malloc(sizeof(acc_t) * (size_t)C * C);
+    for (int b = 0; b < B; ++b) {
+        const float *q = qkv + (size_t)b * 3 * C * N;
+        const float *k = q + (size_t)C * N;
+        const float *v = k + (size_t)C * N;
+        float *o = out + (size_t)b * C * N;
 #pragma omp parallel
-    {
-        float *ks = (float *)malloc(sizeof(float) * (size_t)C * N);
-        acc_t *ctx = (acc_t *)malloc(sizeof(acc_t) * (size_t)C * C);
+        {
 #pragma omp for schedule(static)
-        for (int b = 0; b < B; ++b) {
-            const float *q = qkv + (size_t)b * 3 * C * N;
-            const float *k = q + (size_t)C * N;
-            const float *v = k + (size_t)C * N;
             for (int d = 0; d < C; ++d) {
                 const float *kr = k + (size_t)d * N;
                 float m = kr[0];
@@ -258,6 +264,7 @@ void orc_linear_attention_core(const float *qkv, float *out, int B, int C, int N
                 for (int n = 0; n < N; ++n)
                     ks[(size_t)d * N + n] = (float)((acc_t)ks[(size_t)d * N + n] / z);
             }
+#pragma omp for collapse(2) schedule(static)
             for (int d = 0; d < C; ++d)
                 for (int e = 0; e < C; ++e) {
                     acc_t s = 0;
@@ -265,12 +272,8 @@ void orc_linear_attention_core(const float *qkv, float *out, int B, int C, int N
                     for (int n = 0; n < N; ++n) s += (acc_t)kr[n] * (acc_t)vr[n];
                     ctx[(size_t)d * C + e] = s;
                 }
-            float *o = out + (size_t)b * C * N;
-            for (int e = 0; e < C; ++e) {
-                float *orow = o + (size_t)e * N;
-                for (int n = 0; n < N; ++n) orow[n] = 0.f;
-            }
-            /* out[e,n] = sum_d ctx[d,e] * (q[d,n]*scale) ; accumulate d-outer for contiguity */
+            /* out[e,n] = sum_d ctx[d,e] * (q[d,n]*scale) ; d-outer per row for contiguity */
+#pragma omp for schedule(static)
             for (int e = 0; e < C; ++e) {
                 acc_t *tmp = (acc_t *)malloc(sizeof(acc_t) * N);
                 for (int n = 0; n < N; ++n) tmp[n] = 0;
@@ -284,9 +287,12 @@ void orc_linear_attention_core(const float *qkv, float *out, int B, int C, int N
                 free(tmp);
             }
         }
-        free(ks);
-        free(ctx);
     }
+    free(ks);
+    free(ctx);
 }
 
 int orc_acc_bytes(void) { return (int)sizeof(acc_t); }
+/* OpenMP team size (hosts whose cgroup CPU quota is far below the visible core count must not oversubscribe) */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_threads(void) { return omp_get_max_threads(); }

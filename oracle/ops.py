@@ -26,6 +26,23 @@ def build(force=False):
     return libs
 
 
+def usable_cores():
+    """CPUs this process may really use: affinity mask and cgroup-v2 quota (a container that sees 256 CPUs with a 16-CPU quota
+    must not run 256 OpenMP threads: every barrier then waits for throttled threads)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def _ptr(a):
     return a.ctypes.data_as(_f) if a is not None else None
 
@@ -45,6 +62,8 @@ class OrcOps:
         L.orc_chan_layernorm.argtypes = [_f, _f, _f, _f, _i, _i, _i, ctypes.c_float]
         L.orc_linear_attention_core.argtypes = [_f, _f, _i, _i, _i, ctypes.c_float]
         assert L.orc_acc_bytes() == (4 if acc == "f32" else 8)
+        L.orc_set_threads(usable_cores())
+        self.threads = int(L.orc_get_threads())
 
     def conv2d(self, x, w, b=None, stride=1, padding=0):
         x, w = _c(x), _c(w)
