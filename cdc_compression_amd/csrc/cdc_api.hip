@@ -2324,7 +2324,7 @@ int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_l
     if ((rc = build_hyperdec_program(h, B, hh, wh, true))) return rc;
     const Act &o = h->dec_outs[0];
     const long long nl = (long long)(o.C / 2) * o.H * o.W;
-    if (nh > (1ll << 30) || nl > (1ll << 30)) return fail(h, CDC_ERR_INVALID, "image too large for one coder section");
+    if (nh > (1ll << 29) || nl > (1ll << 29)) return fail(h, CDC_ERR_INVALID, "image too large for one coder section");   // (section offsets are 32-bit)
     DevPool d;
     const float *d_hl = hyper_latent, *d_lat = latent;
     if (mem != CDC_MEM_DEVICE) {
@@ -2427,6 +2427,7 @@ int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *of
         if ((rc = build_hyperdec_program(h, nb, hh, wh, true))) return rc;
         const Act &o = h->dec_outs[0];
         const long long nl = (long long)(o.C / 2) * o.H * o.W;
+        if (nh > (1ll << 29) || nl > (1ll << 29)) return fail(h, CDC_ERR_INVALID, "image too large for one coder section");
         std::vector<long long> off(2 * (size_t)nb);
         std::vector<int> len(2 * (size_t)nb), esc(2 * (size_t)nb);
         for (int b = b0; b < b1; ++b) {

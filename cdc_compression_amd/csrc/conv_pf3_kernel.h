@@ -47,7 +47,8 @@ namespace cdc {
 #define CDC_PF3_D 5          // weight stages are issued D steps ahead; ring = D + 2 slots (a slot is rewritten two steps after its last reader)
 #endif
 
-constexpr int kPf3Resid = 1, kPf3F32 = 2, kPf3Pf = 4, kPf3Stat = 8;     // EPV: which vector-memory operations the epilogue issues
+constexpr int kPf3Resid = 1, kPf3F32 = 2, kPf3Pf = 4, kPf3Stat = 8, kPf3Res3 = 16;     // EPV: which vector-memory operations the epilogue issues
+// (kPf3Res3: the 3-channel res_conv of the first ResnetBlock in the epilogue, conv_args.h: res3_w / res3_x; 64-channel shape only)
 
 __host__ __device__ constexpr int pf3_xsw(int NPW, int WP) { return (4 * (WP * NPW + 2) * 34 + 63) / 64; }
 __host__ __device__ constexpr int pf3_kxw(int NPW, int WP) { return (pf3_xsw(NPW, WP) + 3) / 4; }        // patch DMAs per wave and slot
@@ -57,7 +58,7 @@ __host__ __device__ constexpr size_t pf3_lds_bytes() { return 163840; }
 __host__ __device__ constexpr size_t pf3_lds_used(int MB, int NPW, int WM, int WP, int B) {
     const size_t copt = (size_t)WM * MB * 32;
     return (size_t)(4 * pf3_pst(NPW, WP) + (CDC_PF3_D + 2) * 4 * (int)copt) * 16 +
-           sizeof(float) * ((3 + (size_t)B) * copt + (size_t)2 * 2 * WM * WP * NPW * 32) + 4 * 4096 + PF3_TL_BYTES;
+           sizeof(float) * (((WM == 1 ? 6 : 3) + (size_t)B) * copt + (size_t)2 * 2 * WM * WP * NPW * 32) + 4 * 4096 + PF3_TL_BYTES;
 }
 
 // ---- static vector-memory schedule of a wave -----------------------------------------------------------------------
@@ -72,7 +73,8 @@ __host__ __device__ constexpr Pf3Ops pf3_ops_epi(int nblk, int epv) {
 }
 // SYNC mode: the whole epilogue runs between two slots -- as if it were the B piece of the previous slot's last step
 __host__ __device__ constexpr Pf3Ops pf3_ops_epi_sync(int nblk, int epv) {
-    const int n = 4 * nblk * (((epv & kPf3Resid) ? 1 : 0) + ((epv & kPf3F32) ? 1 : 0) + ((epv & kPf3Pf) ? 2 : 0)) + ((epv & kPf3Stat) ? 4 : 0);
+    const int n = 4 * nblk * (((epv & kPf3Resid) ? 1 : 0) + ((epv & kPf3F32) ? 1 : 0) + ((epv & kPf3Pf) ? 2 : 0)) + ((epv & kPf3Stat) ? 4 : 0) +
+                  ((epv & kPf3Res3) ? 6 : 0);
     return Pf3Ops{{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, n}};
 }
 // Operations of this wave issued after the TARGET and before the wait point of step t (steps < 0: previous slot):
@@ -148,7 +150,10 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
     static_assert(WM * WP == 4, "a group is four waves");
     static_assert(MB * NPW <= 4, "two accumulator sets per wave tile");
     constexpr bool RESID = (EPV & kPf3Resid) != 0, F32 = (EPV & kPf3F32) != 0, PF = (EPV & kPf3Pf) != 0, STAT = (EPV & kPf3Stat) != 0;
+    constexpr bool RES3 = (EPV & kPf3Res3) != 0;
     static_assert(!STAT || SYNC, "LayerNorm statistics of the result: free-running epilogue only");
+    static_assert(!RES3 || (SYNC && WM == 1 && NPW == 2), "epilogue res_conv: free-running epilogue, 64-channel shape");
+    constexpr int EPR = WM == 1 ? 6 : 3;                                  // parameter rows (keep in step with pf3_lds_used)
     constexpr int COPT = WM * MB * 32, ROWS = 4, WST = ROWS * COPT;       // weight stage: planes {WH, WL} x two k-halves
     constexpr int U = WST / 64, UG = U / 2;                               // 1-KiB DMA units per stage / per group
     static_assert(UG >= 1 && UG <= 4, "a group issues at most one weight DMA per wave and step");
@@ -169,8 +174,8 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
     // ---- LDS map: [group 0: patch 0, patch 1][group 1: patch 0, patch 1][weight ring][epilogue parameters] ... [scratch]
     uint4 *patch_g = smem_u + grp * 2 * PST;
     uint4 *ring = smem_u + 4 * PST;
-    float *ep = reinterpret_cast<float *>(smem_u + 4 * PST + R * WST);    // bias / scale, ln g, ln b: [3][COPT]; shift [B][COPT]
-    float *epsh = ep + 3 * COPT;
+    float *ep = reinterpret_cast<float *>(smem_u + 4 * PST + R * WST);    // bias / scale, ln g, ln b (, res3 weights): [EPR][COPT]; shift [B][COPT]
+    float *epsh = ep + EPR * COPT;
     float *red = epsh + (P.shift ? P.B * COPT : 0) + grp * (2 * WM * WP * NPW * 32);
     float *ex = reinterpret_cast<float *>(smem_u) + (163840 - 4 * 4096 - (PF3_TL_BYTES)) / 4;   // 4 KiB per wave of the group in its epilogue
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
@@ -279,6 +284,8 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
         ep[i] = (ok && P.bias) ? P.bias[co] / P.acc_scale : 0.f;     // the accumulators start here (acc_scale is a power of two)
         ep[COPT + i] = (ok && P.ep_g) ? P.ep_g[co] : 0.f;
         ep[2 * COPT + i] = (ok && P.ep_b) ? P.ep_b[co] : 0.f;
+        if constexpr (RES3)
+            for (int c = 0; c < 3; ++c) ep[(3 + c) * COPT + i] = ok ? P.res3_w[(size_t)c * P.COP + co] : 0.f;
     }
     if (P.shift)
         for (int i = tid; i < P.B * COPT; i += 512) {
@@ -528,12 +535,34 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                     }
                 }
             };
+            float x3[NPW][3];                             // res_conv input: the 3 image channels of this lane's pixels
+            auto ldX = [&]() {
+                if constexpr (RES3) {
+                    const float *xp = Pe->res3_x + (size_t)T.b * Pe->res3_bs + (size_t)(T.oy0 + wp * NPW) * Pe->Wo + T.ox0 + j;
+                    const size_t hw = (size_t)Pe->Ho * Pe->Wo;
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) x3[n][c] = xp[(size_t)c * hw + (size_t)n * Pe->Wo];
+                }
+            };
             auto fin_pf = [&](auto qc) {                  // + residual; PF planes of block q
                 constexpr int q = decltype(qc)::value, n = q / MB, m = q % MB;
                 if constexpr (q < NBLK) {
                     if constexpr (RESID) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][n][r] += rv[q & 1][r];
+                    }
+                    if constexpr (RES3) {                 // += sum_c res3_w[c][co] x[c][pixel]   (conv_pf_kernel.h: same expression)
+                        f32x4 w3[3][4];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w3[c][k] = *reinterpret_cast<const f32x4 *>(epl + (3 + c) * COPT + m * 32 + 8 * k);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[m][n][r] += w3[0][r >> 2][r & 3] * x3[n][0] + w3[1][r >> 2][r & 3] * x3[n][1] + w3[2][r >> 2][r & 3] * x3[n][2];
                     }
                     if constexpr (PF) {
                         // per 8-channel group the lane owns 4 consecutive channels = 8 bytes of each plane's 16-byte unit
@@ -603,6 +632,7 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
 #endif
             if constexpr (SYNC) {                       // free-running; the cross-wave LayerNorm exchange (WM > 1) needs its own barriers
                 ldT(Q0{}); ldT(Q1{}); ldT(Q2{}); ldT(Q3{});   // (both groups are here in the same interval: the counts match)
+                ldX();
                 merge();
                 sums();
                 if constexpr (WM > 1) bar();
