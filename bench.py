@@ -199,21 +199,35 @@ def main():
         value = images / dt
         products = PRODUCTS[arith]
         peak = PEAK_16BIT_MFMA_TFLOPS / products
-        # dominant kernel = the launch shape with the largest total time among the matrix-core convolutions
-        conv_ops = [o for o in ops if o["label"].startswith("conv 3x3 s1") and o["flops"] > 0]
-        groups = {}
-        def launch_key(label):                              # layer shape + which kernel runs it (epilogue variants of one kernel together)
+        # Dominant kernel = the (layer shape, kernel) pair with the largest total time among the 3x3 stride-1 Block convolutions
+        # (the rule of rounds 1-2; epilogue variants of one kernel on one layer shape together).  `by_shape` lists the other
+        # pairs, `families` the totals per kernel function (what rocprofv3 --stats rows add up to).
+        conv_ops = [o for o in ops if o["label"].startswith("conv ") and o["flops"] > 0]
+        FAMILY = {"PF3": "conv_pf3_kernel", "PF": "conv_pf_kernel", "PW": "conv_pw_kernel", "SPLIT2H": "conv_split2_kernel",
+                  "SPLIT2": "conv_split2_kernel", "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel"}
+        def kern_of(label):
             t = label.split()
-            kern = next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2") if k in t), "CONV")
-            return " ".join(t[:6]) + " " + kern
+            return next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
+        def op_bytes(label):                                # input once + output once (+ the residual operand), 4 bytes each
+            t = label.split()
+            cin, cout = (int(v) for v in t[3].split("->"))
+            ho, wo = (int(v) for v in t[t.index("out") + 1].split("x"))
+            st = int(t[2][1:]) if t[2].startswith("s") else 1
+            return 4.0 * B * (cin * ho * wo * st * st + cout * ho * wo * (2 if "+res" in t else 1))
+        fams, groups = {}, {}
         for o in conv_ops:
-            key = launch_key(o["label"])
-            g = groups.setdefault(key, dict(ms=0.0, n=0, flops=o["flops"], label=o["label"], labels=[], res=0))
-            g["ms"] += o["ms"]; g["n"] += 1; g["labels"].append(f'{o["ms"]:.4f} ms  {o["label"]}')
-            g["res"] += 1 if "+res" in o["label"].split() else 0
-        domk, dom = max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else ("", dict(ms=0, n=1, flops=0, label=""))
+            kern = kern_of(o["label"])
+            f = fams.setdefault(FAMILY[kern], dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+            f["ms"] += o["ms"]; f["n"] += 1; f["flops"] += o["flops"]; f["bytes"] += op_bytes(o["label"])
+            key = " ".join(o["label"].split()[:6]) + " " + kern
+            g = groups.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, family=FAMILY[kern], labels=[]))
+            g["ms"] += o["ms"]; g["n"] += 1; g["flops"] += o["flops"]; g["bytes"] += op_bytes(o["label"])
+            g["labels"].append(f'{o["ms"]:.4f} ms  {o["label"]}')
+        cand = {k: g for k, g in groups.items() if k.startswith("conv 3x3 s1")}
+        domk, dom = max(cand.items(), key=lambda kv: kv[1]["ms"]) if cand else ("", dict(ms=0, n=1, flops=0, bytes=0, family="", labels=[]))
         dom_ms = dom["ms"] / max(dom["n"], 1)
-        ach = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        alg_bytes = dom["bytes"] / max(dom["n"], 1)
         cls3 = classes["conv3x3"]
         cls_ach = cls3["flops"] / (cls3["ms"] * 1e-3) / 1e12 if cls3["ms"] > 0 else 0.0
         tot_ms = sum(c["ms"] for c in classes.values())
@@ -222,29 +236,23 @@ def main():
         canon_tf = cfgd["gflop_per_image_step"] * scale * 1e-3 * a.sample_steps * value
         exec_gflop_iter = sum(c["flops"] for c in classes.values()) / n_prof_iters / 1e9     # per batch iteration
         exec_tf = exec_gflop_iter * 1e-3 / B * a.sample_steps * value
-        # counter-based HBM traffic of the dominant launch shape, if a PMC pass of THIS build was committed
+        # counter-based HBM traffic of the dominant pair, if a PMC pass of THIS build was committed for it
+        # (tools/gpu_profiles_r03.sh -> profiles/pmc_r03_traffic.json: {launch key: {...}}, the layer launched alone)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_r03_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                want = f"B{B} " + domk
-                if tj.get("launch") == want and tj.get("arith") == arith:
+                tj = json.load(open(tpath)).get(f"B{B} " + domk)
+                if tj and tj.get("arith") == arith:
                     traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("source")
             except Exception:
                 pass
-        pixels_out = 0
-        try:
-            hw = dom["label"].split("out")[1].split()[0].split("x")
-            cio = dom["label"].split()[3].split("->")
-            pixels_out = int(hw[0]) * int(hw[1])
-            cout = int(dom["label"].split("->")[1].split()[0])
-            # input once + output once, 4 bytes per element (+ the residual operand where the launch
-            # has one: it is an input of the fused epilogue)
-            # (averaged over the launches of the group: `res` of its `n` launches read a residual operand)
-            alg_bytes = 4.0 * B * pixels_out * (int(cio[0]) + cout + cout * dom["res"] / max(dom["n"], 1))
-        except Exception:
-            alg_bytes = None
+        by_shape = sorted(({"launch_key": k, "family": g["family"], "launches_per_iteration": g["n"], "avg_launch_ms": g["ms"] / g["n"],
+                            "achieved": g["flops"] / (g["ms"] * 1e-3) / 1e12, "frac": g["flops"] / (g["ms"] * 1e-3) / 1e12 / peak,
+                            "algorithmic_tb_s": g["bytes"] / (g["ms"] * 1e-3) / 1e12, "launches": g["labels"]}
+                           for k, g in groups.items()), key=lambda r: -r["avg_launch_ms"] * r["launches_per_iteration"])
+        families = {k: {"launches_per_iteration": f["n"], "ms_per_iteration": f["ms"], "achieved": f["flops"] / (f["ms"] * 1e-3) / 1e12,
+                        "frac": f["flops"] / (f["ms"] * 1e-3) / 1e12 / peak} for k, f in fams.items() if f["ms"] > 0}
         out = {
             "metric": f"decoded images/sec at {S}x{S}, {a.sample_steps}-step {a.param}-param",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -261,10 +269,11 @@ def main():
                        "arith": "f16x2" if arith == 1 else "bf16x3"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": dom["label"], "launch_key": domk, "launches": dom.get("labels", []),
-                "kernel_note": "dominant (layer shape, kernel) pair: largest total time among the 3x3 Block convolutions with fused "
-                               "LN epilogue; achieved = its algorithmic flops / the hipEvent-timed average duration of its launches "
-                               "(sampled inside the timed region, on the launch stream)",
+                "kernel": dom["family"], "launch_key": domk, "launches": dom["labels"], "by_shape": by_shape[:8], "families": families,
+                "kernel_note": "dominant (layer shape, kernel) pair: largest total time among the 3x3 stride-1 Block convolutions (epilogue "
+                               "variants of the kernel on that layer shape together); achieved = its algorithmic flops / the hipEvent-timed "
+                               "average duration of its launches (sampled inside the timed region, on the launch stream); by_shape = the "
+                               "next pairs, families = totals per kernel function (the rows rocprofv3 --stats adds up)",
                 "hbm_view": ({"algorithmic_bytes_per_launch": alg_bytes, "achieved_tb_s": alg_bytes / (dom_ms * 1e-3) / 1e12,
                               "frac_of_8tb_s": alg_bytes / (dom_ms * 1e-3) / 8e12} if alg_bytes and dom_ms > 0 else None),
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0,
@@ -272,7 +281,7 @@ def main():
                 "mfma_tflops_executed": ach * products,
                 "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 "avg_launch_ms": dom_ms, "launches_per_iteration": dom["n"],
-                "flops_per_launch": dom["flops"], "algorithmic_bytes_per_launch": alg_bytes,
+                "flops_per_launch": dom["flops"] / max(dom["n"], 1), "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "class_conv3x3": {"achieved": cls_ach, "frac": cls_ach / peak if peak else 0,
                                   "avg_launch_ms": cls3["ms"] / max(cls3["launches"], 1),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 passes of tools/gpu_pmc_path.sh: per kernel (those above 2 % of the GPU time) the average
+"""Summarise the rocprofv3 passes of tools/gpu_pmc_path.sh: per kernel (text: those above 2 % of the GPU time; json: above 0.2 %) the average
 duration, HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; raw value
 beside it), MFMA-busy share of the SIMD-busy cycles, MFMA instructions, LDS bank-conflict share; and the whole-iteration
 HBM byte total next to SURVEY 8(d)'s canonical 0.714 GB per image-step."""
@@ -47,7 +47,7 @@ print(f"rocprofv3 passes over `bench.py --sample-steps {steps}` (batch {B}, 256x
 print(f"{'kernel':<112} {'calls':>6} {'avg us':>9} {'% time':>7} {'HBM MB/launch (x2 corr | raw)':>32} {'TB/s':>6} {'MFMA busy':>10} {'MFMA insts':>11} {'LDS confl':>9}")
 rows = []
 for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
-    if s["pct"] < 2.0:
+    if s["pct"] < 0.2:
         continue
     a, b, c = A.get(k, {}), Bc.get(k, {}), C.get(k, {})
     na, nb, nc = max(nA.get(k, 0), 1), max(nB.get(k, 0), 1), max(nC.get(k, 0), 1)
@@ -60,7 +60,8 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
     tbs = corr / (s["avg_ns"] * 1e-9) / 1e12
     rows.append(dict(kernel=k, calls=s["calls"], avg_us=s["avg_ns"] / 1e3, pct=s["pct"], hbm_mb_corr=corr / 1e6, hbm_mb_raw=raw / 1e6,
                      tb_per_s=tbs, mfma_busy=busy, mfma_insts=b.get("SQ_INSTS_MFMA", 0) / nb, lds_conflict=confl))
-    print(f"{k:<112} {s['calls']:>6} {s['avg_ns'] / 1e3:>9.1f} {s['pct']:>7.2f} {corr / 1e6:>16.1f} | {raw / 1e6:>11.1f} {tbs:>6.2f} {busy:>10.3f} {b.get('SQ_INSTS_MFMA', 0) / nb:>11.0f} {confl:>9.3f}")
+    if s["pct"] >= 2.0:
+        print(f"{k:<112} {s['calls']:>6} {s['avg_ns'] / 1e3:>9.1f} {s['pct']:>7.2f} {corr / 1e6:>16.1f} | {raw / 1e6:>11.1f} {tbs:>6.2f} {busy:>10.3f} {b.get('SQ_INSTS_MFMA', 0) / nb:>11.0f} {confl:>9.3f}")
 # whole path: every dispatch of the pass / number of DDIM iterations (the 2-iteration build decode and the context pre-pass are in: upper bound)
 tot_fetch = sum(v.get("FETCH_SIZE", 0) for v in A.values()) * 1024
 tot_write = sum(v.get("WRITE_SIZE", 0) for v in Wc.values()) * 1024
