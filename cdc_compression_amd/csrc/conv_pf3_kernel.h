@@ -43,6 +43,9 @@ namespace cdc {
 #else
 #define PF3_TL_BYTES 0
 #endif
+#ifndef CDC_PF3_ABL
+#define CDC_PF3_ABL 0        // lab only (tools/ubench/pf_lab.hip): 1 no result stores, 2 no residual loads, 4 no LayerNorm math, 8 no LDS transposes, 16 no PF split
+#endif
 #ifndef CDC_PF3_D
 #define CDC_PF3_D 5          // weight stages are issued D steps ahead; ring = D + 2 slots (a slot is rewritten two steps after its last reader)
 #endif
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             asm volatile("" : "+s"(Pe));
             const Tile T = Tc;
             const long long o_cs = Pe->out_cs, r_cs = Pe->resid_cs, p_ps = Pe->pf_ps;
-            const bool has_ln = Pe->ep_g != nullptr, has_shift = Pe->shift != nullptr;
+            const bool has_ln = !(CDC_PF3_ABL & 4) && Pe->ep_g != nullptr, has_shift = Pe->shift != nullptr;
             const int relu = Pe->relu;
             const float relu_slope = Pe->relu_slope, acc_scale = Pe->acc_scale;
             const float eps_s = Pe->eps / (acc_scale * acc_scale);
@@ -416,7 +419,8 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                     const char *sb = r_base + ((size_t)(m * 32) * r_cs + (size_t)n * o_ys) * 4;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        rvT[q][k] = pf3_ld4(sb, voff_rt);
+                        if (!(CDC_PF3_ABL & 2)) rvT[q][k] = pf3_ld4(sb, voff_rt);
+                        else rvT[q][k] = f32x4{1.f, 2.f, 3.f, 4.f};
                         sb += 8 * r_cs * 4;
                     }
                 }
@@ -425,25 +429,36 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                 constexpr int q = decltype(qc)::value;
                 if constexpr (q < NBLK && RESID) {
                     float *xr = (q & 1) ? xr1 : xr0;
+                    if constexpr ((CDC_PF3_ABL & 8) != 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[q & 1][r] = rvT[q][r >> 2][r & 3];
+                    } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(xr + (Lr + 8 * k) * 32 + Lc * 4) = rvT[q][k];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rv[q & 1][r] = xr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j];
+                    }
                 }
             };
             auto wN_rT_st = [&](auto qc) {                // final values of block q: accumulator layout -> region -> rows -> HBM
                 constexpr int q = decltype(qc)::value, n = q / MB, m = q % MB;
                 if constexpr (q < NBLK && F32) {
                     float *xr = (q & 1) ? xr1 : xr0;
+                    f32x4 rows[4];
+                    if constexpr ((CDC_PF3_ABL & 8) != 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rows[k] = f32x4{acc[m][n][4 * k], acc[m][n][4 * k + 1], acc[m][n][4 * k + 2], acc[m][n][4 * k + 3]};
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) xr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[m][n][r];
-                    f32x4 rows[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) rows[k] = *reinterpret_cast<const f32x4 *>(xr + (Lr + 8 * k) * 32 + Lc * 4);
+                    }
                     char *sb = o_base + ((size_t)(m * 32) * o_cs + (size_t)n * o_ys) * 4;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        pf3_st4(sb, voff_ot, rows[k]);
+                        if (!(CDC_PF3_ABL & 1)) pf3_st4(sb, voff_ot, rows[k]);
+                        else asm volatile("" ::"v"(rows[k]));
                         sb += 8 * o_cs * 4;
                     }
                 }
@@ -583,8 +598,10 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                             }
                             // (completing the 16-byte units in registers with v_permlane32_swap and storing 16 bytes per lane was
                             // tried: no faster -- lanes l / l + 32 each write their 8-byte half)
+                            if (!(CDC_PF3_ABL & 1)) {
                             pf3_st2u(sb, voff_p + (unsigned)half * 8u, hw[0], hw[1]);
                             pf3_st2u(sb + p_ps * 16, voff_p + (unsigned)half * 8u, lw[0], lw[1]);
+                            } else asm volatile("" ::"v"(hw[0]), "v"(hw[1]), "v"(lw[0]), "v"(lw[1]));
                             sb += 2 * p_ps * 16;
                         }
                     }
