@@ -62,11 +62,13 @@ hipError_t pf3_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
     a.lognbw = 5; a.dbg = 0; a.B = B;
     a.tiles_x = a.Wo / 32; a.tiles_y = a.Ho / TH;
     a.n_iter = p.pf3_iters; a.xcd_remap = 1;
-    static bool attr_done[2][32];
-    if (!attr_done[COPT == 128][p.pf3_epv]) {
+    static bool attr_done[16][2][32];                     // per device: a function attribute belongs to the device's copy of the code
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev][COPT == 128][p.pf3_epv]) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf3_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_done[COPT == 128][p.pf3_epv] = true;
+        if (dev >= 0 && dev < 16) attr_done[dev][COPT == 128][p.pf3_epv] = true;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)p.pf3_G, 1, 1), dim3(512), pf3_lds_bytes(), st, a);
     return hipGetLastError();
