@@ -396,10 +396,16 @@ class _ContextDecoder:
     def compress_to_bytes(self, images):
         """images [B, 3, H, W] -> list of B bitstreams (bytes): analysis transform + hyper encoder on the GPU, then the
         range-ANS coder of include/cdc_hip.h (cdc_entropy_encode) over exactly the symbols `bpp()` prices."""
+        latent, hyper = self.analysis(images)
+        return self.latents_to_bytes(latent, hyper)
+
+    def latents_to_bytes(self, latent, hyper):
+        """The UNquantised outputs of `analysis()` -> list of B bitstreams.  The coder's determinism contract starts here: the
+        same (latent, hyper) rows give the same bytes whatever the batch they are coded in (the analysis transform itself is
+        an ordinary batched forward: its last bits may depend on the batch size, like any other entry point's)."""
         L, h = _lib.lib(), self._hyper_handle()
         if not (self._hyper_finalized and self._prior_loaded):
             raise _lib.CdcError("the prior.* tensors have not been loaded (load_state_dict with the full state_dict)")
-        latent, hyper = self.analysis(images)
         al, ah = _Arg(latent, self.device_index), _Arg(hyper, self.device_index)
         B, _, hh, wh = ah.shape
         nsym = int(np.prod(al.shape[1:])) + int(np.prod(ah.shape[1:]))

@@ -236,14 +236,14 @@ def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
     g = np.load(os.path.join(GOLDEN, "kodak_x_500.npz"))
     comp, sd = _full_compressor()
     x = (g["crops"].astype(np.float32).transpose(0, 3, 1, 2) / 255.0 * 2.0 - 1.0).astype(np.float32)
-    streams = comp.compress_to_bytes(x)
+    latent_all, hyper_all = comp.analysis(x)
+    streams = comp.latents_to_bytes(latent_all, hyper_all)
     assert len(streams) == 3
     C = comp.reversed_hyper_dims[0]
     prior = oe.raw_prior(sd, C)
     med = comp._median_vector()
     for b in range(3):
-        xb = x[b:b + 1]
-        latent, hyper = comp.analysis(xb)                       # batch-1 plans, as the coder uses
+        latent, hyper = latent_all[b:b + 1], hyper_all[b:b + 1]
         q_hyper = comp.dequantize(hyper, comp._medians_like(hyper))
         mean, scale = comp.hyper_decode(q_hyper)
         q_latent = comp.dequantize(latent, mean)
@@ -264,7 +264,7 @@ def test_bitstreams_match_the_oracle_byte_for_byte_and_round_trip():
         ideal = oe.ideal_bits_latent(sym_l, scale[0])
         lat_bits = 8 * (len(streams[b]) - oe.HEADER - len(oe.encode_hyper(sym_h, prior, med)[0]))
         assert 0 <= lat_bits - ideal <= 64 * 32 + 64, (lat_bits, ideal)     # 64 lane states of 32 bits on top of the ideal length
-        assert comp.compress_to_bytes(xb)[0] == streams[b]          # batch-3 call == batch-1 call, byte for byte
+        assert comp.latents_to_bytes(latent, hyper)[0] == streams[b]   # batch-3 call == batch-1 call, byte for byte
     # whole batch in one call == per-image calls
     q_all = comp.decompress_from_bytes(streams)
     q_ref = np.concatenate([comp.decompress_from_bytes([s]) for s in streams])
@@ -335,8 +335,9 @@ def test_batch_calls_hold_the_bits_of_single_image_calls_and_mixed_arithmetics_d
     comp, sd = _full_compressor()
     x = synth.normal("img", (7, 3, 64, 128), seed=9, std=0.5)
     x[3] *= 2.5                                                    # (another dynamic range: other scale bins, escapes)
-    streams = comp.compress_to_bytes(x)
-    singles = [comp.compress_to_bytes(x[b:b + 1])[0] for b in range(7)]
+    latent, hyper = comp.analysis(x)
+    streams = comp.latents_to_bytes(latent, hyper)
+    singles = [comp.latents_to_bytes(latent[b:b + 1], hyper[b:b + 1])[0] for b in range(7)]
     assert streams == singles
     q_all, h_all = comp.decompress_from_bytes(streams, return_hyper=True)
     for b in range(7):
@@ -354,3 +355,22 @@ def test_batch_calls_hold_the_bits_of_single_image_calls_and_mixed_arithmetics_d
     q_mixed = comp.decompress_from_bytes(mixed)
     for i, s1 in enumerate(mixed):
         np.testing.assert_array_equal(q_mixed[i:i + 1], comp.decompress_from_bytes([s1]))
+
+
+@pytest.mark.gpu
+def test_full_size_batch_round_trip():
+    """BASELINE configs[1] size (batch 32 at 256 x 256): one encode call, one decode call; the decoder returns the encoder's
+    dequantised latents exactly (they are integer + mean, and the mean is reproduced bit for bit), every stream passes its own
+    end conditions and checksum, and streams picked from the batch equal their single-image encodes."""
+    comp, sd = _full_compressor()
+    x = synth.normal("img", (32, 3, 256, 256), seed=21, std=0.45)
+    latent, hyper = comp.analysis(x)
+    streams = comp.latents_to_bytes(latent, hyper)
+    assert len(streams) == 32 and all(s[:4] == b"CDC\x03" for s in streams)
+    ql, qh = comp.decompress_from_bytes(streams, return_hyper=True)
+    for b in (0, 13, 31):
+        assert comp.latents_to_bytes(latent[b:b + 1], hyper[b:b + 1])[0] == streams[b]
+        q_hyper = comp.dequantize(hyper[b:b + 1], comp._medians_like(hyper[b:b + 1]))
+        mean, scale = comp.hyper_decode(q_hyper)
+        np.testing.assert_array_equal(qh[b:b + 1], q_hyper)
+        np.testing.assert_array_equal(ql[b:b + 1], comp.dequantize(latent[b:b + 1], mean))
