@@ -990,3 +990,40 @@ def test_inference_script_counterpart_on_kodak_crops(tmp_path):
                          str(tmp_path / "out_eps"), "--seed", "3"], capture_output=True, text=True, timeout=900, cwd=root)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert len([l for l in r2.stdout.splitlines() if l.startswith("bpp:")]) == 2
+
+
+@pytest.mark.gpu
+def test_persistent_kernel_variants_in_the_network_match_batch1_plans():
+    """BASELINE configs[1] size: at batch 32 / 256 x 256 the 64- and 128-channel 3x3 layers run on conv_pf3_kernel (every
+    epilogue variant, the 3-channel res_conv of downs.0.0 included); one image at a time none of them does.  Rows of the
+    batch-32 forward must equal the batch-1 forwards to fp32 round-off, and the launch program must really contain the
+    persistent kernel."""
+    import torch
+    import cdc_compression_amd as cdc
+    from cdc_compression_amd import _lib
+    kw, man, sd, _, _, _, _ = load_case("full_x")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, S = 32, 256
+    x = torch.randn((B, 3, S, S), generator=g, device=dev) * 0.8
+    t = torch.full((B, 1), 0.37, device=dev)
+    ctx = [torch.randn((B, c, S >> l, S >> l), generator=g, device=dev) * 0.5 for l, c in enumerate([64, 64, 128, 192])]
+    L, h = _lib.lib(), un._handle()
+    L.cdc_prof_reset(h)
+    L.cdc_prof_enable(h, 1)
+    y = un(x, t, ctx).clone()
+    labels = []
+    for i in range(L.cdc_prof_num_ops(h)):
+        lab, ms, n, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+        labels.append(lab.value.decode())
+    L.cdc_prof_enable(h, 0)
+    pf3 = [l for l in labels if " PF3 " in l]
+    assert len(pf3) >= 10 and any("64->64" in l and "+pf +res" in l and "256x256" in l for l in pf3), pf3
+    assert bool(torch.isfinite(y).all())
+    for b in (0, 17, 31):
+        yb = un(x[b:b + 1], t[b:b + 1], [c[b:b + 1].contiguous() for c in ctx])
+        err = float((yb - y[b:b + 1]).abs().max() / y[b:b + 1].abs().max())
+        assert err < 2e-5, (b, err)
