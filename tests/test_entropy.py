@@ -374,3 +374,36 @@ def test_full_size_batch_round_trip():
         mean, scale = comp.hyper_decode(q_hyper)
         np.testing.assert_array_equal(qh[b:b + 1], q_hyper)
         np.testing.assert_array_equal(ql[b:b + 1], comp.dequantize(latent[b:b + 1], mean))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(64, 64), (64, 192), (128, 64)])
+def test_sections_that_do_not_fill_their_last_iteration(hw):
+    """A small compressor (32 hyper channels): the hyper sections hold 32 / 96 / 64 symbols and the latent sections 512 / 1536 / 1024,
+    so the device coder runs with fewer symbols than lanes, with a half-filled last iteration and with exactly full ones; the
+    product's streams equal the CPU checker's byte for byte and decode exactly."""
+    import cdc_compression_amd as cdc
+    comp = cdc.ResnetCompressor(dim=8, dim_mults=[1, 2, 3, 4], reverse_dim_mults=[4, 3, 2, 1], hyper_dims_mults=[4, 4, 4], channels=3,
+                                out_channels=8)
+    man = comp.manifest() + comp.hyper_manifest() + comp.encoder_manifest()
+    sd = synth.unet_state_dict(man, seed=5)
+    C = comp.reversed_hyper_dims[0]
+    sd.update(_prior_sd(C, seed=7))
+    comp.load_state_dict(sd)
+    x = synth.normal("img", (3, 3) + hw, seed=13, std=0.6)
+    latent, hyper = comp.analysis(x)
+    assert (hyper.shape[1] * hyper.shape[2] * hyper.shape[3]) == {(64, 64): 32, (64, 192): 96, (128, 64): 64}[hw]
+    streams = comp.latents_to_bytes(latent, hyper)
+    prior, med = oe.raw_prior(sd, C), comp._median_vector()
+    ql, qh = comp.decompress_from_bytes(streams, return_hyper=True)
+    for b in range(3):
+        q_hyper = comp.dequantize(hyper[b:b + 1], comp._medians_like(hyper[b:b + 1]))
+        mean, scale = comp.hyper_decode(q_hyper)
+        q_latent = comp.dequantize(latent[b:b + 1], mean)
+        sym_h = np.rint(q_hyper[0] - med[:, None, None]).astype(np.int32)
+        sym_l = np.rint(q_latent[0] - mean[0]).astype(np.int32)
+        ref = oe.stream(1, hyper.shape[2], hyper.shape[3], oe.encode_hyper(sym_h, prior, med), oe.encode_latent(sym_l, scale[0]),
+                        oe.model_hash(prior, med), oe.symbol_hash(sym_h, sym_l))
+        assert streams[b] == ref, (b, len(streams[b]), len(ref))
+        np.testing.assert_array_equal(ql[b:b + 1], q_latent)
+        np.testing.assert_array_equal(qh[b:b + 1], q_hyper)
