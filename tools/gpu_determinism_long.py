@@ -24,3 +24,12 @@ for i in range(150):
     bad += int(not torch.equal(un(x, t, c2), y0))
 print("forward repeats differing:", bad, "of 150")
 assert torch.equal(a, b) and bad == 0
+# the persistent ping-ponged kernel runs only at large batches: repeated batch-32 forwards (two barriers per tap, shared weight
+# ring, LDS transposes in the idle patch buffer) must be bit-identical as well
+t32 = torch.full((B, 1), 0.3, device=dev)
+x32 = torch.randn((B, 3, 256, 256), generator=g, device=dev)
+y32 = un(x32, t32, ctx).clone(); bad32 = 0
+for i in range(60):
+    bad32 += int(not torch.equal(un(x32, t32, ctx), y32))
+print("batch-32 forward repeats differing:", bad32, "of 60")
+assert bad32 == 0
