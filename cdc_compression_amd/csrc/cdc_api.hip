@@ -2440,7 +2440,7 @@ int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *of
         int32_t *symh, *syml;
         uint8_t *bin;
         cdc::RansMeta *meta;
-        float *ql = nullptr, *qh = nullptr;
+        float *ql = nullptr;
         HIP_TRY(h, d.get(&d_off, 2 * (size_t)nb)); HIP_TRY(h, d.get(&d_len, 2 * (size_t)nb)); HIP_TRY(h, d.get(&d_esc, 2 * (size_t)nb));
         HIP_TRY(h, d.get(&symh, (size_t)nb * nh)); HIP_TRY(h, d.get(&syml, (size_t)nb * nl)); HIP_TRY(h, d.get(&bin, (size_t)nb * nl));
         HIP_TRY(h, d.get(&meta, 2 * (size_t)nb));
@@ -2471,7 +2471,6 @@ int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *of
         HIP_TRY(h, cdc::symbols_to_latent_launch(syml, o.p, o.bs(), nl, nb, mem == CDC_MEM_DEVICE ? dst_l : ql, st));
         if (mem != CDC_MEM_DEVICE) HIP_TRY(h, hipMemcpyAsync(dst_l, ql, (size_t)nb * nl * sizeof(float), hipMemcpyDeviceToHost, st));
         if (dst_h) {
-            (void)qh;
             HIP_TRY(h, hipMemcpyAsync(dst_h, h->in_x, (size_t)nb * nh * sizeof(float),
                                       mem == CDC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
         }
