@@ -2350,6 +2350,10 @@ int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_l
     HIP_TRY(h, hipMemsetAsync(bad, 0, sizeof(int), st));
     // hyper symbols; their dequantised values are hyper_dec's input (quantize(.., "dequantize", medians), utils.py:72-85)
     HIP_TRY(h, cdc::hyper_symbols_launch(d_hl, h->ent->d_medians, Ch, per, B, symh, h->in_x, bad, st));
+    int hbad = 0;                                         // (before hyper_dec: garbage input must not trip the range guard)
+    HIP_TRY(h, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (hbad) return fail(h, CDC_ERR_INVALID, "non-finite or out-of-range hyper-latent (nothing to code)");
     int fault = 0;
     if ((rc = hyperdec_batch(h, B, st, guard_enabled(h) && !h->in_retry, &fault))) return rc;
     if (fault) {
@@ -2366,12 +2370,11 @@ int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_l
     HIP_TRY(h, d.get(&packed, (size_t)dev_cap));
     cdc::RansPack P{sec_h, sec_l, esc_h, esc_l, meta, meta + B, cap_h, cap_l, nh, nl, dev_cap, packed, d_off, h->ent_model_hash, h->arith, hh, wh};
     HIP_TRY(h, cdc::rans_pack_launch(P, B, st));
-    int hbad = 0;
     std::vector<long long> hoff((size_t)B + 1);
     HIP_TRY(h, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(hoff.data(), d_off, sizeof(long long) * ((size_t)B + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
-    if (hbad) return fail(h, CDC_ERR_INVALID, "non-finite or out-of-range latent, hyper-latent, mean or scale (nothing to code)");
+    if (hbad) return fail(h, CDC_ERR_INVALID, "non-finite or out-of-range latent, mean or scale (nothing to code)");
     if ((unsigned long long)hoff[B] > (unsigned long long)cap)
         return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: %d image(s) need %lld bytes of %zu", B, hoff[B], cap);
     HIP_TRY(h, hipMemcpy(out, packed, (size_t)hoff[B], hipMemcpyDeviceToHost));

@@ -902,6 +902,8 @@ def test_range_guard_in_the_compressor_entry_points():
     comp2 = _small_compressor()
     with pytest.raises(_lib.CdcError, match="non-finite"):
         comp2.compress_to_bytes(img * np.float32(np.nan))
+    # ... and garbage input is refused BEFORE hyper_dec runs: it must not cost the hyper-decoder handle its fast arithmetic
+    assert comp2.status()["hyper_dec"] == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}
 
 
 def test_model_follows_device_change_after_load():
