@@ -138,6 +138,7 @@ struct cdc_handle {
     int shift_bs = 0;
     // program
     int pB = 0, pH = 0, pW = 0;
+    bool retry_futile = false;    // range guard: the BF16X3 repetition was non-finite too
     bool p_batch1_plan = false;   // the program was planned as for one image (entropy coder contract, entropy.hip)
     std::vector<Op> ops;          // per DDIM iteration (depends on x_t and t)
     std::vector<Op> pre_ops;      // depends on the context pyramid only: once per decode / forward
@@ -1795,7 +1796,11 @@ int guard_check(cdc_handle *h, std::initializer_list<GuardBuf> bufs, int B, hipS
 // a fault in F16X2: switch to the full-range arithmetic (returns true: repeat the call); a fault in the repetition: count it
 bool guard_escalate(cdc_handle *h, int *rc) {
     *rc = CDC_OK;
-    if (h->in_retry || h->arith != CDC_ARITH_F16X2) { ++h->nonfinite_results; return false; }
+    if (h->in_retry || h->arith != CDC_ARITH_F16X2) {
+        ++h->nonfinite_results;
+        if (h->in_retry) h->retry_futile = true;            // non-finite in the full-range arithmetic too: it was not the fp16 range
+        return false;
+    }
     ++h->range_faults;
     static bool warned = false;
     if (!warned) {
@@ -1806,7 +1811,20 @@ bool guard_escalate(cdc_handle *h, int *rc) {
     *rc = cdc_set_arith(h, CDC_ARITH_BF16X3);
     return *rc == CDC_OK;
 }
-struct RetryScope { cdc_handle *h; explicit RetryScope(cdc_handle *h_) : h(h_) { h->in_retry = true; } ~RetryScope() { h->in_retry = false; } };
+// The repetition of a call in BF16X3.  When that result is non-finite as well (a NaN / inf in the inputs or the parameters), the
+// range was not the cause: the handle goes back to F16X2 and the fault is counted in nonfinite_results only.
+struct RetryScope {
+    cdc_handle *h;
+    explicit RetryScope(cdc_handle *h_) : h(h_) { h->in_retry = true; h->retry_futile = false; }
+    ~RetryScope() {
+        h->in_retry = false;
+        if (h->retry_futile) {
+            h->retry_futile = false;
+            if (h->range_faults > 0) --h->range_faults;
+            (void)cdc_set_arith(h, CDC_ARITH_F16X2);
+        }
+    }
+};
 }  // namespace
 
 namespace {

@@ -88,8 +88,9 @@ const char *cdc_version(void);
  *                              CDC_ARITH_BF16X3.  The handle then STAYS in that mode (a warning is printed once;
  *                              cdc_get_arith / cdc_get_range_faults tell).  Results that are non-finite in the full-range
  *                              arithmetic too (non-finite inputs, parameters beyond fp32) come back as they are, as the
- *                              reference's would (counted by cdc_get_nonfinite_results).  CDC_NO_RANGE_GUARD=1 in the
- *                              environment switches the check off.
+ *                              reference's would (counted by cdc_get_nonfinite_results); the range was not their cause,
+ *                              so such a call leaves the handle in CDC_ARITH_F16X2 and is not counted as a range fault.
+ *                              CDC_NO_RANGE_GUARD=1 in the environment switches the check off.
  *   CDC_ARITH_BF16X3           a = a1 + a2 + a3 exactly as three bf16 numbers: six v_mfma_f32_32x32x16_bf16,
  *                              full fp32 range.
  * Changing the mode drops the handle's launch program (rebuilt on the next call).  New handles take
