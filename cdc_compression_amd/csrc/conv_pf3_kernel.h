@@ -61,7 +61,7 @@ __host__ __device__ constexpr size_t pf3_lds_bytes() { return 163840; }
 __host__ __device__ constexpr size_t pf3_lds_used(int MB, int NPW, int WM, int WP, int B) {
     const size_t copt = (size_t)WM * MB * 32;
     return (size_t)(4 * pf3_pst(NPW, WP) + (CDC_PF3_D + 2) * 4 * (int)copt) * 16 +
-           sizeof(float) * (((WM == 1 ? 6 : 3) + (size_t)B) * copt + (size_t)2 * 2 * WM * WP * NPW * 32) + 4 * 4096 + PF3_TL_BYTES;
+           sizeof(float) * (((WM == 1 ? 6 : 3) + (size_t)8 + (size_t)(0 * B)) * copt +      /* parameter rows + one shift row per wave */ (size_t)2 * 2 * WM * WP * NPW * 32) + 4 * 4096 + PF3_TL_BYTES;
 }
 
 // ---- static vector-memory schedule of a wave -----------------------------------------------------------------------
@@ -177,9 +177,9 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
     // ---- LDS map: [group 0: patch 0, patch 1][group 1: patch 0, patch 1][weight ring][epilogue parameters] ... [scratch]
     uint4 *patch_g = smem_u + grp * 2 * PST;
     uint4 *ring = smem_u + 4 * PST;
-    float *ep = reinterpret_cast<float *>(smem_u + 4 * PST + R * WST);    // bias / scale, ln g, ln b (, res3 weights): [EPR][COPT]; shift [B][COPT]
-    float *epsh = ep + EPR * COPT;
-    float *red = epsh + (P.shift ? P.B * COPT : 0) + grp * (2 * WM * WP * NPW * 32);
+    float *ep = reinterpret_cast<float *>(smem_u + 4 * PST + R * WST);    // bias / scale, ln g, ln b (, res3 weights): [EPR][COPT]
+    float *epsh = ep + EPR * COPT + wave8 * COPT;                         // this wave's copy of its tile's shift row: [8][COPT]
+    float *red = ep + (EPR + 8) * COPT + grp * (2 * WM * WP * NPW * 32);
     float *ex = reinterpret_cast<float *>(smem_u) + (163840 - 4 * 4096 - (PF3_TL_BYTES)) / 4;   // 4 KiB per wave of the group in its epilogue
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
     const unsigned patch_lds = lds0 + (unsigned)(grp * 2 * PST) * 16u;
@@ -290,11 +290,6 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
         if constexpr (RES3)
             for (int c = 0; c < 3; ++c) ep[(3 + c) * COPT + i] = ok ? P.res3_w[(size_t)c * P.COP + co] : 0.f;
     }
-    if (P.shift)
-        for (int i = tid; i < P.B * COPT; i += 512) {
-            const int bb = i / COPT, c = i - bb * COPT;
-            epsh[i] = (cog * COPT + c < P.Cout) ? P.shift[(size_t)bb * P.shift_bs + cog * COPT + c] : 0.f;
-        }
     for (int q = 0; q < D; ++q) issue_w();
     {
         const char *src = patch_src(Tc, 0);
@@ -392,7 +387,13 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             f32x4 rvT[NBLK][4];                           // residual operand, row layout
             float rv[2][16];                              // ... of the two blocks in flight, accumulator layout
             const int slot_i = (wp * NPW) * 32 + j;
-            const float *shl = epsh + T.b * COPT + wm * MB * 32 + 4 * half;
+            // the per-image shift row of this tile: every wave keeps its own copy (no barrier; a row per image of the batch did not
+            // fit next to the ring beyond batch 32)
+            if (has_shift) {
+                const float *srow = Pe->shift + (size_t)T.b * Pe->shift_bs + cog * COPT;
+                for (int i = lane; i < COPT; i += 64) epsh[i] = (cog * COPT + i < Pe->Cout) ? srow[i] : 0.f;
+            }
+            const float *shl = epsh + wm * MB * 32 + 4 * half;
             // private LDS regions of this wave: block q uses region q & 1 (the group's idle patch buffer / the scratch area)
             // (SYNC: tau already points at the next tile's first patch; the buffer of the tile's last chunk is the idle one, and both
             // groups are in their epilogue at once -> one region per wave)
