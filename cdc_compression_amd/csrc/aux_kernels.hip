@@ -196,9 +196,10 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache) {
-        static const int pl8_max = dev_env("CDC_LN_PL8_MAX") ? atoi(dev_env("CDC_LN_PL8_MAX")) : 256;
+        static const int pl8_max = dev_env("CDC_LN_PL8_MAX") ? atoi(dev_env("CDC_LN_PL8_MAX")) : 64;
         // 8-pixel workgroups also wherever 32-pixel ones would leave most of the chip idle (small batches)
-        const bool pl8 = a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < 1024;
+        static const int min_wgs = dev_env("CDC_LN_MIN_WGS") ? atoi(dev_env("CDC_LN_MIN_WGS")) : 256;    // (measured at batch 32: 16x16 maps are faster on 32-pixel workgroups, 128-byte rows)
+        const bool pl8 = a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < min_wgs;
         const dim3 grid((unsigned)ceil_div(a.HW, pl8 ? 8 : 32), (unsigned)B);
 #define CDC_LN_LAUNCH(PLV, NPV) hipLaunchKernelGGL((ln_kernel_sliced<PLV, NPV>), grid, dim3(256), 0, st, a)
         if (pl8) {
