@@ -23,6 +23,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL / CUDA-tensor sharing fail with "hipIpcGetMemHandle: invalid
+# argument" otherwise); set before torch / HIP initialise, for every rank torchrun starts from this script
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # canonical (reference op list, fused-minimum bytes) work per image and DDIM iteration at 256x256;
 # both scale with the pixel count.
@@ -90,6 +93,222 @@ def cpu_baseline(param, size, sample_steps, n_iter=4):
             "reference_probe": REFERENCE_PROBE}
 
 
+def arith_name(arith):
+    return "f16x2" if arith == 1 else "bf16x3"
+
+
+def dtype_label(arith):
+    """`dtype` of the JSON line: float32 tensors and accumulation, products formed on the 16-bit matrix cores."""
+    return "f32 (f16x2 split products)" if arith == 1 else "f32 (bf16x3 split products)"
+
+
+def build_model(param, local):
+    import cdc_compression_amd as cdc
+    from cdc_compression_amd import synth
+    cfgd = FULL[param]
+    un = cdc.Unet(**cfgd["kw"], device=local)
+    un.load_state_dict(synth.unet_state_dict(un.manifest(), seed=0, final_gain=0.2 if param == "eps" else 1.0))
+    if param == "x":
+        diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=cfgd["T"], pred_mode="x", var_schedule=cfgd["vs"])
+    else:
+        diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=cfgd["T"], clip_noise="none", pred_mode="noise",
+                                        var_schedule=cfgd["vs"])
+    return un, diff, cfgd
+
+
+def make_inputs(cfgd, B, S, dev, seed):
+    import torch
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    init = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8          # gamma 0.8
+    ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5 for l, c in enumerate(cfgd["ctx"])]
+    return init, ctx, gen
+
+
+def read_prof(L, h):
+    """Per-class and per-op hipEvent tables of the handle (sampled DDIM iterations inside the timed region)."""
+    classes = {}
+    for c in range(L.cdc_prof_num_classes()):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        L.cdc_prof_get(h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+        classes[L.cdc_prof_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    ops = []
+    for i in range(L.cdc_prof_num_ops(h)):
+        lab, ms, n, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+        if n.value:
+            ops.append(dict(label=lab.value.decode(), ms=ms.value / n.value, n=n.value, flops=fl.value))
+    return classes, ops
+
+
+FAMILY = {"PF3": "conv_pf3_kernel", "PF": "conv_pf_kernel", "PW": "conv_pw_kernel", "SPLIT2H": "conv_split2_kernel",
+          "SPLIT2": "conv_split2_kernel", "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel"}
+
+
+def kern_of(label):
+    t = label.split()
+    return next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
+
+
+def op_bytes(label, B):
+    """input once + output once (+ the residual operand), 4 bytes each."""
+    t = label.split()
+    cin, cout = (int(v) for v in t[3].split("->"))
+    ho, wo = (int(v) for v in t[t.index("out") + 1].split("x"))
+    st = int(t[2][1:]) if t[2].startswith("s") else 1
+    return 4.0 * B * (cin * ho * wo * st * st + cout * ho * wo * (2 if "+res" in t else 1))
+
+
+def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cfgd, prof_every, full=True):
+    """The `roofline` object of the JSON line.  Dominant kernel = the (layer shape, kernel) pair with the largest total time among
+    the 3x3 stride-1 Block convolutions (the rule of rounds 1-3; epilogue variants of one kernel on one layer shape together);
+    `by_shape` lists the other pairs, `families` the totals per kernel function (what rocprofv3 --stats rows add up to)."""
+    products = PRODUCTS[arith]
+    peak = PEAK_16BIT_MFMA_TFLOPS / products
+    conv_ops = [o for o in ops if o["label"].startswith("conv ") and o["flops"] > 0]
+    fams, groups = {}, {}
+    for o in conv_ops:
+        kern = kern_of(o["label"])
+        f = fams.setdefault(FAMILY[kern], dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+        f["ms"] += o["ms"]; f["n"] += 1; f["flops"] += o["flops"]; f["bytes"] += op_bytes(o["label"], B)
+        key = " ".join(o["label"].split()[:6]) + " " + kern
+        g = groups.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, family=FAMILY[kern], labels=[], raw=[]))
+        g["ms"] += o["ms"]; g["n"] += 1; g["flops"] += o["flops"]; g["bytes"] += op_bytes(o["label"], B)
+        g["labels"].append(f'{o["ms"]:.4f} ms  {o["label"]}')
+        g["raw"].append(o["label"])
+    cand = {k: g for k, g in groups.items() if k.startswith("conv 3x3 s1")}
+    domk, dom = max(cand.items(), key=lambda kv: kv[1]["ms"]) if cand else ("", dict(ms=0, n=1, flops=0, bytes=0, family="", labels=[], raw=[]))
+    dom_ms = dom["ms"] / max(dom["n"], 1)
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    alg_bytes = dom["bytes"] / max(dom["n"], 1)
+    out = {"bound": "mfma", "kernel": dom["family"], "launch_key": domk, "launches": dom["labels"],
+           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0,
+           "avg_launch_ms": dom_ms, "launches_per_iteration": dom["n"],
+           "ms_per_ddim_iter": dt / steps / sample_steps * 1e3}
+    if not full:
+        return out
+    cls3 = classes["conv3x3"]
+    cls_ach = cls3["flops"] / (cls3["ms"] * 1e-3) / 1e12 if cls3["ms"] > 0 else 0.0
+    tot_ms = sum(c["ms"] for c in classes.values())
+    n_prof_iters = max(1, len([i for i in range(sample_steps) if i % max(2, prof_every) == 0]) * steps)
+    scale = (S / 256.0) ** 2
+    canon_tf = cfgd["gflop_per_image_step"] * scale * 1e-3 * sample_steps * value
+    exec_gflop_iter = sum(c["flops"] for c in classes.values()) / n_prof_iters / 1e9     # per batch iteration
+    exec_tf = exec_gflop_iter * 1e-3 / B * sample_steps * value
+    # Counter-based HBM traffic of the dominant pair, if PMC passes of THIS round's build were committed for it
+    # (tools/gpu_profiles_r04.sh -> profiles/pmc_r04_traffic.json: {op label: {...}}, per-dispatch FETCH_SIZE / WRITE_SIZE of the
+    # whole-path passes matched to the launch program's op labels).  `traffic` is the mean over the SAME launches that
+    # `algorithmic_bytes_per_launch` averages (every epilogue variant of the pair), so the two figures compare like with like.
+    traffic, traffic_src, traffic_variants = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_r04_traffic.json")
+    if os.path.exists(tpath) and dom["raw"]:
+        try:
+            tj = json.load(open(tpath))
+            per = tj.get("ops", {}) if tj.get("batch") == B and tj.get("arith") == arith_name(arith) else {}
+            rows = [per.get(lab) for lab in dom["raw"]]
+            if rows and all(rows):
+                traffic = sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
+                traffic_src = tj.get("source")
+                traffic_variants = [{"launch": lab, "hbm_bytes_corrected": r["hbm_bytes_corrected"], "hbm_bytes_raw": r["hbm_bytes_raw"],
+                                     "algorithmic_bytes": op_bytes(lab, B)} for lab, r in zip(dom["raw"], rows)]
+        except Exception:
+            pass
+    by_shape = sorted(({"launch_key": k, "family": g["family"], "launches_per_iteration": g["n"], "avg_launch_ms": g["ms"] / g["n"],
+                        "achieved": g["flops"] / (g["ms"] * 1e-3) / 1e12, "frac": g["flops"] / (g["ms"] * 1e-3) / 1e12 / peak,
+                        "algorithmic_tb_s": g["bytes"] / (g["ms"] * 1e-3) / 1e12, "launches": g["labels"]}
+                       for k, g in groups.items()), key=lambda r: -r["avg_launch_ms"] * r["launches_per_iteration"])
+    families = {k: {"launches_per_iteration": f["n"], "ms_per_iteration": f["ms"], "achieved": f["flops"] / (f["ms"] * 1e-3) / 1e12,
+                    "frac": f["flops"] / (f["ms"] * 1e-3) / 1e12 / peak} for k, f in fams.items() if f["ms"] > 0}
+    out.update({
+        "by_shape": by_shape[:8], "families": families,
+        "kernel_note": "dominant (layer shape, kernel) pair: largest total time among the 3x3 stride-1 Block convolutions (epilogue "
+                       "variants of the kernel on that layer shape together); achieved = its algorithmic flops / the hipEvent-timed "
+                       "average duration of its launches (sampled inside the timed region, on the launch stream); by_shape = the "
+                       "next pairs, families = totals per kernel function (the rows rocprofv3 --stats adds up)",
+        "hbm_view": ({"algorithmic_bytes_per_launch": alg_bytes, "achieved_tb_s": alg_bytes / (dom_ms * 1e-3) / 1e12,
+                      "frac_of_8tb_s": alg_bytes / (dom_ms * 1e-3) / 8e12} if alg_bytes and dom_ms > 0 else None),
+        "peak_basis": f"2500 TFLOP/s dense 16-bit MFMA / {products} products per algorithmic fp32 product",
+        "mfma_tflops_executed": ach * products,
+        "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+        "flops_per_launch": dom["flops"] / max(dom["n"], 1), "algorithmic_bytes_per_launch": alg_bytes,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_by_variant": traffic_variants,
+        "traffic_note": "mean corrected counter bytes (FETCH_SIZE x2 + WRITE_SIZE) over the same launches that algorithmic_bytes_per_launch "
+                        "averages; null when no PMC pass of this build / batch / arithmetic is committed",
+        "class_conv3x3": {"achieved": cls_ach, "frac": cls_ach / peak if peak else 0,
+                          "avg_launch_ms": cls3["ms"] / max(cls3["launches"], 1),
+                          "flops_per_launch": cls3["flops"] / max(cls3["launches"], 1)},
+        # SURVEY 8(d): whole-path terms.  canonical = the reference's op list (what a user gets per image);
+        # executed = what the launch program really multiplies (context hoisting removes ~25 %)
+        "whole_path_tflops_canonical": canon_tf,
+        "whole_path_tflops_executed": exec_tf,
+        "whole_path_mfma_frac_canonical": canon_tf / peak, "whole_path_mfma_frac_executed": exec_tf / peak,
+        "whole_path_hbm_frac": ((cfgd["gb_per_image_step"] * scale + 0.160 / B) * 1e9 * sample_steps * value) / 8e12,
+        "whole_path_hbm_note": "north_star's >= 40 % of the HBM roofline is not reachable in fp32-class arithmetic "
+                               "(AI ~180 flop/B vs a ridge of ~100-300): the path is matrix-bound (SURVEY section 7)",
+        "class_ms_share": {k: (v["ms"] / tot_ms if tot_ms else 0) for k, v in classes.items()},
+        "class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0) for k, v in classes.items()},
+        # algorithmic bytes of the class (each op: its inputs once + its outputs once) / its time
+        "class_tb_per_s": {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0) for k, v in classes.items()},
+        "class_ms_per_ddim_iter": {k: v["ms"] / n_prof_iters for k, v in classes.items()},
+    })
+    return out
+
+
+def verify_rows(decode_fn, init, ctx, rec, B, sample_steps):
+    """Rows 0 and B-1 of a timed decode decoded again on their own (batch-1 launch plans: different kernels, K splits and
+    summation orders) must agree; also the batch-1 latency (what the reference's test scripts run: one image per call)."""
+    import torch
+    rows, errs, t1 = (0, B - 1), [], 0.0
+    for k in rows:
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        r1 = decode_fn(init[k:k + 1], [c[k:k + 1] for c in ctx])
+        torch.cuda.synchronize()
+        t1 += time.perf_counter() - ta
+        den = max(1.0, float(rec[k].abs().max().item()))
+        errs.append(float((r1[0] - rec[k]).abs().max().item()) / den)
+    verify = {"rows": list(rows), "max_rel_err_vs_batch1_decode": max(errs), "tolerance": 1e-4, "ok": bool(max(errs) <= 1e-4)}
+    batch1 = {"images_per_s": len(rows) / t1, "ms_per_ddim_iter": t1 / len(rows) / sample_steps * 1e3,
+              "note": "one image per call, same model and step count (the reference test scripts' mode)"}
+    return verify, batch1
+
+
+def other_config(param, B, S, sample_steps, local, dev, prof_every):
+    """One timed decode of another BASELINE.json configuration (same code path as the headline workload, its own model and
+    launch program), verified against batch-1 decodes of two rows.  Reported beside the headline, never inside `value`."""
+    import torch
+    from cdc_compression_amd import _lib
+    un, diff, cfgd = build_model(param, local)
+    init, ctx, _ = make_inputs(cfgd, B, S, dev, 2000)
+
+    def decode_fn(i, c, steps=None):
+        return diff.decompress(c, (c[0].shape[0], 3, S, S), sample_steps=steps or sample_steps, init=i)
+
+    decode_fn(init, ctx, steps=2)
+    L, h = _lib.lib(), un._handle()
+    L.cdc_prof_reset(h)
+    L.cdc_prof_enable(h, max(2, prof_every))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec = decode_fn(init, ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    classes, ops = read_prof(L, h)
+    L.cdc_prof_enable(h, 0)
+    arith = L.cdc_get_arith(h)
+    value = B / dt
+    rl = roofline_block(classes, ops, B, S, arith, value, sample_steps, 1, dt, cfgd, prof_every, full=False)
+    verify, batch1 = verify_rows(decode_fn, init, ctx, rec, B, sample_steps)
+    res = {"workload": workload_name(param, B, S, sample_steps, 1), "value": value, "unit": "images/s", "ms_per_step": dt * 1e3,
+           "ms_per_ddim_iter": dt / sample_steps * 1e3, "dtype": dtype_label(arith),
+           "finite": bool(torch.isfinite(rec).all().item()) and verify["ok"],
+           "roofline": {k: rl[k] for k in ("kernel", "launch_key", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+           "whole_path_tflops_canonical": cfgd["gflop_per_image_step"] * (S / 256.0) ** 2 * 1e-3 * sample_steps * value,
+           "verify": verify, "batch1_ms_per_ddim_iter": batch1["ms_per_ddim_iter"], "range_guard": _lib.handle_status(h),
+           "note": "one timed decode, inputs resident in HBM, outside `value`"}
+    del diff, un
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,10 +318,15 @@ def main():
     ap.add_argument("--sample-steps", type=int, default=None, help="DDIM iterations (default 500 x-param, 1000 eps-param)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--param", choices=["x", "eps"], default="x")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend: nccl = RCCL over xGMI (one rank per GPU); gloo lets several ranks share one GPU "
+                         "(dry run of the multi-rank path on a 1-GPU box: rank r uses cuda:(LOCAL_RANK mod device count))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the B=1 re-decode of two output rows")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra decode in the exact bf16x3 arithmetic")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational compressor / entropy coder legs (profiling runs)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the timed decodes of BASELINE configs[2] and configs[4]")
+    ap.add_argument("--dump-ops", default=None, help="write the launch program's op labels (program order) to this file (profiling tools)")
     ap.add_argument("--prof-every", type=int, default=50)
     a = ap.parse_args()
     if a.sample_steps is None:
@@ -117,29 +341,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if a.backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ       # under torchrun always (exercises the RCCL path at N=1 too)
     dist = None
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    cfgd = FULL[a.param]
-    un = cdc.Unet(**cfgd["kw"], device=local)
-    un.load_state_dict(synth.unet_state_dict(un.manifest(), seed=0,
-                                             final_gain=0.2 if a.param == "eps" else 1.0))
-    if a.param == "x":
-        diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=cfgd["T"], pred_mode="x",
-                                      var_schedule=cfgd["vs"])
-    else:
-        diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=cfgd["T"], clip_noise="none",
-                                        pred_mode="noise", var_schedule=cfgd["vs"])
+    un, diff, cfgd = build_model(a.param, local)
     B, S = a.batch, a.size
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    init = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8          # gamma 0.8
-    ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5
-           for l, c in enumerate(cfgd["ctx"])]
+    init, ctx, gen = make_inputs(cfgd, B, S, dev, 1000 + rank)
 
     def decode_fn(i, c, steps=None):
         return diff.decompress(c, (c[0].shape[0], 3, S, S), sample_steps=steps or a.sample_steps, init=i)
@@ -176,88 +393,38 @@ def main():
     ok = bool(torch.isfinite(full).all().item()) and tuple(full.shape) == (B * world, 3, S, S)
     arith = L.cdc_get_arith(h)
 
-    classes = {}
-    for c in range(L.cdc_prof_num_classes()):
-        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-        L.cdc_prof_get(h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
-        classes[L.cdc_prof_name(c).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value,
-                                                   bytes=by.value)
-    ops = []
-    for i in range(L.cdc_prof_num_ops(h)):
-        lab, ms, n, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
-        if n.value:
-            ops.append(dict(label=lab.value.decode(), ms=ms.value / n.value, n=n.value, flops=fl.value))
+    classes, ops = read_prof(L, h)
     L.cdc_prof_enable(h, 0)
     if rank == 0 and os.environ.get("CDC_BENCH_OPS"):       # development aid: per-op table (hipEvent averages) on stderr
         order = ops if os.environ.get("CDC_BENCH_OPS_ORDER") else sorted(ops, key=lambda o: -o["ms"])   # program order / by time
         for o in order[: int(os.environ["CDC_BENCH_OPS"])]:
             print(f'[op] {o["ms"]:8.4f} ms  {o["flops"] / max(o["ms"], 1e-9) / 1e9:7.1f} TF  {o["label"]}', file=sys.stderr)
+    if rank == 0 and a.dump_ops:
+        with open(a.dump_ops, "w") as f:
+            for i in range(L.cdc_prof_num_ops(h)):
+                lab, ms, n, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+                L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+                f.write(lab.value.decode() + "\n")
+
+    # rows of every rank's shard against batch-1 decodes on rank 0 would need the other ranks' inputs: every rank checks its own
+    shard_ok = 1.0
+    if world > 1 and not a.no_verify:
+        v, _ = verify_rows(decode_fn, init, ctx, rec, B, a.sample_steps)
+        shard_ok = 1.0 if v["ok"] else 0.0
+    if use_dist:
+        t = torch.tensor([shard_ok], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        shard_ok = float(t.item())
 
     if rank == 0:
         images = B * world * a.steps
         value = images / dt
-        products = PRODUCTS[arith]
-        peak = PEAK_16BIT_MFMA_TFLOPS / products
-        # Dominant kernel = the (layer shape, kernel) pair with the largest total time among the 3x3 stride-1 Block convolutions
-        # (the rule of rounds 1-2; epilogue variants of one kernel on one layer shape together).  `by_shape` lists the other
-        # pairs, `families` the totals per kernel function (what rocprofv3 --stats rows add up to).
-        conv_ops = [o for o in ops if o["label"].startswith("conv ") and o["flops"] > 0]
-        FAMILY = {"PF3": "conv_pf3_kernel", "PF": "conv_pf_kernel", "PW": "conv_pw_kernel", "SPLIT2H": "conv_split2_kernel",
-                  "SPLIT2": "conv_split2_kernel", "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel"}
-        def kern_of(label):
-            t = label.split()
-            return next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
-        def op_bytes(label):                                # input once + output once (+ the residual operand), 4 bytes each
-            t = label.split()
-            cin, cout = (int(v) for v in t[3].split("->"))
-            ho, wo = (int(v) for v in t[t.index("out") + 1].split("x"))
-            st = int(t[2][1:]) if t[2].startswith("s") else 1
-            return 4.0 * B * (cin * ho * wo * st * st + cout * ho * wo * (2 if "+res" in t else 1))
-        fams, groups = {}, {}
-        for o in conv_ops:
-            kern = kern_of(o["label"])
-            f = fams.setdefault(FAMILY[kern], dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
-            f["ms"] += o["ms"]; f["n"] += 1; f["flops"] += o["flops"]; f["bytes"] += op_bytes(o["label"])
-            key = " ".join(o["label"].split()[:6]) + " " + kern
-            g = groups.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, family=FAMILY[kern], labels=[]))
-            g["ms"] += o["ms"]; g["n"] += 1; g["flops"] += o["flops"]; g["bytes"] += op_bytes(o["label"])
-            g["labels"].append(f'{o["ms"]:.4f} ms  {o["label"]}')
-        cand = {k: g for k, g in groups.items() if k.startswith("conv 3x3 s1")}
-        domk, dom = max(cand.items(), key=lambda kv: kv[1]["ms"]) if cand else ("", dict(ms=0, n=1, flops=0, bytes=0, family="", labels=[]))
-        dom_ms = dom["ms"] / max(dom["n"], 1)
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        alg_bytes = dom["bytes"] / max(dom["n"], 1)
-        cls3 = classes["conv3x3"]
-        cls_ach = cls3["flops"] / (cls3["ms"] * 1e-3) / 1e12 if cls3["ms"] > 0 else 0.0
-        tot_ms = sum(c["ms"] for c in classes.values())
-        n_prof_iters = max(1, len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps)
         scale = (S / 256.0) ** 2
-        canon_tf = cfgd["gflop_per_image_step"] * scale * 1e-3 * a.sample_steps * value
-        exec_gflop_iter = sum(c["flops"] for c in classes.values()) / n_prof_iters / 1e9     # per batch iteration
-        exec_tf = exec_gflop_iter * 1e-3 / B * a.sample_steps * value
-        # counter-based HBM traffic of the dominant pair, if a PMC pass of THIS build was committed for it
-        # (tools/gpu_profiles_r03.sh -> profiles/pmc_r03_traffic.json: {launch key: {...}}, the layer launched alone)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_r03_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath)).get(f"B{B} " + domk)
-                if tj and tj.get("arith") == arith:
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], tj.get("source")
-            except Exception:
-                pass
-        by_shape = sorted(({"launch_key": k, "family": g["family"], "launches_per_iteration": g["n"], "avg_launch_ms": g["ms"] / g["n"],
-                            "achieved": g["flops"] / (g["ms"] * 1e-3) / 1e12, "frac": g["flops"] / (g["ms"] * 1e-3) / 1e12 / peak,
-                            "algorithmic_tb_s": g["bytes"] / (g["ms"] * 1e-3) / 1e12, "launches": g["labels"]}
-                           for k, g in groups.items()), key=lambda r: -r["avg_launch_ms"] * r["launches_per_iteration"])
-        families = {k: {"launches_per_iteration": f["n"], "ms_per_iteration": f["ms"], "achieved": f["flops"] / (f["ms"] * 1e-3) / 1e12,
-                        "frac": f["flops"] / (f["ms"] * 1e-3) / 1e12 / peak} for k, f in fams.items() if f["ms"] > 0}
         out = {
             "metric": f"decoded images/sec at {S}x{S}, {a.sample_steps}-step {a.param}-param",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_label(arith), "data": "synthetic",
             "dtype_note": ("float32 tensors and accumulation; convolution products formed on the 16-bit matrix cores from "
                            + ("two-plane fp16 split operands (3 MFMA products per fp32 product; operands carry 22-23 significant "
                               "bits, not 24; |activation| < 65504 or the range guard repeats the call in bf16x3 -- see `range_guard`, "
@@ -266,60 +433,18 @@ def main():
             "config": {"workload": workload_name(a.param, B, S, a.sample_steps, world),
                        "batch_per_gpu": B, "global_batch": B * world, "sample_steps": a.sample_steps, "size": S,
                        "parallelism": f"batch-shard x{world}", "finite": ok, "rccl_ranks_seen": ranks_seen,
-                       "arith": "f16x2" if arith == 1 else "bf16x3"},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": dom["family"], "launch_key": domk, "launches": dom["labels"], "by_shape": by_shape[:8], "families": families,
-                "kernel_note": "dominant (layer shape, kernel) pair: largest total time among the 3x3 stride-1 Block convolutions (epilogue "
-                               "variants of the kernel on that layer shape together); achieved = its algorithmic flops / the hipEvent-timed "
-                               "average duration of its launches (sampled inside the timed region, on the launch stream); by_shape = the "
-                               "next pairs, families = totals per kernel function (the rows rocprofv3 --stats adds up)",
-                "hbm_view": ({"algorithmic_bytes_per_launch": alg_bytes, "achieved_tb_s": alg_bytes / (dom_ms * 1e-3) / 1e12,
-                              "frac_of_8tb_s": alg_bytes / (dom_ms * 1e-3) / 8e12} if alg_bytes and dom_ms > 0 else None),
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0,
-                "peak_basis": f"2500 TFLOP/s dense 16-bit MFMA / {products} products per algorithmic fp32 product",
-                "mfma_tflops_executed": ach * products,
-                "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                "avg_launch_ms": dom_ms, "launches_per_iteration": dom["n"],
-                "flops_per_launch": dom["flops"] / max(dom["n"], 1), "algorithmic_bytes_per_launch": alg_bytes,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "class_conv3x3": {"achieved": cls_ach, "frac": cls_ach / peak if peak else 0,
-                                  "avg_launch_ms": cls3["ms"] / max(cls3["launches"], 1),
-                                  "flops_per_launch": cls3["flops"] / max(cls3["launches"], 1)},
-                # whole-path terms.  canonical = the reference's op list (what a user gets per image);
-                # executed = what the launch program really multiplies (context hoisting removes ~25 %)
-                "whole_path_tflops_canonical": canon_tf,
-                "whole_path_tflops_executed": exec_tf,
-                "whole_path_mfma_frac_canonical": canon_tf / peak, "whole_path_mfma_frac_executed": exec_tf / peak,
-                "whole_path_hbm_frac": ((cfgd["gb_per_image_step"] * scale + 0.160 / B) * 1e9 * a.sample_steps * value) / 8e12,
-                "whole_path_hbm_note": "north_star's >= 40 % of the HBM roofline is not reachable in fp32-class arithmetic "
-                                       "(AI ~180 flop/B vs a ridge of ~100-300): the path is matrix-bound (SURVEY section 7)",
-                "class_ms_share": {k: (v["ms"] / tot_ms if tot_ms else 0) for k, v in classes.items()},
-                "class_tflops": {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
-                                 for k, v in classes.items()},
-                # algorithmic bytes of the class (each op: its inputs once + its outputs once) / its time
-                "class_tb_per_s": {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0)
-                                   for k, v in classes.items()},
-                "class_ms_per_ddim_iter": {k: v["ms"] / n_prof_iters for k, v in classes.items()},
-                "ms_per_ddim_iter": dt / a.steps / a.sample_steps * 1e3,
-            },
+                       "backend": (a.backend if use_dist else None),
+                       "arith": arith_name(arith)},
+            "roofline": roofline_block(classes, ops, B, S, arith, value, a.sample_steps, a.steps, dt, cfgd, a.prof_every),
         }
+        if world > 1 and not a.no_verify:
+            out["verify"] = {"every_rank_checked_rows_0_and_last_of_its_shard_against_batch1_decodes": True,
+                             "tolerance": 1e-4, "ok": bool(shard_ok == 1.0)}
+            out["config"]["finite"] = ok and out["verify"]["ok"]
         if world == 1 and not a.no_verify:
             # Verification + batch-1 latency (what test_xparam.py runs: one image per call): rows 0 and B-1 of the
             # timed decode are decoded again on their own (different launch plans) and must agree.
-            rows, errs, t1 = (0, B - 1), [], 0.0
-            for k in rows:
-                torch.cuda.synchronize()
-                ta = time.perf_counter()
-                r1 = decode_fn(init[k:k + 1], [c[k:k + 1] for c in ctx])
-                torch.cuda.synchronize()
-                t1 += time.perf_counter() - ta
-                den = max(1.0, float(rec[k].abs().max().item()))
-                errs.append(float((r1[0] - rec[k]).abs().max().item()) / den)
-            out["verify"] = {"rows": list(rows), "max_rel_err_vs_batch1_decode": max(errs), "tolerance": 1e-4,
-                             "ok": bool(max(errs) <= 1e-4)}
-            out["batch1"] = {"images_per_s": len(rows) / t1, "ms_per_ddim_iter": t1 / len(rows) / a.sample_steps * 1e3,
-                             "note": "one image per call, same model and step count (the reference test scripts' mode)"}
+            out["verify"], out["batch1"] = verify_rows(decode_fn, init, ctx, rec, B, a.sample_steps)
             out["config"]["finite"] = ok and out["verify"]["ok"]
         if world == 1 and not a.no_alt_arith and arith == 1:
             # The exact-split arithmetic on the record beside the default one: the same decode once more in
@@ -332,14 +457,27 @@ def main():
             torch.cuda.synchronize()
             tb = time.perf_counter() - ta
             den = max(1.0, float(rec.abs().max().item()))
-            out["alt_arith"] = {"arith": "bf16x3", "value": B / tb, "unit": "images/s", "ms_per_step": tb * 1e3,
+            out["alt_arith"] = {"arith": "bf16x3", "dtype": dtype_label(0), "value": B / tb, "unit": "images/s", "ms_per_step": tb * 1e3,
                                 "ms_per_ddim_iter": tb / a.sample_steps * 1e3, "peak_tflops": PEAK_16BIT_MFMA_TFLOPS / PRODUCTS[0],
                                 "whole_path_tflops_canonical": cfgd["gflop_per_image_step"] * scale * 1e-3 * a.sample_steps * B / tb,
                                 "max_rel_diff_vs_f16x2_decode": float((rec_alt - rec).abs().max().item()) / den,
                                 "finite": bool(torch.isfinite(rec_alt).all().item()),
                                 "note": "one timed decode of the same batch, outside `value`"}
+            del rec_alt
             _lib.check(h, L.cdc_set_arith(h, 1))
         out["range_guard"] = _lib.handle_status(h)
+        headline = world == 1 and a.param == "x" and B == 32 and S == 256 and a.sample_steps == 500
+        if headline and not a.no_other_configs:
+            # BASELINE.json configs[2] and configs[4] on the driver's line: one timed decode each.  The headline
+            # model's activations are released first (configs[4] alone holds 14 GB of them).
+            del full, rec
+            del diff, un
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = [other_config("eps", 32, 256, 1000, local, dev, a.prof_every),
+                                    other_config("x", 16, 512, 500, local, dev, a.prof_every)]
+            gc.collect()
         if world == 1 and a.param == "x" and S % 64 == 0 and not a.no_extras:
             # informational (outside the timed region): the compressor on the GPU -- Compressor.forward (analysis
             # transform, hyper encoder/decoder, quantisers, rate estimate, synthesis transform) and decode alone

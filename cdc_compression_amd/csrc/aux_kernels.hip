@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) ln_kernel(const LnArgs a) {
         q += d * d;
     }
     const float var = q / (float)a.C;
+    if (a.fault && !(var < 3.0e38f)) *a.fault = 1;       // range guard (ConvArgs::fault): before LayerNorm + ReLU can hide it
     if (!a.out) {
         a.stat_mean[(size_t)b * a.HW + p] = mean;
         a.stat_rstd[(size_t)b * a.HW + p] = 1.0f / sqrtf(var + a.eps);
@@ -139,6 +140,7 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
 #pragma unroll
     for (int k = 0; k < CS; ++k) tot += red[k][pl];
     const float var = tot / (float)a.C;
+    if (a.fault && !(var < 3.0e38f)) *a.fault = 1;       // range guard (ConvArgs::fault)
     if (!a.out) {
         if (pv && cs == 0) {
             a.stat_mean[(size_t)b * a.HW + p] = mean;

@@ -677,6 +677,20 @@ struct Builder {
         (cur ? cur : &h->ops)->push_back(op);
     }
 
+    // Range-guard flag of the handle (conv_args.h: ConvArgs::fault): every convolution / LayerNorm launch of a program reports
+    // non-finite accumulators there; the entry points clear it before a call and read it back after (guard_check).
+    int *fault_flag() {
+        if (!h->d_fault && !rc) {
+            void *p = nullptr;
+            hipError_t e = hipMalloc(&p, sizeof(int));
+            if (e == hipSuccess) e = hipMemset(p, 0, sizeof(int));
+            if (e != hipSuccess) { rc = fail(h, CDC_ERR_NOMEM, "range-guard flag: %s", hipGetErrorString(e)); return nullptr; }
+            h->d_fault = (int *)p;
+            h->weight_allocs.push_back(p);
+        }
+        return h->d_fault;
+    }
+
     float *dalloc(size_t nfloats) {
         if (rc) return nullptr;
         void *p = nullptr;
@@ -849,7 +863,11 @@ struct Builder {
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
-        pf3_make_plan(a, B, w.nz, &op.pfplan);          // large 3x3 layers: the persistent ping-ponged kernel
+        a.fault = fault_flag();
+        // large 3x3 layers: the persistent ping-ponged kernel.  Its chunk summation order depends on the launch geometry
+        // (batch size, CU count), so a program planned "as for one image" (planB: the entropy coder's bit-exactness
+        // contract between batch sizes) never uses it.
+        if (planB == 0) pf3_make_plan(a, B, w.nz, &op.pfplan);
         if (getenv("CDC_DEBUG_PLAN"))
             fprintf(stderr, "[plan] conv %dx%d %d->%d out %dx%d on conv_pf%s_kernel (epv %d, %d workgroups x %d tiles per group)\n", w.KH, w.KW, w.Cin, w.Cout,
                     s.Ho, s.Wo, op.pfplan.pf3_epv ? "3" : "", op.pfplan.pf3_epv, op.pfplan.pf3_G, op.pfplan.pf3_iters);
@@ -906,6 +924,7 @@ struct Builder {
         a.relu = o.relu; a.relu_slope = o.relu_slope; a.eps = 1e-5f;
         a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
+        a.fault = fault_flag();
         const double px = (double)B * s.Ho * s.Wo;
         op.flops = 2.0 * px * w.Cout * w.Cin;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
@@ -1022,6 +1041,7 @@ struct Builder {
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.out_ks = (long long)B * out_bs;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
+        a.fault = fault_flag();
         if (o.emit_pf && !ks_scratch && plan.ksplit <= 1 && (w.Cout % 32) == 0)
             if (PfTwin *to = twin(out)) {
                 const int Ht = w.transposed ? 2 * H : s.Ho, Wt = w.transposed ? 2 * W : s.Wo;
@@ -1067,6 +1087,7 @@ struct Builder {
         a.nparts = nparts; a.part_stride = (long long)B * C * HW;
         a.in = in; a.out = out; a.C = C; a.HW = HW; a.g = g; a.b = b; a.eps = 1e-5f; a.relu = relu;
         a.shift = shift; a.shift_bs = h->shift_bs; a.resid = resid; a.stat_mean = sm; a.stat_rstd = sr;
+        a.fault = fault_flag();
         op.bytes = 4.0 * B * C * HW * (out ? 2 : 1);
         emit(op);
     }
@@ -1954,6 +1975,7 @@ int cdc_finalize_weights(cdc_handle *h) {
     HIP_TRY(h, hipDeviceSynchronize());
     free_program(h);
     free_pool(&h->weight_allocs);
+    h->d_fault = nullptr; h->d_step = nullptr;          // (they lived in that pool)
     h->rbs.clear(); h->attns.clear(); h->downs.clear(); h->ups.clear();
     if (h->kind == 3) {
         const int n = (int)h->enc_dims.size() - 1;
@@ -2392,7 +2414,12 @@ int entropy_encode_impl(cdc_handle *h, const float *latent, const float *hyper_l
     HIP_TRY(h, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(hoff.data(), d_off, sizeof(long long) * ((size_t)B + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
-    if (hbad) return fail(h, CDC_ERR_INVALID, "non-finite or out-of-range latent, mean or scale (nothing to code)");
+    if (hbad) {
+        // (in the BF16X3 repetition of a range fault: the range was not the cause -- RetryScope puts the handle back into F16X2
+        // and takes the fault off the count, as include/cdc_hip.h promises for every entry point)
+        if (h->in_retry) h->retry_futile = true;
+        return fail(h, CDC_ERR_INVALID, "non-finite or out-of-range latent, mean or scale (nothing to code)");
+    }
     if ((unsigned long long)hoff[B] > (unsigned long long)cap)
         return fail(h, CDC_ERR_NOMEM, "bitstream buffer too small: %d image(s) need %lld bytes of %zu", B, hoff[B], cap);
     HIP_TRY(h, hipMemcpy(out, packed, (size_t)hoff[B], hipMemcpyDeviceToHost));
@@ -2941,6 +2968,13 @@ int cdc_prof_reset(cdc_handle *h) {
 // ---- single operators ----------------------------------------------------------------------------
 namespace {
 
+constexpr int kOpRetry = -10000;  // internal: repeat the operator in CDC_ARITH_BF16X3 (never returned to the caller)
+template <class F> int op_with_guard(cdc_handle *h, F &&f) {
+    int rc = f();
+    if (rc == kOpRetry) { RetryScope r(h); rc = f(); if (rc == kOpRetry) rc = CDC_ERR_STATE; }
+    return rc;
+}
+
 struct OpScope {                 // temporary device pool + op list for the cdc_op_* entry points
     cdc_handle *h;
     std::vector<void *> pool;
@@ -2958,11 +2992,24 @@ struct OpScope {                 // temporary device pool + op list for the cdc_
         h->shift_bs = saved_shift_bs;
     }
     int up(const float *src, size_t n, float **dst) { return upload(h, src, n, dst, &pool); }
+    // Range guard of the single-operator entry points: the launches report non-finite accumulators (ConvArgs::fault) and the
+    // result is checked; a faulting F16X2 call returns kOpRetry and its entry point repeats it in BF16X3.
     int run(int B, float *host_out, const float *dev_out, size_t n) {
         hipStream_t st = h->own_stream;
+        const bool guard = guard_enabled(h);
+        int rc;
+        if (guard) { if ((rc = ensure_fault_flag(h))) return rc; HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st)); }
         for (const Op &op : h->ops) {
-            int rc = run_op(h, op, B, st);
+            rc = run_op(h, op, B, st);
             if (rc) return rc;
+        }
+        if (guard) {
+            int fault = 0;
+            if ((rc = guard_check(h, {{dev_out, 0, (long long)n}}, 1, st, &fault))) return rc;
+            if (fault) {
+                if (guard_escalate(h, &rc)) return kOpRetry;
+                if (rc) return rc;
+            }
         }
         HIP_TRY(h, hipStreamSynchronize(st));
         HIP_TRY(h, hipMemcpy(host_out, dev_out, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -2976,7 +3023,7 @@ int op_ready(cdc_handle *h) { return ensure_device(h); }
 
 extern "C" {
 
-int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y, int B,
+static int op_conv2d_impl(cdc_handle *h, const float *x, const float *w, const float *bias, float *y, int B,
                   int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                   const float *ln_g, const float *ln_b, int relu, const float *shift,
                   const float *resid) {
@@ -3019,7 +3066,7 @@ int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bi
     return sc.run(B, y, dy, (size_t)B * Cout * Ho * Wo);
 }
 
-int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y,
+static int op_conv_transpose2d_impl(cdc_handle *h, const float *x, const float *w, const float *bias, float *y,
                             int B, int Cin, int H, int W, int Cout) {
     int rc = op_ready(h);
     if (rc) return rc;
@@ -3043,7 +3090,7 @@ int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const
     return sc.run(B, y, dy, ny);
 }
 
-int cdc_op_chan_layernorm(cdc_handle *h, const float *x, const float *g, const float *b, float *y, int B,
+static int op_chan_layernorm_impl(cdc_handle *h, const float *x, const float *g, const float *b, float *y, int B,
                           int C, int HW) {
     int rc = op_ready(h);
     if (rc) return rc;
@@ -3060,7 +3107,7 @@ int cdc_op_chan_layernorm(cdc_handle *h, const float *x, const float *g, const f
     return sc.run(B, y, dy, (size_t)B * C * HW);
 }
 
-int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, const float *norm_b,
+static int op_linear_attention_impl(cdc_handle *h, const float *x, const float *norm_g, const float *norm_b,
                             const float *w_qkv, const float *w_out, const float *b_out, float *y, int B,
                             int C, int H, int W) {
     int rc = op_ready(h);
@@ -3110,6 +3157,30 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
         }
     }
     return sc.run(B, y, ay.p, (size_t)B * C * H * W);
+}
+
+
+int cdc_op_conv2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y, int B,
+                  int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                  const float *ln_g, const float *ln_b, int relu, const float *shift,
+                  const float *resid) {
+    return op_with_guard(h, [&] { return op_conv2d_impl(h, x, w, bias, y, B, Cin, H, W, Cout, KH, KW, stride, pad, ln_g, ln_b, relu, shift, resid); });
+}
+
+int cdc_op_conv_transpose2d(cdc_handle *h, const float *x, const float *w, const float *bias, float *y,
+                            int B, int Cin, int H, int W, int Cout) {
+    return op_with_guard(h, [&] { return op_conv_transpose2d_impl(h, x, w, bias, y, B, Cin, H, W, Cout); });
+}
+
+int cdc_op_chan_layernorm(cdc_handle *h, const float *x, const float *g, const float *b, float *y, int B,
+                          int C, int HW) {
+    return op_with_guard(h, [&] { return op_chan_layernorm_impl(h, x, g, b, y, B, C, HW); });
+}
+
+int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, const float *norm_b,
+                            const float *w_qkv, const float *w_out, const float *b_out, float *y, int B,
+                            int C, int H, int W) {
+    return op_with_guard(h, [&] { return op_linear_attention_impl(h, x, norm_g, norm_b, w_qkv, w_out, b_out, y, B, C, H, W); });
 }
 
 }  // extern "C"

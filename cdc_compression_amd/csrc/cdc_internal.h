@@ -1,5 +1,6 @@
 // cdc_internal.h -- host-side declarations shared by the translation units of libcdc_hip.so.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,7 +69,12 @@ hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long lo
 // User-level variables stay plain getenv: CDC_ARITH, CDC_NO_RANGE_GUARD, CDC_GRAPH, CDC_DEBUG_PLAN, CDC_PROF_OPS.
 inline const char *dev_env(const char *name) {
     static const bool on = [] { const char *e = ::getenv("CDC_DEV"); return e && atoi(e) != 0; }();
-    return on ? ::getenv(name) : nullptr;
+    if (on) return ::getenv(name);
+    if (::getenv(name)) {       // a tuning tool that forgot CDC_DEV=1 would silently time the default plan under every label
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "cdc_hip: %s is set but ignored: development switches need CDC_DEV=1\n", name); }
+    }
+    return nullptr;
 }
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -88,6 +94,7 @@ struct LnArgs {
     float *stat_mean, *stat_rstd;   // [B][HW] statistics of the FINAL values, or null
     int nparts;               // > 1: `in` holds split-K partial sums, slice k at in + k*part_stride
     long long part_stride;
+    int *fault;               // range guard (ConvArgs::fault): set to 1 when a pixel's statistics are not finite (may be null)
 };
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st);
 

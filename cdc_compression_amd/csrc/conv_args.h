@@ -83,6 +83,9 @@ struct ConvArgs {
     long long pf_bs, pf_ps;
     int pf_ys, pf_xs, pf_zoff[4];
     int pf_only;    // the planes are the ONLY copy of the result (its single consumer reads planes): skip the fp32 store
+    // range guard of the fp16 arithmetic (cdc_api.hip): set to 1 when an accumulator of this launch is inf / NaN -- checked
+    // BEFORE the LayerNorm / ReLU of the epilogue can turn it into a finite value (may be null)
+    int *fault;
 #ifdef CDC_TIMELINE
     unsigned long long *tl;         // tools/build_variant.sh timeline -DCDC_TIMELINE: 64 cycle stamps per workgroup
 #endif
@@ -136,6 +139,7 @@ struct PfArgs {
                                     // of one image's flattened H*W (H*W % 32 == 0), a workgroup may span images
     int dbg;                        // CDC_PF_DBG (timing experiments, wrong results): 1 no weight DMA in the loop, 2 no patch
                                     // DMA in the loop, 4 no barrier in the loop, 8 no DMA waits, 16 no epilogue stores
+    int *fault;                     // range guard: set to 1 when an accumulator is inf / NaN (see ConvArgs::fault; may be null)
 };
 
 constexpr int kPfXS = 12;   // patch DMA instructions per chunk and patch wave (two patch waves: <= 24 per chunk)

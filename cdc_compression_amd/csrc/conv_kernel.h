@@ -179,6 +179,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
                     q += d * d;
                 }
             q += __shfl_xor(q, 32);
+            // range guard: an inf / NaN accumulator (an operand left the fp16 range) makes q non-finite; the LayerNorm
+            // + ReLU below could turn it into a finite, wrong value, so it is reported here
+            if (P.fault && !(q < 3.0e38f)) *P.fault = 1;
             const float rinv = 1.0f / sqrtf(q * inv_c + P.eps);
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -187,6 +190,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
                     const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
                     acc[m][n][r] = (acc[m][n][r] - mean) * rinv * epl[COPT + ci] + epl[2 * COPT + ci];
                 }
+        } else if (P.fault) {
+            float s = 0.f;              // any inf / NaN among the pixel's values makes the sum of |v| non-finite
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += fabsf(acc[m][n][r]);
+            if (!(s < 3.0e38f)) *P.fault = 1;
         }
         if (P.relu) {
 #pragma unroll

@@ -299,13 +299,13 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     }
     dim3 block(64 * p.WN);
 #ifdef CDC_TIMELINE
-    // Development build only: per-workgroup cycle stamps of the split2 kernel, summarised on stderr.
+    // Development build only: per-workgroup cycle categories of the split2 kernel, summarised on stderr.
     static unsigned long long *tl_dev = nullptr;
-    const size_t tl_wgs = (size_t)grid.x * grid.y;
+    const size_t tl_wgs = (size_t)grid.x * grid.y * grid.z;
     a.tl = nullptr;
-    if (p.split == 2 && tl_wgs <= (1u << 16)) {
-        if (!tl_dev) hipMalloc(&tl_dev, sizeof(unsigned long long) * 64 * (1u << 16));
-        hipMemsetAsync(tl_dev, 0, sizeof(unsigned long long) * 64 * tl_wgs, st);
+    if (p.split == 2 && tl_wgs <= (1u << 18)) {
+        if (!tl_dev) hipMalloc(&tl_dev, sizeof(unsigned long long) * 16 * (1u << 18));
+        hipMemsetAsync(tl_dev, 0, sizeof(unsigned long long) * 16 * tl_wgs, st);
         a.tl = tl_dev;
     }
 #endif
@@ -313,18 +313,20 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
 #ifdef CDC_TIMELINE
     if (a.tl) {
         hipStreamSynchronize(st);
-        std::vector<unsigned long long> h(64 * tl_wgs);
+        std::vector<unsigned long long> h(16 * tl_wgs);
         hipMemcpy(h.data(), tl_dev, h.size() * 8, hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull, t1 = 0;
-        double dsum[64] = {0}; size_t dn[64] = {0};
+        double cat[7] = {0}, life = 0;
         for (size_t w = 0; w < tl_wgs; ++w) {
-            const unsigned long long *r = &h[w * 64];
-            if (!r[0]) continue;
-            t0 = std::min(t0, r[0]);
-            for (int k = 1; k < 64 && r[k]; ++k) { dsum[k] += (double)(r[k] - r[k - 1]); dn[k]++; t1 = std::max(t1, r[k]); }
+            const unsigned long long *r = &h[w * 16];
+            for (int c = 0; c < 7; ++c) cat[c] += (double)r[c];
+            t0 = std::min(t0, r[7]); t1 = std::max(t1, r[8]);
+            life += (double)(r[8] - r[7]);
         }
-        fprintf(stderr, "[timeline] wgs %zu  span %llu cycles; mean delta per stamp:", tl_wgs, t1 - t0);
-        for (int k = 1; k < 64 && dn[k]; ++k) fprintf(stderr, " %d:%.0f", k, dsum[k] / dn[k]);
+        static const char *names[7] = {"prologue", "convert+ds_write", "chunk-head wait+barrier", "tap loops", "group-end dma wait", "group-end barrier", "epilogue"};
+        fprintf(stderr, "[timeline] conv %dx%d s%d %d->%d out %dx%d: %zu workgroups x %d threads, lds %zu, kernel span %llu cycles, mean workgroup life %.0f cycles (= %.2f of the span);"
+                        " per workgroup (wave 0):", a.KH, a.KW, a.stride, a.Cin, a.Cout, a.Ho, a.Wo, tl_wgs, 64 * p.WN, p.lds_bytes, t1 - t0, life / tl_wgs, life / tl_wgs / (double)(t1 - t0));
+        for (int c = 0; c < 7; ++c) fprintf(stderr, "  %s %.0f", names[c], cat[c] / tl_wgs);
         fprintf(stderr, "\n");
     }
 #endif

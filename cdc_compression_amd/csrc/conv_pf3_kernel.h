@@ -521,6 +521,10 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                                 part[n] = sm;
                             }
                             const float var = part[n] * inv_c + eps_s;
+                            // range guard (ConvArgs::fault): a non-finite accumulator shows in the variance; reported before the
+                            // LayerNorm + ReLU below can turn it into a finite value.  (One more vector-memory operation in this
+                            // wave's queue only makes the counted waits of the static schedule stricter, never looser.)
+                            if (!(var < 3.0e38f) && Pe->fault) *Pe->fault = 1;
                             float y = __builtin_amdgcn_rsqf(var);      // + one Newton step: full fp32 accuracy without the division sequence
                             y = y * (1.5f - 0.5f * var * y * y);
                             rinv_v[n] = y;
@@ -529,17 +533,15 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][n][r] = __builtin_fmaf(acc[m][n][r] * rinv_v[n], gq[r >> 2][r & 3], bq[r >> 2][r & 3]);
                     } else {
+                        float sa = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[m][n][r] *= acc_scale;
+                        for (int r = 0; r < 16; ++r) { acc[m][n][r] *= acc_scale; sa += fabsf(acc[m][n][r]); }
+                        if (!(sa < 3.0e38f) && Pe->fault) *Pe->fault = 1;
                     }
                     if (relu) {
-                        if (relu_slope == 0.f) {
+                        // max(v, slope v) also for slope 0: 0 * NaN = NaN keeps a NaN alive (v_max_f32(NaN, 0) would return 0)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], 0.f);
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], relu_slope * acc[m][n][r]);
-                        }
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], relu_slope * acc[m][n][r]);
                     }
                     if (has_shift) {
                         f32x4 sq[4];

@@ -410,7 +410,11 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
             }
         }
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) rinv_o[n] = 1.0f / sqrtf(part[n] * inv_c + P.eps);
+        for (int n = 0; n < NPW; ++n) {
+            // range guard (ConvArgs::fault): a non-finite accumulator shows in the variance, before LayerNorm + ReLU can hide it
+            if (P.fault && !(part[n] < 3.0e38f)) *P.fault = 1;
+            rinv_o[n] = 1.0f / sqrtf(part[n] * inv_c + P.eps);
+        }
     };
     if (P.ep_g) {
         chan_stats(mean_v, rinv_v);
@@ -423,6 +427,16 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
                     const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
                     acc[m][n][r] = (acc[m][n][r] - mean_v[n]) * rinv_v[n] * epl[COPT + ci] + epl[2 * COPT + ci];
                 }
+    } else if (P.fault) {
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += fabsf(acc[m][n][r]);
+            if (!(s < 3.0e38f)) *P.fault = 1;
+        }
     }
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {

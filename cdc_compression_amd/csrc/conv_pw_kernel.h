@@ -257,6 +257,14 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
                 acc[m][n][r] = (ACC2 ? acc[m][n][r] + acc2[ACC2 ? m : 0][ACC2 ? n : 0][r] * (1.0f / 2048.0f) : acc[m][n][r]) * sc +
                                epl[m * 32 + (r & 3) + 8 * (r >> 2)];
         if (!ok) continue;
+        if (P.fault) {                  // range guard (ConvArgs::fault): non-finite accumulators are reported where they arise
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += fabsf(acc[m][n][r]);
+            if (!(s < 3.0e38f)) *P.fault = 1;
+        }
         if (P.pre_add) {
             const float *pp = P.pre_add + (size_t)bn * P.out_bs + opix + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll

@@ -266,12 +266,15 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) 
     static_assert(XU == 1 || LNMODE == 0, "two-unit variant carries no LayerNorm-on-load");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef CDC_TIMELINE
-    int tl_n = 0;
-#define TL() do { if (P.tl && threadIdx.x == 0 && tl_n < 64) P.tl[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+    // development build (tools/build_variant.sh timeline -DCDC_TIMELINE): cycles of wave 0 per category, summed over the tile:
+    // 0 prologue (descriptors, first loads), 1 convert + ds_write (store_x), 2 chunk-head wait + barrier, 3 tap loops (ds_read + MFMA),
+    // 4 group-end DMA wait, 5 group-end barrier, 6 epilogue; slot 7 = start stamp, 8 = end stamp
+    unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_readcyclecounter();
+    const unsigned long long tl_start = tl_last;
+#define TLC(c) do { const unsigned long long n_ = __builtin_readcyclecounter(); tl_acc[c] += n_ - tl_last; tl_last = n_; } while (0)
 #else
-#define TL() do { } while (0)
+#define TLC(c) do { } while (0)
 #endif
-    TL();
     constexpr int COPT = MB * 32;
     constexpr int KC = 16;
     const int tid = threadIdx.x;
@@ -532,19 +535,18 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) 
     load_x(c_lo);
     issue_w(0, c_lo, 0);
     int wstage = 0;
-    TL();
+    TLC(0);
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         // (everyone finished reading the previous chunk's planes: the barrier that ends its last tap group)
-        TL();
 #ifndef CDC_AB_NOSTOREX
         store_x(chunk);
 #else
         if (chunk == c_lo) store_x(chunk);
 #endif
-        TL();
+        TLC(1);
         dma_wait();                         // first weight stage landed (nothing else is in flight)
         __syncthreads();                    // planes of `chunk` + first weight row visible
-        TL();
+        TLC(2);
 #ifndef CDC_AB_NOLOADX
         if (chunk + 1 < c_hi) load_x(chunk + 1);     // in flight during the tap loop; the group-end
                                                      // waits cover it (issued >= one group earlier)
@@ -617,15 +619,14 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) 
                 }
             }
             __builtin_amdgcn_s_setprio(0);
-            TL();
+            TLC(3);
             dma_wait();
-            TL();
+            TLC(4);
             __syncthreads();
-            TL();
+            TLC(5);
             wstage ^= 1;
         }
     }
-    TL();
 
     float prstd[LNMODE == 2 ? NPW : 1];
     if constexpr (LNMODE == 2) {
@@ -647,8 +648,15 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) 
     conv_epilogue<MB, NPW, LNMODE, 0>(P, geom, acc[0], smem, prstd);
 #endif
     }
-    TL();
-#undef TL
+    TLC(6);
+#ifdef CDC_TIMELINE
+    if (P.tl && threadIdx.x == 0) {
+        unsigned long long *o = P.tl + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16;
+        for (int c = 0; c < 7; ++c) o[c] = tl_acc[c];
+        o[7] = tl_start; o[8] = tl_last;
+    }
+#endif
+#undef TLC
 }
 
 }  // namespace cdc

@@ -35,6 +35,10 @@ class Ops:
         except Exception:
             pass
 
+    def status(self):
+        """{"arith", "range_faults", "nonfinite_results"} of this handle (range guard of the fp16 arithmetic)."""
+        return _lib.handle_status(self._h)
+
     def prof(self, on=True):
         L = _lib.lib()
         L.cdc_prof_reset(self._h)

@@ -18,11 +18,20 @@ from oracle import ops as oops
 from helpers import GOLDEN, digest_idx, load_case, oracle_cfg
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = 1e-4         # north_star's statement.  The test bounds below are ~3x what is MEASURED on the MI355X:
+TOL_FWD = 1.5e-5   #   one U-Net / compressor forward (or a stage of it) against the reference golden: measured <= 5e-6
+TOL_DEC = 3e-5     #   a few-step / full-length decode chain against the reference golden: measured <= 1e-5
+# (CDC_TEST_OBS=<file>: every relerr() of a run is appended there with its test id -- how the bounds were measured;
+#  tools/gpu_parity_obs.sh, summary under profiles/parity_obs_r04.txt)
 
 
 def relerr(a, ref):
-    return float(np.abs(a - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    e = float(np.abs(a - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    obs = os.environ.get("CDC_TEST_OBS")
+    if obs:
+        with open(obs, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "relerr": e}) + "\n")
+    return e
 
 
 @pytest.fixture(scope="module")
@@ -239,7 +248,7 @@ def test_unet_forward_matches_reference_golden(name):
     un, kw, sd, x, time, ctx, g = make_unet(name)
     y = un(x, time, ctx)
     assert y.shape == g["y"].shape
-    assert relerr(y, g["y"]) < TOL, relerr(y, g["y"])
+    assert relerr(y, g["y"]) < TOL_FWD, relerr(y, g["y"])
 
 
 @pytest.mark.parametrize("name,env", [("full_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}), ("small_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),
@@ -257,7 +266,7 @@ def test_unet_forward_alternate_kernel_modes(name, env, monkeypatch):
         monkeypatch.setenv(k, v)
     un, kw, sd, x, time, ctx, g = make_unet(name)
     y = un(x, time, ctx)
-    assert relerr(y, g["y"]) < TOL, relerr(y, g["y"])
+    assert relerr(y, g["y"]) < TOL_FWD, relerr(y, g["y"])
 
 
 def test_unet_forward_matches_oracle_other_batch(O):
@@ -268,7 +277,7 @@ def test_unet_forward_matches_oracle_other_batch(O):
     ctx = [synth.normal("c0", (B, 8, H, W), 31, 0.5), synth.normal("c1", (B, 16, H // 2, W // 2), 31, 0.5)]
     time = np.array([[0.05], [0.5], [0.93]], np.float32)
     ref = om.unet_forward(O, oracle_cfg(kw), sd, x, time, ctx)
-    assert relerr(un(x, time, ctx), ref) < TOL
+    assert relerr(un(x, time, ctx), ref) < TOL_FWD
 
 
 @pytest.mark.parametrize("name,param,T,vs", [("small_x", "x", 8193, "cosine"),
@@ -287,7 +296,7 @@ def test_decode_matches_reference_golden(name, param, T, vs):
     for key in [k for k in g.files if k.startswith("decode_")]:
         steps = int(key.split("_")[1])
         rec = diff.decompress(ctx, x.shape, sample_steps=steps, init=init)
-        assert relerr(rec, g[key]) < TOL, (key, relerr(rec, g[key]))
+        assert relerr(rec, g[key]) < TOL_DEC, (key, relerr(rec, g[key]))
     if "eta_steps" in g.files:
         # eta != 0 with the reference's recorded torch.randn_like draws, fed step by step
         steps = int(g["eta_steps"])
@@ -303,7 +312,7 @@ def test_decode_matches_reference_golden(name, param, T, vs):
                                           out.ctypes.data, x.shape[0], x.shape[2], x.shape[3],
                                           0 if param == "x" else 1, 1 if param == "x" else 0, 0, None))
             img = out.copy()
-        assert relerr(img, g["eta_decode"]) < TOL
+        assert relerr(img, g["eta_decode"]) < TOL_DEC
 
 
 def test_compress_api_with_torch_cuda_tensors():
@@ -322,9 +331,9 @@ def test_compress_api_with_torch_cuda_tensors():
     init = torch.from_numpy(synth.normal("init", x.shape, seed=1, std=0.8)).to(dev)
     rec, bpp = diff.compress(torch.zeros(x.shape, device=dev), sample_steps=4, init=init)
     assert rec.is_cuda and rec.shape == tuple(x.shape)
-    assert relerr(rec.cpu().numpy(), gd["decode_4"]) < TOL
+    assert relerr(rec.cpu().numpy(), gd["decode_4"]) < TOL_DEC
     y = un(torch.from_numpy(x).to(dev), torch.from_numpy(time).to(dev), tctx)
-    assert relerr(y.cpu().numpy(), g["y"]) < TOL
+    assert relerr(y.cpu().numpy(), g["y"]) < TOL_FWD
 
 
 def test_full_resolution_256_digest_and_properties():
@@ -339,12 +348,12 @@ def test_full_resolution_256_digest_and_properties():
     x = synth.normal("x", (B, 3, H, W), seed=1, std=0.8)
     ctx = synth.context_pyramid([64, 64, 128, 192], B, H, W, seed=3)
     y = un(x, g["time"], ctx)
-    assert relerr(y.reshape(-1)[g["y_idx"]], g["y_val"]) < TOL
+    assert relerr(y.reshape(-1)[g["y_idx"]], g["y_val"]) < TOL_FWD
     assert abs(float(y.astype(np.float64).sum()) - float(g["y_sum"])) < 1e-4 * y.size
     diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
     init = synth.normal("init", (B, 3, H, W), seed=1, std=0.8)
     rec = diff.decompress(ctx, (B, 3, H, W), sample_steps=4, init=init)
-    assert relerr(rec.reshape(-1)[g["dec4_idx"]], g["dec4_val"]) < TOL
+    assert relerr(rec.reshape(-1)[g["dec4_idx"]], g["dec4_val"]) < TOL_DEC
     assert np.abs(rec).max() <= 1.0 + 1e-6
     # batch independence: duplicate the image -> both rows equal the B=1 result bit-for-bit
     x2 = np.concatenate([x, x]); ctx2 = [np.concatenate([c, c]) for c in ctx]
@@ -396,10 +405,10 @@ def test_context_decoder_matches_reference_golden(name):
     for i, o in enumerate(outs):
         assert list(o.shape) == list(g[f"out{i}_shape"])
         flat = o.reshape(-1)
-        assert relerr(flat[g[f"out{i}_idx"]], g[f"out{i}_val"]) < TOL
+        assert relerr(flat[g[f"out{i}_idx"]], g[f"out{i}_val"]) < TOL_FWD
         assert abs(float(flat.astype(np.float64).sum()) - float(g[f"out{i}_sum"])) < 1e-4 * flat.size
         if f"out{i}" in g.files:
-            assert relerr(o, g[f"out{i}"]) < TOL
+            assert relerr(o, g[f"out{i}"]) < TOL_FWD
 
 
 def test_context_decoder_matches_oracle_other_shape_and_feeds_the_unet(O):
@@ -411,7 +420,7 @@ def test_context_decoder_matches_oracle_other_shape_and_feeds_the_unet(O):
     ref = om.compressor_decode(O, cfg, sd, q)
     for o, r in zip(outs, ref):
         assert o.shape == r.shape
-        assert relerr(o, r) < TOL
+        assert relerr(o, r) < TOL_FWD
     un, kw, usd, x, time, ctx, g = make_unet("full_x")
     diff = cdc.GaussianDiffusionX(un, m, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
     shape = (2, 3, 32, 64)
@@ -455,10 +464,10 @@ def test_hyper_decoder_matches_reference_golden(name):
     for key, a in (("mean", mean), ("scale", scale)):
         assert list(a.shape) == list(g[f"{key}_shape"])
         flat = a.reshape(-1)
-        assert relerr(flat[g[f"{key}_idx"]], g[f"{key}_val"]) < TOL
+        assert relerr(flat[g[f"{key}_idx"]], g[f"{key}_val"]) < TOL_FWD
         assert abs(float(flat.astype(np.float64).sum()) - float(g[f"{key}_sum"])) < 1e-4 * flat.size
         if key in g.files:
-            assert relerr(a, g[key]) < TOL
+            assert relerr(a, g[key]) < TOL_FWD
     assert float(scale.min()) >= 0.1
     if "mean" in g.files and "q_latent" in g.files:
         # dequantize is discrete: feed the reference's own mean -> the reference's q_latent, bit for bit
@@ -479,14 +488,14 @@ def test_latents_to_image_chain(O):
     qh = np.round(synth.normal("qh", (1, 256, 1, 2), seed=12, std=2.0)).astype(np.float32)
     mean, scale = m.hyper_decode(qh)
     rmean, rscale = om.hyper_decode(O, meta["dims"], sd, qh)
-    assert relerr(mean, rmean) < TOL and relerr(scale, rscale) < TOL
+    assert relerr(mean, rmean) < TOL_FWD and relerr(scale, rscale) < TOL_FWD
     sym = np.round(synth.normal("sym", mean.shape, seed=13, std=2.0)).astype(np.float32)
     q_latent = m.dequantize(sym + rmean, rmean)            # integers + offset survive the round trip
     np.testing.assert_array_equal(q_latent, om.dequantize(sym + rmean, rmean))
     ctx = m.decode(q_latent)
     cfg = om.CompressorConfig(64, (4, 3, 2, 1), 64, 1)
     for a, r in zip(ctx, om.compressor_decode(O, cfg, sd, q_latent)):
-        assert relerr(a, r) < TOL
+        assert relerr(a, r) < TOL_FWD
 
 
 def test_non_square_frame_against_double_accumulating_oracle():
@@ -526,14 +535,14 @@ def test_rate_estimate_matches_reference_bpp(name):
 
 # ---- encoder and the whole compressor forward ---------------------------------
 
-def _symbols_close(a, ref, max_flip_frac=2e-3):
+def _symbols_close(a, ref, max_flip_frac=1e-4):
     """Quantised tensors: equal up to fp32 round-off except where a value sat within round-off of a rounding
     boundary (then it differs by exactly one quantisation step): allow a small fraction of such flips."""
     d = np.abs(a - ref)
-    near = d <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    near = d <= 1.5e-5 * max(1.0, float(np.abs(ref).max()))
     flip = np.abs(d - 1.0) <= 1e-3
     assert (near | flip).all()
-    assert flip.mean() <= max_flip_frac, float(flip.mean())
+    assert flip.sum() <= max(1, int(max_flip_frac * flip.size)), (int(flip.sum()), flip.size)     # measured: 1 of 196 608 on the Kodak crops
 
 
 @pytest.mark.parametrize("name", ["encoder_small_x", "encoder_full_x", "encoder_full_eps"])
@@ -550,9 +559,9 @@ def test_compressor_forward_matches_reference_golden(name):
     latent, hyper = m.analysis(x)
     for key, a in (("latent", latent), ("hyper_latent", hyper)):
         assert list(a.shape) == list(g[f"{key}_shape"])
-        assert relerr(a.reshape(-1)[g[f"{key}_idx"]], g[f"{key}_val"]) < TOL
+        assert relerr(a.reshape(-1)[g[f"{key}_idx"]], g[f"{key}_val"]) < TOL_FWD
         if key in g.files:
-            assert relerr(a, g[key]) < TOL
+            assert relerr(a, g[key]) < TOL_FWD
     out = m(x)
     assert set(out) == {"output", "bpp", "q_latent", "q_hyper_latent"}
     for key in ("q_latent", "q_hyper_latent"):
@@ -562,8 +571,8 @@ def test_compressor_forward_matches_reference_golden(name):
     assert len(out["output"]) == 4 and list(out["output"][0].shape) == list(g["ctx0_shape"])
     # the pyramid depends on q_latent: where no symbol flipped it matches the reference
     if "q_latent" in g.files and np.array_equal(out["q_latent"], g["q_latent"]):
-        assert relerr(out["output"][3].reshape(-1)[g["ctx3_idx"]], g["ctx3_val"]) < TOL
-        assert relerr(out["output"][0].reshape(-1)[g["ctx0_idx"]], g["ctx0_val"]) < TOL
+        assert relerr(out["output"][3].reshape(-1)[g["ctx3_idx"]], g["ctx3_val"]) < TOL_FWD
+        assert relerr(out["output"][0].reshape(-1)[g["ctx0_idx"]], g["ctx0_val"]) < TOL_FWD
 
 
 def test_compress_end_to_end_without_reference_module():
@@ -638,7 +647,7 @@ def test_kodak_crops_eps_1000_steps_match_reference():
     rec = diff.decompress(comp.decode(g["q_latent"]), x.shape, sample_steps=steps, init=init)
     scale = max(1.0, float(np.abs(g["rec_val"]).max()))
     d = np.abs(rec.reshape(-1)[g["rec_idx"]] - g["rec_val"]) / scale
-    assert d.max() < 5e-5, float(d.max())          # relative to |x| ~ 480; measured 4.4e-6
+    assert d.max() < 1.5e-5, float(d.max())        # relative to |x| ~ 480; measured 4.4e-6
     out = comp(x)
     assert np.abs(out["bpp"] - g["bpp"]).max() <= 1e-5 * float(np.abs(g["bpp"]).max())
     assert int((np.abs(out["q_latent"] - g["q_latent"]) > 0.5).sum()) <= 2
@@ -663,10 +672,10 @@ def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
 
 # ---- round 2: the remaining BASELINE shapes, per-stage taps, sampler variants ---------------------------------
 
-def _digest_check(a, g, key, tol=TOL):
+def _digest_check(a, g, key, tol=TOL_FWD):
     flat = a.reshape(-1)
     ref = g[key + "_val"]
-    assert float(np.abs(flat[g[key + "_idx"]] - ref).max()) <= tol * max(1.0, float(np.abs(ref).max()))
+    assert relerr(flat[g[key + "_idx"]], ref) <= tol
     assert abs(float(a.astype(np.float64).sum()) - float(g[key + "_sum"])) <= tol * a.size * max(1.0, float(np.abs(ref).max()))
 
 
@@ -687,7 +696,7 @@ def test_x_param_512_matches_reference_digest_and_batch16_rows():
     init = synth.normal("init", (1, 3, H, W), seed=1, std=0.8)
     steps = int(g["steps"])
     rec1 = diff.decompress(ctx, (1, 3, H, W), sample_steps=steps, init=init)
-    _digest_check(rec1, g, "dec")
+    _digest_check(rec1, g, "dec", TOL_DEC)
     B = 16
     rec16 = diff.decompress([np.repeat(c, B, 0) for c in ctx], (B, 3, H, W), sample_steps=steps, init=np.repeat(init, B, 0))
     for k in (0, 7, 15):      # (different attention / split-K partitions: summation order differs; measured 1.1e-5)
@@ -712,7 +721,7 @@ def test_eps_param_256_matches_reference_digest_and_batch32_rows():
     init = synth.normal("init", (1, 3, H, W), seed=1, std=0.8)
     steps = int(g["steps"])
     rec1 = diff.decompress(ctx, (1, 3, H, W), sample_steps=steps, init=init)
-    _digest_check(rec1, g, "dec")
+    _digest_check(rec1, g, "dec", TOL_DEC)
     B = 32
     y32 = un(np.repeat(x, B, 0), np.repeat(g["time"], B, 0), [np.repeat(c, B, 0) for c in ctx])
     for k in (0, 13, 31):
@@ -720,6 +729,31 @@ def test_eps_param_256_matches_reference_digest_and_batch32_rows():
     rec32 = diff.decompress([np.repeat(c, B, 0) for c in ctx], (B, 3, H, W), sample_steps=steps, init=np.repeat(init, B, 0))
     for k in (0, 19, 31):
         assert relerr(rec32[k], rec1[0]) < 3e-5, (k, relerr(rec32[k], rec1[0]))
+
+
+def test_configs1_full_length_batch32_rows_match_batch1_decodes():
+    """BASELINE configs[1] at full length and full batch INSIDE pytest (bench.py's `verify` does the same
+    outside it): x-param, batch 32 of DISTINCT images, 256x256, all 500 DDIM iterations on the batch-32 launch program
+    (persistent kernels, fused plans), then rows 0 / 17 / 31 decoded on their own with the batch-1 program (other kernels,
+    K splits and summation orders).  The chain is contractive (x0 is clamped each step): measured 8e-6."""
+    import torch
+    kw, man, sd, _, _, _, _ = load_case("full_x")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    B, S, steps = 32, 256, 500
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    init = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8
+    ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5 for l, c in enumerate([64, 64, 128, 192])]
+    rec = diff.decompress(ctx, (B, 3, S, S), sample_steps=steps, init=init)
+    assert bool(torch.isfinite(rec).all().item()) and float(rec.abs().max().item()) <= 1.0
+    assert float((rec[0] - rec[17]).abs().max().item()) > 0.1            # the rows really are different images
+    for k in (0, 17, 31):
+        r1 = diff.decompress([c[k:k + 1] for c in ctx], (1, 3, S, S), sample_steps=steps, init=init[k:k + 1])
+        e = relerr(r1[0].cpu().numpy(), rec[k].cpu().numpy())
+        assert e < TOL_DEC, (k, e)
+    assert un.status() == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}
 
 
 TAPS = ["downs.0.0", "downs.0.2", "downs.1.3", "mid_block1", "ups.0"]
@@ -743,14 +777,14 @@ def test_unet_stage_taps_match_reference(name):
             ref = g[f"tap_{k}"]
             got = un.tap(key)
             assert got.shape == ref.shape, (k, got.shape, ref.shape)
-            assert relerr(got, ref) < TOL, (k, relerr(got, ref))
+            assert relerr(got, ref) < TOL_FWD, (k, relerr(got, ref))
             checked += 1
         elif f"tap_{k}_val" in g.files:
             got = un.tap(key)
             ref = g[f"tap_{k}_val"]
             err = float(np.abs(got.reshape(-1)[g[f"tap_{k}_idx"]] - ref).max()) / max(1.0, float(np.abs(ref).max()))
-            assert err < TOL, (k, err)
-            assert abs(float(got.astype(np.float64).sum()) - float(g[f"tap_{k}_sum"])) < TOL * got.size * max(1.0, float(np.abs(ref).max()))
+            assert err < TOL_FWD, (k, err)
+            assert abs(float(got.astype(np.float64).sum()) - float(g[f"tap_{k}_sum"])) < TOL_FWD * got.size * max(1.0, float(np.abs(ref).max()))
             checked += 1
     assert checked >= 4, checked
 
@@ -762,17 +796,17 @@ def test_sampler_variants_match_reference_golden():
     init = synth.normal("init", x.shape, seed=1, std=0.8)
     diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="noise", var_schedule="cosine")
     rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
-    assert relerr(rec, g["small_x"]) < TOL, relerr(rec, g["small_x"])
+    assert relerr(rec, g["small_x"]) < TOL_DEC, relerr(rec, g["small_x"])
     un, kw, sd, x, time, ctx, _ = make_unet("small_eps")
     diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=20000, clip_noise="half", pred_mode="noise", var_schedule="linear")
     rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
-    assert relerr(rec, g["small_eps"]) < TOL, relerr(rec, g["small_eps"])
+    assert relerr(rec, g["small_eps"]) < TOL_DEC, relerr(rec, g["small_eps"])
     assert np.abs(rec[: x.shape[0] // 2]).max() <= np.abs(rec).max()
     # x-tree pred_mode="v" (xparam :128-139,161-162: predict_start_from_v), through cdc_decode and through cdc_ddim_step
     un, kw, sd, x, time, ctx, _ = make_unet("small_x")
     diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="v", var_schedule="cosine")
     rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
-    assert relerr(rec, g["small_x_v"]) < TOL, relerr(rec, g["small_x_v"])
+    assert relerr(rec, g["small_x_v"]) < TOL_DEC, relerr(rec, g["small_x_v"])
     h = un._handle()
     img = init.copy()
     out = np.empty_like(img)
@@ -827,6 +861,67 @@ def test_fp16_range_overflow_falls_back_to_bf16_planes():
     diff2 = cdc.GaussianDiffusionEps(un2, None, num_timesteps=20000, clip_noise="none", pred_mode="noise", var_schedule="linear")
     ref = diff2.decompress(big, x.shape, sample_steps=2, init=init)
     np.testing.assert_array_equal(rec, ref)
+
+
+OVERFLOW_BLOCK_CASES = [
+    # (case, env) -- one per kernel family that can fuse / follow a Block convolution with LayerNorm + ReLU
+    ((2, 64, 32, 32, 64, 3, 1, 1, True), {}),                                        # conv_split2_kernel, LayerNorm in the epilogue
+    ((2, 64, 32, 32, 64, 3, 1, 1, True), {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),     # conv_pf_kernel
+    ((4, 64, 128, 256, 64, 3, 1, 1, True), {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),   # conv_pf3_kernel (persistent)
+    ((4, 320, 16, 16, 320, 3, 1, 1, True), {}),                                      # split-K partial sums + ln_kernel_sliced
+    ((1, 24, 24, 40, 24, 3, 1, 1, True), {}),                                        # Cout % 32 != 0: convolution + ln_kernel
+    ((1, 64, 36, 32, 192, 1, 1, 0, True), {}),                                       # 1x1 (conv_pw_kernel / split2) + LayerNorm
+]
+
+
+@pytest.mark.parametrize("case,env", OVERFLOW_BLOCK_CASES)
+def test_block_conv_reports_fp16_overflow_where_layernorm_relu_would_hide_it(O, case, env, monkeypatch):
+    """ONE activation outside the fp16 range feeding conv -> LayerNorm -> ReLU (+ residual).  In F16X2 the
+    accumulators of that pixel neighbourhood become inf / NaN, the LayerNorm turns them into NaN and a ReLU written as
+    max(NaN, 0) returns 0 -- finite and wrong, invisible to a check of the result.  Every epilogue therefore reports
+    non-finite accumulators BEFORE its LayerNorm / ReLU (ConvArgs::fault); the call must come back as a range fault,
+    repeated in BF16X3, and match the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B, Ci, H, W, Co, k, s, p, _ = case
+    x = synth.normal("cx", (B, Ci, H, W), 21)
+    x[B - 1, Ci // 2, H // 2, W // 3] = np.float32(1.0e5)            # > 65504
+    w = synth.normal("cw", (Co, Ci, k, k), 21, 1.0 / np.sqrt(Ci * k * k))
+    b = synth.normal("cb", (Co,), 21, 0.1)
+    g = synth.normal("cg", (Co,), 21, 0.2, 1.0)
+    bb = synth.normal("cbb", (Co,), 21, 0.2)
+    conv = O.conv2d(x, w, b, s, p)
+    resid = synth.normal("cr", conv.shape, 21)
+    ref = np.maximum(O.chan_layernorm(conv, g, bb), 0) + resid
+    G = Ops(0)
+    assert G.status() == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}
+    got = G.conv2d(x, w, b, s, p, ln_g=g, ln_b=bb, relu=True, resid=resid)
+    assert G.status() == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}, G.status()
+    assert np.isfinite(got).all()
+    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+    # the same handle, in range again: stays in the full-range arithmetic, no further fault
+    x2 = synth.normal("cx", (B, Ci, H, W), 21)
+    got2 = G.conv2d(x2, w, b, s, p, ln_g=g, ln_b=bb, relu=True, resid=resid)
+    ref2 = np.maximum(O.chan_layernorm(O.conv2d(x2, w, b, s, p), g, bb), 0) + resid
+    assert relerr(got2, ref2) < 2e-5 and G.status()["range_faults"] == 1
+
+
+def test_overflow_of_a_block_input_only_is_detected_inside_the_network(O):
+    """The in-network form of the case above: a time-embedding bias of 2e5 on one channel makes h1 = Block1(x) + mlp(t) leave
+    the fp16 range; h1 feeds block2 and nothing else (network_components.py:107-114), so the overflow sits ONLY in the
+    input of a conv -> LayerNorm -> ReLU and the residual path keeps every tensor finite.  The forward must report a
+    range fault and agree with the oracle (before round 4 this relied on a later linear layer meeting the value)."""
+    un, kw, sd, x, time, ctx, _ = make_unet("small_x")
+    sd = {k: v.copy() for k, v in sd.items()}
+    key = "downs.1.1.mlp.1.bias"
+    sd[key][3] = np.float32(2.0e5)
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    ref = om.unet_forward(O, oracle_cfg(kw), sd, x, time, ctx)
+    assert np.isfinite(ref).all()
+    y = un(x, time, ctx)
+    assert un.status() == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}, un.status()
+    assert relerr(y, ref) < 3e-5, relerr(y, ref)
 
 
 def _small_compressor():
@@ -951,6 +1046,30 @@ def test_bench_under_torchrun_one_rank_nccl(tmp_path):
     assert d["n_gpus"] == 1 and d["config"]["rccl_ranks_seen"] == 1
     assert d["config"]["global_batch"] == 3 and d["config"]["finite"] is True
     assert d["value"] > 0 and d["roofline"]["achieved"] >= 0
+
+
+def test_bench_multi_rank_branch_two_ranks_on_one_gpu():
+    """the world > 1 branch of bench.py (per-rank seeds, shard of a global batch, all_gather of the decoded
+    images, MAX-over-ranks timing, rank count, per-rank verification) on the one GPU of a test box: torchrun starts TWO ranks
+    that share cuda:0 and the collectives run over gloo (RCCL refuses two ranks on one device).  The 8-GPU command differs
+    only in `--backend nccl` (the default) and one GPU per rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}    # bench.py sets it itself
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--batch", "3", "--sample-steps", "6", "--size", "64", "--no-cpu-baseline", "--prof-every", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 6 and d["config"]["batch_per_gpu"] == 3 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["verify"]["ok"] is True and d["config"]["finite"] is True
+    assert d["scaling"] == "weak" and abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and "other_configs" not in d   # N = 1 legs only
 
 
 def test_inference_script_counterpart_on_kodak_crops(tmp_path):

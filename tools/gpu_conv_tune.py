@@ -37,7 +37,7 @@ if __name__ == "__main__":
         shape, plans = sys.argv[1:9], sys.argv[9:] or ["auto"]
         print("shape B,Cin,H,W,Cout,k,s,LN =", " ".join(shape), flush=True)
         for p in plans:
-            env = dict(os.environ, TUNE_CHILD="1", CDC_DEBUG_PLAN="1")
+            env = dict(os.environ, TUNE_CHILD="1", CDC_DEBUG_PLAN="1", CDC_DEV="1")   # CDC_PLAN is a development switch
             if p != "auto":
                 env["CDC_PLAN"] = p
             r = subprocess.run([sys.executable, __file__] + shape, env=env, capture_output=True, text=True)

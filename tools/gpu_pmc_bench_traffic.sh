@@ -5,6 +5,7 @@
 # per /opt/skills/guides/MI355X_MICROARCH.md: hbm_bytes = FETCH_SIZE*1024*2 (gfx950 reports 1/2 of a wide coalesced
 # read) + WRITE_SIZE*1024.  Writes profiles-ready files under gpurun_out/pmc_r02/ (copy them to profiles/).
 set -u
+export CDC_DEV=1      # the CDC_* planner switches below are development switches (cdc_internal.h: dev_env)
 SHAPE="${1:-32 64 256 256 64 3 1 1}"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_r02
 mkdir -p $OUT

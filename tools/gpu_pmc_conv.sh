@@ -2,6 +2,7 @@
 # Development aid: PMC counters (separate passes) for one convolution shape via tools/gpu_conv_tune.py child.
 # usage: gpu_pmc_conv.sh "<B Cin H W Cout k s LN>" [CDC_PLAN]
 set -u
+export CDC_DEV=1      # the CDC_* planner switches below are development switches (cdc_internal.h: dev_env)
 SHAPE="$1"; PLAN="${2:-}"
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc

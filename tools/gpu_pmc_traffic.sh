@@ -3,6 +3,7 @@
 # --kernel-trace), per MI355X_MICROARCH.md: hbm_bytes = FETCH_SIZE*1024*2 (gfx950 reports 1/2 of a wide
 # coalesced read) + WRITE_SIZE*1024 (uncalibrated).   usage: gpu_pmc_traffic.sh "<B Cin H W Cout k s LN>"
 set -u
+export CDC_DEV=1      # the CDC_* planner switches below are development switches (cdc_internal.h: dev_env)
 SHAPE="$1"
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic

@@ -5,6 +5,7 @@
 #   rocprof_r02_kernel_stats.csv rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline`
 #   pmc_r02_*                    PMC passes for the dominant launch shape (tools/gpu_pmc_bench_traffic.sh)
 set -u
+export CDC_DEV=1      # the CDC_* planner switches below are development switches (cdc_internal.h: dev_env)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles_r02; mkdir -p $OUT
 cd $R
 CDC_BENCH_OPS=400 python bench.py > $OUT/bench_r02.json 2> $OUT/bench_stderr.txt
