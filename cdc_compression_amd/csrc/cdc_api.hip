@@ -653,9 +653,9 @@ struct Builder {
         char buf[160];
         const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack"};
         if (op.kind == Op::CONV)
-            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d KC%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d tg%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.KC, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? " SPLIT2H" : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.tg, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? (op.plan.pipe ? " SPLIT2H PIPE" : " SPLIT2H") : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)

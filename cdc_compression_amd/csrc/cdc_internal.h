@@ -22,6 +22,7 @@ conv_kernel_fn conv_lookup_split(int MB, int NPW);           // conv_split_kerne
 conv_kernel_fn conv_lookup_split_abl(int MB, int NPW, int abl);
 conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);
 conv_kernel_fn conv_lookup_split2h(int MB, int NPW, int lnmode, int xu = 1);   // AR = 1: two fp16 planes
+conv_kernel_fn conv_lookup_split2hp(int MB, int NPW, int lnmode, int xu = 1);  // AR = 1, software-pipelined tap loop (PIPE = 1)
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;

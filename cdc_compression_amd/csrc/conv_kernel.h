@@ -143,6 +143,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &P, const TileGeom 
         const size_t pix = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
         if (P.pre_add) {
             // hoisted partial sums (context half of a concatenated input), same addressing as out
+            // (loading them BEFORE the K loop as the accumulators' start value was measured in round 4: slower, 0.40 -> 0.43 ms on
+            // the first 7x1 layer -- the 64 loads per lane delay the prologue, while here the other workgroups of the CU cover them)
             const float *pp = P.pre_add + (size_t)b * P.out_bs + pix +
                               (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll

@@ -109,6 +109,19 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     const int ar = s.arith;                          // 1: two fp16 planes (register-staged variant only)
     const int xpl = ar ? 16 : 24;                    // floats of split patch per position
     auto lookup2 = [&](int mb, int npw, int ln, int xu) { return ar ? conv_lookup_split2h(mb, npw, ln, xu) : conv_lookup_split2(mb, npw, ln, xu); };
+    // software-pipelined tap loop (round 4 experiment, off by default): CDC_SPLIT2_PIPE = 0 off, 1 every fp16 shape with more than
+    // one tap, 2 only the variants that keep three waves per SIMD (<= 168 VGPRs)
+    static const int pipe_mode = dev_env("CDC_SPLIT2_PIPE") ? atoi(dev_env("CDC_SPLIT2_PIPE")) : 0;
+    const int xu_of = s.stride == 2 ? 2 : 1;
+    conv_kernel_fn pipe_fn = (ar && s.KH * s.KW > 1 && pipe_mode != 0) ? conv_lookup_split2hp(MB, NPW, s.lnmode, xu_of) : nullptr;
+    // Measured (round 4, tools/gpu_r04_b.sh, per-workgroup cycle timelines): the pipelined loop shortens a workgroup's life by 12 - 33 %,
+    // but where its second operand set costs the third workgroup per CU (> 168 VGPRs) the layer gets SLOWER (256->64 @128^2 0.517 ->
+    // 0.538 ms, transposed 64 ch 0.377 -> 0.450): these kernels are bound by what a CU's resident workgroups overlap, not by
+    // one wave's latency chain.  Mode 2 (the variants that keep three waves per SIMD) changes nothing measurable either (1x7 final
+    // layer 0.383 -> 0.377 ms, 384 -> 384 @8^2 0.0389 -> 0.0401: the one-block tiles are LDS-bandwidth-bound, 5 ds_read_b128 per 3
+    // MFMAs), so the loop stays off by default.
+    bool pipe = pipe_fn != nullptr;
+    if (pipe && pipe_mode == 2 && kernel_vgprs(pipe_fn) > 168) pipe = false;
     const int nblocks = ceil_div(s.Cout, 32);
     if (nblocks % MB) return false;
     const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
@@ -137,7 +150,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // a third workgroup per CU (+12 % measured on 64->64 @256^2) when single-tap stages bring the LDS
     // footprint under 160/3 KiB and the kernel's registers allow three waves per SIMD
     if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !dev_env("CDC_NO_TG1"))
-        if (conv_kernel_fn f = lookup2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
+        if (conv_kernel_fn f = pipe ? pipe_fn : lookup2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
             if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
     // Few workgroups (low-resolution levels): the chip cannot hide the weight-stage latency by occupancy,
     // so stage ALL taps of a chunk at once -- one barrier and one DMA wait per 16 channels, and the DMA of
@@ -178,6 +191,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->ipw = ipw;
     p->xu = v2 ? xu : 1;
     p->arith = v2 ? ar : 0;
+    p->pipe = (v2 && ar && pipe) ? 1 : 0;
     return true;
 }
 
@@ -274,7 +288,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     const int xv = p.xvec ? 4 : 1;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
-    conv_kernel_fn fn = p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
+    conv_kernel_fn fn = p.split == 2 ? (p.arith ? (p.pipe ? conv_lookup_split2hp(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu))
+                                                : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
 #ifdef CDC_WITH_ABLATIONS      // tuning build only (make ABL=1): compile-time ablated kernels, wrong results
     static const int ablate = dev_env("CDC_ABLATE") ? atoi(dev_env("CDC_ABLATE")) : 0;

@@ -250,8 +250,9 @@ constexpr int kXR = 8;      // float4 registers per thread for the in-flight pat
 // LNMODE 2 (1x1 only): PreNorm LayerNorm folded as in conv_kernel.h -- the pixel mean is subtracted before
 // the split, the accumulators are scaled by rstd in the epilogue, g and W.b live in the packed weights.
 // three workgroups per CU wherever the accumulators leave room (<= 168 VGPRs)
-constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int AR = 0) {
-    if (XU > 1) return 2;
+constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int AR = 0, int PIPE = 0) {
+    if (PIPE && XU == 1 && MB * NPW <= 2) return 3;     // PIPE: two operand register sets; the small tiles still fit three workgroups per CU
+    if (XU > 1 || PIPE) return MB * NPW > 4 ? 1 : 2;
     return (LNMODE == 0 ? MB * NPW <= 4 : (MB * NPW <= 2 || (LNMODE == 2 && (MB * NPW == 3 || (MB == 4 && NPW == 1))))) ? 3 : 2;
 }
 
@@ -260,8 +261,14 @@ constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int AR = 0
 // other column) are contiguous 16-byte units instead of a 2-way bank conflict.
 // (An all-phase ConvTranspose2d variant -- four phases per workgroup, one shared patch -- was measured slower than four
 // phase launches folded onto one XCD, 0.54 vs 0.46 ms at 128^2 -> 256^2, and was removed in round 2.)
-template <int MB, int NPW, int LNMODE = 0, int XU = 1, int AR = 0>
-__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) conv_split2_kernel(const ConvArgs P) {
+// PIPE = 1 (AR = 1 only; round 4): software-pipelined tap loop.  The round-3 loop read the operands of a tap, waited for LDS,
+// multiplied, read the next term's weights, waited, ... -- three to four dependent LDS round trips per tap with two to four MFMAs
+// between them (cycle timeline of wave 0, stride-2 64->64 @256^2: 1570 cycles per tap for 192 cycles of matrix work).  PIPE keeps two
+// operand register sets: all ds_reads of tap t+1 (activation planes always; weight planes unless the tap opens a new weight stage,
+// which is read right after the stage's barrier) are issued BEFORE the MFMAs of tap t.
+template <int MB, int NPW, int LNMODE = 0, int XU = 1, int AR = 0, int PIPE = 0>
+__global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR, PIPE)) conv_split2_kernel(const ConvArgs P) {
+    static_assert(PIPE == 0 || AR == 1, "the pipelined tap loop exists for the fp16 arithmetic only");
     constexpr int NP = AR == 1 ? 2 : 3;               // B-operand (activation) planes
     static_assert(XU == 1 || LNMODE == 0, "two-unit variant carries no LayerNorm-on-load");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -536,6 +543,111 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR)) 
     issue_w(0, c_lo, 0);
     int wstage = 0;
     TLC(0);
+    if constexpr (PIPE != 0) {
+        typedef f16x8 OpA[3][MB];
+        typedef f16x8 OpB[2][NPW];
+        OpA A0, A1;
+        OpB B0, B1;
+        const int T = P.KH * P.KW;
+        const uint4 *xcu = reinterpret_cast<const uint4 *>(xc);
+        const uint4 *wlu = reinterpret_cast<const uint4 *>(wl) + a_lane;
+        const int wst_u = wst_floats / 4;
+        // fetch cursor = the next tap to read: (fky, fkx), its index ftt inside its weight stage, the stage buffer fst
+        int fky = 0, fkx = 0, ftt = 0, fst = 0;
+        auto fetchB = [&](OpB &Bv) {
+            const uint4 *xb = xcu + (fky * PW + (s2 ? ((fkx + xs) & 1) * (PW / 2) + ((fkx + xs) >> 1) : fkx));
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) Bv[p][n] = __builtin_bit_cast(f16x8, xb[bidx[p][n]]);
+        };
+        auto fetchA = [&](OpA &A) {
+            const uint4 *wa = wlu + fst * wst_u + ftt * 6 * COPT;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa[(pl * 2) * COPT + m * 32]);
+        };
+        auto advance = [&]() {
+            if (++fkx == P.KW) { fkx = 0; ++fky; }
+            if (++ftt == TG) { ftt = 0; fst ^= 1; }
+        };
+        // planes: B = {h, l'}, A = {WH, WL, WH2}; terms smallest first: WL.h, WH2.l', WH.h
+        auto mma = [&](const OpA &A, const OpB &Bv) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                constexpr int PA[3] = {1, 2, 0};
+                constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term]][m], Bv[PB[term]][n], acc[0][m][n], 0, 0, 0);
+            }
+        };
+        for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+            store_x(chunk);
+            TLC(1);
+            dma_wait();                         // first weight stage landed (nothing else is in flight)
+            __syncthreads();                    // planes of `chunk` + first weight stage visible
+            TLC(2);
+            if (chunk + 1 < c_hi) load_x(chunk + 1);
+            int grp = 0, ctt = 0;               // weight stage (tap group) of the current tap, the tap's index inside it
+            if (1 < ntg) issue_w(1, chunk, wstage ^ 1);
+            else if (chunk + 1 < c_hi) issue_w(0, chunk + 1, wstage ^ 1);
+            fky = 0; fkx = 0; ftt = 0; fst = wstage;
+            fetchA(A0);
+            fetchB(B0);
+            advance();
+            __builtin_amdgcn_s_setprio(3);
+            // The fetches of a step are unconditional: a fetch under a condition makes hipcc's s_waitcnt insertion merge the two
+            // paths conservatively (the MFMAs then wait for the operands just requested), and MFMAs on two branches double the
+            // accumulator registers.  At the last tap of a weight stage the next tap's weights are not visible yet: that read
+            // returns stale data and is repeated right after the stage's barrier.
+            auto group_end_sync = [&]() {
+                __builtin_amdgcn_s_setprio(0);
+                TLC(3);
+                dma_wait();                     // the next stage (this wave's pieces) landed ...
+                TLC(4);
+                __syncthreads();                // ... everyone's did, and everyone is done reading this one
+                TLC(5);
+                wstage ^= 1;
+                ++grp;
+                ctt = 0;
+            };
+            // one tap that has a successor: operands (Ax, Bx) are in registers, the cursor points at the next tap -> (Ay, By)
+            auto step = [&](const OpA &Ax, const OpB &Bx, OpA &Ay, OpB &By) {
+                fetchB(By);
+                fetchA(Ay);
+                __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the reads below the first MFMAs)
+                mma(Ax, Bx);
+                __builtin_amdgcn_sched_barrier(0);
+                if (++ctt == TG) {
+                    group_end_sync();
+                    if (grp + 1 < ntg) issue_w(grp + 1, chunk, wstage ^ 1);
+                    else if (chunk + 1 < c_hi) issue_w(0, chunk + 1, wstage ^ 1);
+                    fetchA(Ay);
+                    __builtin_amdgcn_s_setprio(3);
+                }
+                advance();
+            };
+            auto last = [&](const OpA &Ax, const OpB &Bx) {
+                mma(Ax, Bx);
+                group_end_sync();
+            };
+            int cur = 0;
+            for (; cur + 2 < T; cur += 2) {
+                step(A0, B0, A1, B1);
+                step(A1, B1, A0, B0);
+            }
+            if (T - cur == 2) {
+                step(A0, B0, A1, B1);
+                last(A1, B1);
+            } else {
+                last(A0, B0);
+            }
+        }
+    } else
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         // (everyone finished reading the previous chunk's planes: the barrier that ends its last tap group)
 #ifndef CDC_AB_NOSTOREX

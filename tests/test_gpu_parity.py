@@ -19,8 +19,8 @@ from helpers import GOLDEN, digest_idx, load_case, oracle_cfg
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4         # north_star's statement.  The test bounds below are ~3x what is MEASURED on the MI355X:
-TOL_FWD = 1.5e-5   #   one U-Net / compressor forward (or a stage of it) against the reference golden: measured <= 5e-6
-TOL_DEC = 3e-5     #   a few-step / full-length decode chain against the reference golden: measured <= 1e-5
+TOL_FWD = 1e-5     #   one U-Net / compressor forward (or a stage of it) against the reference golden: measured <= 3.0e-6
+TOL_DEC = 5e-5     #   a few-step / full-length decode chain against the reference golden: measured <= 1.8e-5
 # (CDC_TEST_OBS=<file>: every relerr() of a run is appended there with its test id -- how the bounds were measured;
 #  tools/gpu_parity_obs.sh, summary under profiles/parity_obs_r04.txt)
 
@@ -101,7 +101,7 @@ def test_conv2d_matches_oracle(O, G, case):
     ref = O.conv2d(x, w, b, s, p)
     got = G.conv2d(x, w, b, s, p)
     assert got.shape == ref.shape
-    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+    assert relerr(got, ref) < 1e-5, relerr(got, ref)
     if fused:
         g = synth.normal("cg", (Co,), 21, 0.2, 1.0)
         bb = synth.normal("cbb", (Co,), 21, 0.2)
@@ -109,10 +109,10 @@ def test_conv2d_matches_oracle(O, G, case):
         resid = synth.normal("cr", ref.shape, 21)
         r2 = np.maximum(O.chan_layernorm(ref, g, bb), 0) + shift[:, :, None, None] + resid
         g2 = G.conv2d(x, w, b, s, p, ln_g=g, ln_b=bb, relu=True, shift=shift, resid=resid)
-        assert relerr(g2, r2) < 5e-5, relerr(g2, r2)
+        assert relerr(g2, r2) < 1e-5, relerr(g2, r2)
 
 
-def _conv_check(O, G, case, tol_plain=2e-5, tol_fused=5e-5):
+def _conv_check(O, G, case, tol_plain=1e-5, tol_fused=1e-5):
     B, Ci, H, W, Co, k, s, p, fused = case
     x = synth.normal("cx", (B, Ci, H, W), 21)
     w = synth.normal("cw", (Co, Ci, k, k), 21, 1.0 / np.sqrt(Ci * k * k))
@@ -162,10 +162,10 @@ def test_conv2d_pointwise_kernel(O, case, monkeypatch):
     w = synth.normal("pw", (Co, Ci, 1, 1), 27, 1.0 / np.sqrt(Ci))
     b = synth.normal("pb", (Co,), 27, 0.1)
     ref = O.conv2d(x, w, b, 1, 0)
-    assert relerr(G2.conv2d(x, w, b, 1, 0), ref) < 2e-5
+    assert relerr(G2.conv2d(x, w, b, 1, 0), ref) < 1e-5
     resid = synth.normal("pr", ref.shape, 27)
     r2 = ref + resid
-    assert relerr(G2.conv2d(x, w, b, 1, 0, resid=resid), r2) < 2e-5
+    assert relerr(G2.conv2d(x, w, b, 1, 0, resid=resid), r2) < 1e-5
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[4], CONV_CASES[6], CONV_CASES[7], CONV_CASES[10], CONV_CASES[11]] + PF_CASES[:2])
@@ -184,14 +184,14 @@ def test_conv_transpose2d_matches_oracle(O, G, case):
     b = synth.normal("tb", (Co,), 22, 0.1)
     ref = O.conv_transpose2d(x, w, b, 2, 1)
     got = G.conv_transpose2d(x, w, b)
-    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+    assert relerr(got, ref) < 1e-5, relerr(got, ref)
 
 
 def test_layernorm_matches_oracle(O, G):
     x = synth.normal("lx", (2, 48, 9, 7), 23, 2.0, 0.5)
     g = synth.normal("lg", (48,), 23, 0.2, 1.0)
     b = synth.normal("lb", (48,), 23, 0.2)
-    assert relerr(G.chan_layernorm(x, g, b), O.chan_layernorm(x, g, b)) < 1e-5
+    assert relerr(G.chan_layernorm(x, g, b), O.chan_layernorm(x, g, b)) < 1e-6
 
 
 @pytest.mark.parametrize("case", [(2, 16, 8, 8), (1, 64, 32, 32), (2, 64, 64, 64), (1, 128, 64, 64), (2, 128, 16, 16), (1, 384, 8, 8),
@@ -207,7 +207,7 @@ def test_linear_attention_matches_oracle(O, G, case):
     ref = om.attention(O, sd, "a", x)
     got = G.linear_attention(x, sd["a.fn.norm.g"], sd["a.fn.norm.b"], sd["a.fn.fn.to_qkv.weight"],
                              sd["a.fn.fn.to_out.weight"], sd["a.fn.fn.to_out.bias"])
-    assert relerr(got, ref) < 5e-5, relerr(got, ref)
+    assert relerr(got, ref) < 5e-6, relerr(got, ref)
 
 
 @pytest.mark.parametrize("case,env", [((2, 64, 64, 64), {"CDC_KVCTX16": "0"}), ((2, 64, 64, 64), {"CDC_KVCTX16": "2"}),
@@ -232,7 +232,7 @@ def test_linear_attention_alternate_kernels(O, case, env, monkeypatch):
     ref = om.attention(O, sd, "a", x)
     got = G2.linear_attention(x, sd["a.fn.norm.g"], sd["a.fn.norm.b"], sd["a.fn.fn.to_qkv.weight"],
                               sd["a.fn.fn.to_out.weight"], sd["a.fn.fn.to_out.bias"])
-    assert relerr(got, ref) < 5e-5, relerr(got, ref)
+    assert relerr(got, ref) < 5e-6, relerr(got, ref)
 
 
 def make_unet(name):
@@ -360,7 +360,7 @@ def test_full_resolution_256_digest_and_properties():
     t2 = np.concatenate([g["time"], g["time"]])
     y2 = un(x2, t2, ctx2)
     np.testing.assert_array_equal(y2[0], y2[1])
-    assert relerr(y2[0], y[0]) < 1e-5
+    assert relerr(y2[0], y[0]) < 5e-6
 
 
 def test_run_to_run_determinism(G):
@@ -446,7 +446,7 @@ def test_batch32_launch_plans_match_batch1():
     B = 32
     y32 = un(np.repeat(x, B, 0), np.repeat(t, B, 0), [np.repeat(c, B, 0) for c in ctx])
     for k in (0, 1, 17, 31):
-        assert relerr(y32[k], y1[0]) < 1e-5, (k, relerr(y32[k], y1[0]))
+        assert relerr(y32[k], y1[0]) < 5e-6, (k, relerr(y32[k], y1[0]))
     np.testing.assert_array_equal(y32[5], y32[26])
 
 
@@ -511,7 +511,7 @@ def test_non_square_frame_against_double_accumulating_oracle():
     t = np.full((B, 1), 0.41, np.float32)
     y = un(x, t, ctx)
     ref64 = om.unet_forward(oops.OrcOps("f64"), oracle_cfg(kw), sd, x, t, ctx)
-    assert relerr(y, ref64) < 2e-5, relerr(y, ref64)
+    assert relerr(y, ref64) < 1e-5, relerr(y, ref64)
 
 
 @pytest.mark.parametrize("name", ["hyperdec_small_x", "hyperdec_full_x", "hyperdec_full_eps"])
@@ -725,7 +725,7 @@ def test_eps_param_256_matches_reference_digest_and_batch32_rows():
     B = 32
     y32 = un(np.repeat(x, B, 0), np.repeat(g["time"], B, 0), [np.repeat(c, B, 0) for c in ctx])
     for k in (0, 13, 31):
-        assert relerr(y32[k], y1[0]) < 1e-5, (k, relerr(y32[k], y1[0]))
+        assert relerr(y32[k], y1[0]) < 5e-6, (k, relerr(y32[k], y1[0]))
     rec32 = diff.decompress([np.repeat(c, B, 0) for c in ctx], (B, 3, H, W), sample_steps=steps, init=np.repeat(init, B, 0))
     for k in (0, 19, 31):
         assert relerr(rec32[k], rec1[0]) < 3e-5, (k, relerr(rec32[k], rec1[0]))
@@ -833,7 +833,7 @@ def test_heavy_tailed_parameters_match_reference_in_both_arithmetics(case):
         un.load_state_dict(sd)
         _lib.check(un._handle(), _lib.lib().cdc_set_arith(un._handle(), arith))
         y = un(x, time, ctx)
-        assert relerr(y, y_ref) < 2e-4, (case, arith, relerr(y, y_ref))
+        assert relerr(y, y_ref) < 1e-5, (case, arith, relerr(y, y_ref))
         st = un.status()
         if arith == 1 and case == "in_range":
             assert biggest < 65504 and st == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}, st
@@ -841,7 +841,7 @@ def test_heavy_tailed_parameters_match_reference_in_both_arithmetics(case):
             assert biggest > 65504 and st == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}, st
         diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
         rec = diff.decompress(ctx, x.shape, sample_steps=3, init=init)
-        assert float(np.abs(rec - rec_ref).max()) < 2e-4, (case, arith, float(np.abs(rec - rec_ref).max()))
+        assert relerr(rec, rec_ref) < TOL_DEC, (case, arith, relerr(rec, rec_ref))     # (|rec| <= 1: absolute = relative)
 
 
 def test_fp16_range_overflow_falls_back_to_bf16_planes():
@@ -868,7 +868,7 @@ OVERFLOW_BLOCK_CASES = [
     ((2, 64, 32, 32, 64, 3, 1, 1, True), {}),                                        # conv_split2_kernel, LayerNorm in the epilogue
     ((2, 64, 32, 32, 64, 3, 1, 1, True), {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),     # conv_pf_kernel
     ((4, 64, 128, 256, 64, 3, 1, 1, True), {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),   # conv_pf3_kernel (persistent)
-    ((4, 320, 16, 16, 320, 3, 1, 1, True), {}),                                      # split-K partial sums + ln_kernel_sliced
+    ((4, 320, 16, 16, 328, 3, 1, 1, True), {}),                                      # Cout % 32 != 0, C <= 384: convolution + ln_kernel_sliced
     ((1, 24, 24, 40, 24, 3, 1, 1, True), {}),                                        # Cout % 32 != 0: convolution + ln_kernel
     ((1, 64, 36, 32, 192, 1, 1, 0, True), {}),                                       # 1x1 (conv_pw_kernel / split2) + LayerNorm
 ]
@@ -898,12 +898,12 @@ def test_block_conv_reports_fp16_overflow_where_layernorm_relu_would_hide_it(O, 
     got = G.conv2d(x, w, b, s, p, ln_g=g, ln_b=bb, relu=True, resid=resid)
     assert G.status() == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}, G.status()
     assert np.isfinite(got).all()
-    assert relerr(got, ref) < 2e-5, relerr(got, ref)
+    assert relerr(got, ref) < 1e-5, relerr(got, ref)
     # the same handle, in range again: stays in the full-range arithmetic, no further fault
     x2 = synth.normal("cx", (B, Ci, H, W), 21)
     got2 = G.conv2d(x2, w, b, s, p, ln_g=g, ln_b=bb, relu=True, resid=resid)
     ref2 = np.maximum(O.chan_layernorm(O.conv2d(x2, w, b, s, p), g, bb), 0) + resid
-    assert relerr(got2, ref2) < 2e-5 and G.status()["range_faults"] == 1
+    assert relerr(got2, ref2) < 1e-5 and G.status()["range_faults"] == 1
 
 
 def test_overflow_of_a_block_input_only_is_detected_inside_the_network(O):
@@ -921,7 +921,7 @@ def test_overflow_of_a_block_input_only_is_detected_inside_the_network(O):
     assert np.isfinite(ref).all()
     y = un(x, time, ctx)
     assert un.status() == {"arith": 0, "range_faults": 1, "nonfinite_results": 0}, un.status()
-    assert relerr(y, ref) < 3e-5, relerr(y, ref)
+    assert relerr(y, ref) < 1e-5, relerr(y, ref)
 
 
 def _small_compressor():
