@@ -730,7 +730,9 @@ struct Builder {
         const int m = pf_mode();
         if (m == 1) return s != SITE_NONE;
         if (m != 3) return false;
-        const long long join_max = dev_env("CDC_PF_JOIN_MAXPIX") ? atoll(dev_env("CDC_PF_JOIN_MAXPIX")) : 4096;
+        // (round 4: up to 128 x 128 -- the Upsample half of a join is written as planes INSTEAD of fp32 when both of its readers take
+        //  planes, join_reads_planes, so only the skip half costs a second copy: 256->64 @128^2 0.52 -> 0.37 ms on conv_pf3_kernel)
+        const long long join_max = dev_env("CDC_PF_JOIN_MAXPIX") ? atoll(dev_env("CDC_PF_JOIN_MAXPIX")) : 16384;
         return s == SITE_RB_CHAIN || s == SITE_DOWN || (s == SITE_JOIN && (long long)H * W <= join_max);
     }
     bool pf_on() const { return pf_mode() != 0; }
@@ -787,7 +789,29 @@ struct Builder {
         bool no_f32 = false;                           // PF path only: nobody reads the fp32 copy of `out`
     };
     int last_ksplit = 1;                               // slices the last conv() call really used
+    bool last_pf_only = false;                         // the last conv() call wrote its result as planes only (no fp32 copy exists)
     const float *next_res3_w = nullptr, *next_res3_x = nullptr; long long next_res3_bs = 0;   // for the next block()
+
+    // Would BOTH readers of a decoder join cat[a0, a1] -- block1 (3x3, fused LayerNorm) and res_conv (1x1) of the ResnetBlock -- run
+    // on the plane-operand kernels, given the twins of the two halves?  Then a0 (an Upsample output, read by nothing else) needs no
+    // fp32 copy at all.  Mirrors the conditions of try_pf.
+    bool join_reads_planes(const ResBlockW &rb, const float *p0, int C0, const float *p1, int H, int W) {
+        if (!pf_on() || !rb.has_res || rb.hoist_cx || dev_env("CDC_NO_PF_ONLY_JOIN")) return false;
+        PfTwin *t0 = twin(p0), *t1 = twin(p1);
+        if (!t0 || !t1 || !t1->valid || t0->H != H || t0->W != W || t1->H != H || t1->W != W) return false;
+        if (t0->C != C0 || t0->C + t1->C != rb.c1.Cin || rb.cres.Cin != rb.c1.Cin || (C0 % 16)) return false;
+        for (const ConvW *w : {&rb.c1, &rb.cres}) {
+            const bool k3 = w->KH == 3 && w->KW == 3, k1 = w->KH == 1 && w->KW == 1;
+            if (!w->wsh || w->stride != 1 || w->transposed || (w->Cin % 16) || !(k3 || k1)) return false;
+            if ((w->pad_y >= 0 ? w->pad_y : w->pad) != w->KH / 2 || (w->pad_x >= 0 ? w->pad_x : w->pad) != w->KW / 2) return false;
+            PfShape ps;
+            ps.Cin = w->Cin; ps.Cout = w->Cout; ps.C0 = C0; ps.KH = w->KH; ps.KW = w->KW; ps.nz = 1; ps.Ho = H; ps.Wo = W; ps.B = pb();
+            ps.need_all_cout = k3;
+            PfPlan plan;
+            if (!pf_make_plan(ps, &plan)) return false;
+        }
+        return true;
+    }
 
     // Would a single-source 3x3 / 1x1 layer with fused LayerNorm run on conv_pf_kernel (given a PF input)?
     bool pf_would_plan(const ConvW &w, int H, int W) {
@@ -875,6 +899,7 @@ struct Builder {
         op.flops = 2.0 * px * w.Cout * w.Cin * w.KH * w.KW;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
         last_ksplit = 1;
+        last_pf_only = a.out == nullptr;
         emit(op);
         return true;
     }
@@ -929,6 +954,7 @@ struct Builder {
         op.flops = 2.0 * px * w.Cout * w.Cin;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
         last_ksplit = 1;
+        last_pf_only = false;
         emit(op);
         return true;
     }
@@ -978,6 +1004,7 @@ struct Builder {
             return true;
         }
         last_ksplit = 1;
+        last_pf_only = false;
         if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !dev_env("CDC_NO_KSPLIT")) {
             // few workgroups and a long K loop (low-resolution levels): slice K so that the chip holds
             // >= 4 workgroups per CU; the LayerNorm kernel that follows adds the slices
@@ -1054,6 +1081,7 @@ struct Builder {
                         a.pf_ys = Wt + 2; a.pf_xs = 1; a.pf_zoff[0] = (Wt + 2) + 1;
                     }
                     a.pf_only = o.no_f32 ? 1 : 0;
+                    last_pf_only = a.pf_only != 0;
                     to->valid = true;
                 }
             }
@@ -1252,7 +1280,7 @@ struct Builder {
     std::vector<std::pair<const float *, size_t>> dbg_taps;   // debugging aid (CDC_ATTN_TAP)
 
     // Residual(PreNorm(LinearAttention)) (network_components.py:10-16,69-77,117-139)
-    Act attention(const AttnW &at, Act x, float *sm, float *sr) {
+    Act attention(const AttnW &at, Act x, float *sm, float *sr, Site out_site = SITE_JOIN) {
         if (rc) return Act();
         const int C = at.C, H = x.H, W = x.W, N = H * W;
         const bool fold = at.WoT && N >= 16 * C && !dev_env("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
@@ -1321,7 +1349,7 @@ struct Builder {
         ConvW cw;    // per-image weights produced above
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
         cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1; cw.bias = nullptr;
-        Act y = new_act(C, H, W, true, SITE_JOIN);      // skip tensor / Upsample input: a decoder concat half
+        Act y = new_act(C, H, W, true, out_site);       // a skip tensor is a decoder concat half; an Upsample input has no plane reader
         if (!fused)
         dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
                     {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
@@ -1418,7 +1446,8 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         h->taps[dn + ".0"] = x;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         h->taps[dn + ".1"] = x;
-        x = bd.attention(h->attns[ati++], x, sm, sr);
+        // (the level-0 skip is never popped -- unet.py:113 pushes six, :123 pops five: its only reader is the Downsample)
+        x = bd.attention(h->attns[ati++], x, sm, sr, i >= 1 ? Builder::SITE_JOIN : Builder::SITE_NONE);
         h->taps[dn + ".2"] = x;
         skips.push_back(x);
         if (i < n - 1) {
@@ -1450,11 +1479,16 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
         x = bd.resblock(h->rbs[rbi++], x, &skip, false, nullptr, nullptr, Builder::SITE_RB_CHAIN);
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
-        x = bd.attention(h->attns[ati++], x, sm, sr);
+        // (an Upsample reads fp32: planes of its input only with the development switch that runs it on conv_pf_kernel)
+        x = bd.attention(h->attns[ati++], x, sm, sr, dev_env("CDC_PF_TRANSPOSED") ? Builder::SITE_JOIN : Builder::SITE_NONE);
         const ConvW &uw = h->ups[i];
         Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2, true, Builder::SITE_JOIN);
         Builder::ConvOpts ou;
         ou.emit_pf = i < n - 2;              // (the last Upsample feeds the final convolution only)
+        // the next level's join is this tensor's only reader: planes INSTEAD of fp32 when block1 and res_conv both take planes
+        if (i < n - 2 && !skips.empty())
+            ou.no_f32 = bd.join_reads_planes(h->rbs[rbi], y.p, y.C, skips.back().p, y.H, y.W);
+        bool up_pf_only = false;
         bool done = false;
         if (i == n - 2) {
             // the final LayerNorm (unet.py:104) needs per-pixel statistics of this output: emit them
@@ -1476,13 +1510,14 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         }
         if (!done) {
             bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, false, PC_UP);
+            up_pf_only = bd.last_pf_only;
             if (i == n - 2) {
                 if (!fsm) { fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl); }
                 bd.ln(y.p, nullptr, y.C, y.H * y.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
             }
         }
         x = y;
-        if (!final_ln_done) h->taps["ups." + std::to_string(i)] = x;   // (the last one may hold LN(up(x)) instead)
+        if (!final_ln_done && !up_pf_only) h->taps["ups." + std::to_string(i)] = x;   // (the last one may hold LN(up(x)) instead; a planes-only tensor has no fp32 tap)
         if (bd.rc) return bd.rc;
     }
     if (n == 1) {       // no Upsample stage: statistics of the last attention output
