@@ -97,6 +97,7 @@ def lib():
     L.cdc_hyperdec_decode.argtypes = [H, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _i, _vp]
     L.cdc_entropy_encode.argtypes = [H, _vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), _i, _vp]
     L.cdc_entropy_peek.argtypes = [_vp, ctypes.c_size_t, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]
+    L.cdc_entropy_set_limit.argtypes = [H, _i]
     L.cdc_entropy_decode.argtypes = [H, _vp, ctypes.POINTER(ctypes.c_size_t), _vp, _i, _vp, _vp, _i, _vp]
     L.cdc_dequantize.argtypes = [H, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp]
     L.cdc_bpp.argtypes = [H, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
@@ -131,7 +132,7 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_op_linear_attention", "cdc_ctxdec_create", "cdc_ctxdec_decode", "cdc_hyperdec_create",
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
            "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap", "cdc_prof_num_ops", "cdc_prof_op",
-           "cdc_entropy_encode", "cdc_entropy_peek", "cdc_entropy_decode", "cdc_get_range_faults",
+           "cdc_entropy_encode", "cdc_entropy_peek", "cdc_entropy_set_limit", "cdc_entropy_decode", "cdc_get_range_faults",
            "cdc_get_nonfinite_results", "cdc_set_schedule_v"]
 
 

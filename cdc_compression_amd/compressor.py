@@ -418,10 +418,14 @@ class _ContextDecoder:
         raw = buf[: offs[B]].tobytes()
         return [raw[offs[b]: offs[b + 1]] for b in range(B)]
 
-    def decompress_from_bytes(self, streams, like=None, return_hyper=False):
+    def decompress_from_bytes(self, streams, like=None, return_hyper=False, max_image_hw=None):
         """list of B bitstreams -> q_latent [B, C, h, w] exactly as the encoder dequantised it (numpy, or a tensor on
-        `like`'s device); all streams must have the same latent size."""
+        `like`'s device); all streams must have the same latent size.  max_image_hw=(H, W): refuse streams whose header
+        describes a larger image before anything is allocated (untrusted input; default: the library's 2^22-position bound)."""
         L, h = _lib.lib(), self._hyper_handle()
+        if max_image_hw is not None:
+            down = 2 ** (len(self.reversed_dims) - 1 + len(self.reversed_hyper_dims) - 2) if hasattr(self, "reversed_dims") else 64
+            _lib.check(h, L.cdc_entropy_set_limit(h, max(1, -(-int(max_image_hw[0]) // down)) * max(1, -(-int(max_image_hw[1]) // down))))
         if not (self._hyper_finalized and self._prior_loaded):
             raise _lib.CdcError("the prior.* tensors have not been loaded (load_state_dict with the full state_dict)")
         streams = [bytes(s) for s in streams]

@@ -111,6 +111,7 @@ struct cdc_handle {
     std::vector<double> h_prior;  // kind 2: the same in float64 (probability tables of the entropy coder)
     std::unique_ptr<cdc::EntropyModel> ent;   // kind 2: entropy coder tables (built on first use)
     uint32_t ent_model_hash = 0;
+    int ent_max_positions = 1 << 22;          // kind 2: largest hh * wh cdc_entropy_decode accepts from a stream header (cdc_entropy_set_limit)
     std::vector<int> rev_dims;    // kind 1: [dim*m for m in rev_mults] + [out_channels]
     int up_index = 1;
     std::vector<Act> dec_outs;    // kind 1: outputs of the program, coarsest first
@@ -659,10 +660,10 @@ struct Builder {
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)
-            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s", op.pf.KH, op.pf.KW,
+            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s%s", op.pf.KH, op.pf.KW,
                      op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
                      op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
-                     op.pf.resid ? " +res" : "");
+                     op.pf.resid ? " +res" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -2483,7 +2484,9 @@ int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *of
         const size_t n = offsets[b + 1] - offsets[b];
         Hdr &q = hd[b];
         if (cdc_entropy_peek(s, n, &q.hh, &q.wh, &q.ar)) return fail(h, CDC_ERR_INVALID, "image %d: not a CDC bitstream (version %d container)", b, kStreamVersion);
-        if (q.hh < 1 || q.wh < 1 || (long long)q.hh * q.wh > kMaxHyperPositions) return fail(h, CDC_ERR_INVALID, "image %d: implausible hyper-latent size %d x %d", b, q.hh, q.wh);
+        if (q.hh < 1 || q.wh < 1 || (long long)q.hh * q.wh > std::min(kMaxHyperPositions, h->ent_max_positions))
+            return fail(h, CDC_ERR_INVALID, "image %d: hyper-latent size %d x %d in the stream header exceeds the decoder's limit of %d positions "
+                        "(cdc_entropy_set_limit)", b, q.hh, q.wh, std::min(kMaxHyperPositions, h->ent_max_positions));
         if (q.ar != CDC_ARITH_BF16X3 && q.ar != CDC_ARITH_F16X2) return fail(h, CDC_ERR_INVALID, "image %d: unknown arithmetic %d", b, q.ar);
         q.nbh = get_u32(s + 10); q.nbl = get_u32(s + 14); q.sum = get_u32(s + 22); q.eh = get_u32(s + 26); q.el = get_u32(s + 30);
         if ((unsigned long long)kStreamHeader + q.nbh + q.nbl != n) return fail(h, CDC_ERR_INVALID, "image %d: truncated bitstream", b);
@@ -2568,6 +2571,13 @@ int entropy_decode_impl(cdc_handle *h, const unsigned char *in, const size_t *of
 int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
                        int hh, int wh, unsigned char *out, size_t cap, size_t *offsets, int mem, void *stream) {
     return no_throw(h, [&] { return entropy_encode_impl(h, latent, hyper_latent, medians, B, hh, wh, out, cap, offsets, mem, stream); });
+}
+
+int cdc_entropy_set_limit(cdc_handle *h, int max_hyper_positions) {
+    if (!h || h->kind != 2) return h ? fail(h, CDC_ERR_STATE, "handle is not a hyper decoder") : CDC_ERR_INVALID;
+    if (max_hyper_positions < 1) return fail(h, CDC_ERR_INVALID, "limit %d", max_hyper_positions);
+    h->ent_max_positions = std::min(max_hyper_positions, kMaxHyperPositions);
+    return CDC_OK;
 }
 
 int cdc_entropy_peek(const unsigned char *in, size_t n, int *hh, int *wh, int *arith) {

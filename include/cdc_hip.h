@@ -272,6 +272,10 @@ int cdc_bpp(cdc_handle *h, const float *q_hyper_latent, const float *q_latent, c
 int cdc_entropy_encode(cdc_handle *h, const float *latent, const float *hyper_latent, const float *medians, int B,
                        int h_hyper, int w_hyper, unsigned char *out, size_t cap, size_t *offsets, int mem_kind, void *stream);
 int cdc_entropy_peek(const unsigned char *in, size_t n, int *h_hyper, int *w_hyper, int *arith);
+/* A stream header sizes the decoder's allocations and its hyper_dec launch program (up to 2^22 positions = a 131072 x 131072
+ * image: tens of GB on a 288 GB part).  A caller that knows what it expects bounds that BEFORE decoding untrusted bytes: streams whose
+ * header asks for more than max_hyper_positions = h_hyper * w_hyper are refused (CDC_ERR_INVALID) before anything is allocated. */
+int cdc_entropy_set_limit(cdc_handle *h, int max_hyper_positions);
 /* -> q_latent [B][dims[n]/2][up*h][up*w] (exactly the encoder's dequantised latent) and, optionally, q_hyper_latent. */
 int cdc_entropy_decode(cdc_handle *h, const unsigned char *in, const size_t *offsets, const float *medians, int B,
                        float *q_latent, float *q_hyper_latent, int mem_kind, void *stream);

@@ -306,6 +306,17 @@ def test_corrupt_stream_is_rejected():
         bad = s[:6] + struct.pack("<HH", hh, wh) + s[10:]
         with pytest.raises(_lib.CdcError):
             comp.decompress_from_bytes([bad])
+    # a header may describe up to 2^22 positions (tens of GB of allocations); a caller that knows the image size bounds
+    # it: a plausible but larger-than-expected extent is refused BEFORE anything is allocated, the expected one decodes
+    big = s[:6] + struct.pack("<HH", 1024, 1024) + s[10:]
+    with pytest.raises(_lib.CdcError, match="exceeds the decoder's limit"):
+        comp.decompress_from_bytes([big], max_image_hw=(64, 64))
+    assert comp.decompress_from_bytes([s], max_image_hw=(64, 64)).shape[0] == 1
+    s128 = comp.compress_to_bytes(synth.normal("img", (1, 3, 128, 128), seed=4, std=0.4))[0]      # 2 x 2 hyper positions
+    with pytest.raises(_lib.CdcError, match="exceeds the decoder's limit"):
+        comp.decompress_from_bytes([s128], max_image_hw=(64, 64))
+    assert comp.decompress_from_bytes([s128], max_image_hw=(128, 128)).shape == (1, 256, 8, 8)
+    comp.decompress_from_bytes([s], max_image_hw=(1 << 17, 1 << 17))           # (back to the library's own bound)
     # version-1 containers (no fingerprints) are not accepted
     with pytest.raises(_lib.CdcError):
         comp.decompress_from_bytes([s[:3] + b"\x01" + s[4:]])

@@ -11,6 +11,8 @@ import os
 import sys
 
 out, steps = sys.argv[1], int(sys.argv[2])
+tag = sys.argv[3] if len(sys.argv) > 3 else "r03"            # round tag of the output files
+ops_file = sys.argv[4] if len(sys.argv) > 4 else None        # bench.py --dump-ops: the launch program's op labels in program order
 B = 32
 
 
@@ -73,4 +75,63 @@ json.dump({"steps": steps, "batch": B, "kernels": rows, "hbm_gb_per_image_iter_c
            "hbm_gb_per_image_iter_raw": per_iter_raw / B / 1e9, "canonical_gb_per_image_iter": 0.714,
            "note": "FETCH_SIZE x2 is the guide's gfx950 correction for wide coalesced reads; 4-byte accesses are uncalibrated, so the "
                    "truth lies between the raw and the corrected figure"},
-          open(os.path.join(out, "pmc_r03_path.json"), "w"), indent=1)
+          open(os.path.join(out, f"pmc_{tag}_path.json"), "w"), indent=1)
+
+
+# ---- per-op traffic (round 4): the convolution dispatches of the LAST DDIM iteration of the FETCH_SIZE / WRITE_SIZE passes, matched
+# in program order to the launch program's op labels (every convolution op is exactly one dispatch of its kernel family; an iteration
+# ends with the sampler kernel).  bench.py averages these over the launches of its dominant (layer shape, kernel) pair, so that
+# `roofline.traffic` and `roofline.algorithmic_bytes_per_launch` describe the same launches.
+def dispatches(d, counter):
+    per = collections.OrderedDict()
+    for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = int(r["Dispatch_Id"])
+            e = per.setdefault(k, [short(r["Kernel_Name"]), 0.0])
+            e[1] += float(r["Counter_Value"])
+    return [per[k] for k in sorted(per)]
+
+
+def last_iteration(seq):
+    ends = [i for i, (k, _) in enumerate(seq) if k.startswith("ddim_kernel")]
+    if len(ends) < 2:
+        return []
+    return seq[ends[-2] + 1: ends[-1] + 1]
+
+
+FAMILY = {"PF3": "conv_pf3_kernel", "PF": "conv_pf_kernel", "PW": "conv_pw_kernel", "SPLIT2H": "conv_split2_kernel", "SPLIT2": "conv_split2_kernel",
+          "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel"}
+
+
+def kern_of(label):
+    t = label.split()
+    return next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
+
+
+if ops_file and os.path.exists(ops_file):
+    labels = [l.rstrip("\n") for l in open(ops_file) if l.startswith("conv ") and " HOIST" not in l]
+    fa, wr = last_iteration(dispatches("a", "FETCH_SIZE")), last_iteration(dispatches("w", "WRITE_SIZE"))
+    conv_a = [x for x in fa if x[0].startswith("conv_")]
+    conv_w = [x for x in wr if x[0].startswith("conv_")]
+    ops, ok = {}, len(conv_a) == len(labels) == len(conv_w)
+    if ok:
+        for lab, (ka, f), (kw, w) in zip(labels, conv_a, conv_w):
+            if not (ka.startswith(FAMILY[kern_of(lab)]) and kw.startswith(FAMILY[kern_of(lab)])):
+                ok = False
+                break
+            e = ops.setdefault(lab, dict(n=0, fetch=0.0, write=0.0))
+            e["n"] += 1; e["fetch"] += f * 1024; e["write"] += w * 1024
+    if ok:
+        res = {lab: {"launches": e["n"], "fetch_bytes_raw": e["fetch"] / e["n"], "write_bytes": e["write"] / e["n"],
+                     "hbm_bytes_corrected": (2 * e["fetch"] + e["write"]) / e["n"], "hbm_bytes_raw": (e["fetch"] + e["write"]) / e["n"]}
+               for lab, e in ops.items()}
+        arith = "bf16x3" if os.environ.get("CDC_ARITH") == "0" else "f16x2"
+        json.dump({"batch": B, "arith": arith, "ops": res,
+                   "source": f"profiles/pmc_{tag}_path.* passes (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes, "
+                             "FETCH_SIZE x2 gfx950 correction): the convolution dispatches of the last DDIM iteration matched in program order to the op labels"},
+                  open(os.path.join(out, f"pmc_{tag}_traffic.json"), "w"), indent=1)
+        print(f"\nper-op traffic: {len(labels)} convolution launches matched -> pmc_{tag}_traffic.json")
+    else:
+        print(f"\nper-op traffic: could not match {len(labels)} op labels to {len(conv_a)} / {len(conv_w)} convolution dispatches", file=sys.stderr)
