@@ -825,7 +825,21 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
     bool bad = false;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n;
          idx += (long long)gridDim.x * blockDim.x) {
-        const float fx = a.fx[idx], x = a.x[idx];
+        float fx;
+        if (a.P) {
+            // the 7-row combine of the row-folded final convolution (fold_combine_kernel) evaluated here: out_fx is never written
+            const long long plane = (long long)a.pH * a.pW, img_co = idx / plane;      // = b * Cout + co
+            const int pix = (int)(idx - img_co * plane), y = pix / a.pW;
+            const float *p = a.P + (size_t)img_co * a.pKH * plane + pix;
+            fx = a.P_bias ? a.P_bias[(int)(img_co % a.pC)] : 0.f;
+            for (int ky = 0; ky < a.pKH; ++ky) {
+                const int r = y + ky - a.pPad;
+                if (r >= 0 && r < a.pH) fx += p[(size_t)ky * plane + (long long)(ky - a.pPad) * a.pW];
+            }
+        } else {
+            fx = a.fx[idx];
+        }
+        const float x = a.x[idx];
         bad |= !(fabsf(fx) <= 3.0e38f);                    // inf / NaN from the U-Net (fp16-plane range overflow)
         float x0, eps;
         if (a.pred_mode == 0 || a.pred_mode == 3) {

@@ -1731,8 +1731,9 @@ int run_pre(cdc_handle *h, hipStream_t st) {
 
 // step >= 0: sampler iteration `step` (time-embedding shifts come from the per-decode table);
 // step < 0: plain Unet.forward with the caller's per-image time values.
-int run_unet(cdc_handle *h, hipStream_t st, int step) {
+int run_unet(cdc_handle *h, hipStream_t st, int step, bool skip_combine = false) {
     for (const Op &op : h->ops) {
+        if (skip_combine && op.kind == Op::COMBINE) continue;      // (the sampler kernel evaluates it: ddim_on_device)
         if (op.kind == Op::TEMB && (step >= 0 || step == -2)) {
             Op c = op;
             c.kind = Op::COPY;
@@ -2815,12 +2816,20 @@ static int ddim_on_device(cdc_handle *h, const float *x_in, int i, const float *
     const size_t n = (size_t)B * h->cfg.channels * H * W;
     if (x_in != h->in_x)
         HIP_TRY(h, hipMemcpyAsync(h->in_x, x_in, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if ((rc = run_unet(h, st, i))) return rc;
+    // the 7-row combine of the final convolution rides in the sampler kernel (one launch and a 3-channel tensor less per iteration)
+    static const bool fuse_combine = getenv("CDC_NO_COMBINE_FUSE") == nullptr;
+    const Op *cb = nullptr;
+    if (fuse_combine && !h->ops.empty() && h->ops.back().kind == Op::COMBINE && h->ops.back().cb.out == h->out_fx) cb = &h->ops.back();
+    if ((rc = run_unet(h, st, i, cb != nullptr))) return rc;
     Op op;
     op.kind = Op::DDIM; op.prof = PC_SMALL;
     op.ddim = {h->out_fx, h->in_x, (eta != 0.f) ? noise : nullptr, x_out, h->d_tab, h->steps, i < 0 ? 0 : i,
                i == -2 ? h->d_step : nullptr, pred_mode, clip, eta, (long long)n,
                (long long)(B / 2) * h->cfg.channels * H * W, h->d_fault, pred_mode == CDC_PRED_V ? h->d_tab_v : nullptr};
+    if (cb) {
+        op.ddim.P = cb->cb.P; op.ddim.P_bias = cb->cb.bias; op.ddim.pC = cb->cb.Cout; op.ddim.pKH = cb->cb.KH; op.ddim.pPad = cb->cb.pad;
+        op.ddim.pH = cb->cb.H; op.ddim.pW = cb->cb.W;
+    }
     op.bytes = 16.0 * n;
     return run_op(h, op, B, st);
 }

@@ -177,6 +177,10 @@ struct DdimArgs {
     long long clip_half_n; // elements of the first B/2 images
     int *fault;            // set to 1 when the U-Net output holds inf / NaN (may be null)
     const float *tab_v;    // pred_mode 3: device table [2][steps]: sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod
+    // non-null: fx is the 7-row combine of the row-folded final convolution's partial planes P [B][pC][pKH][pH][pW] (+ P_bias[pC]),
+    // evaluated inside the sampler kernel (same sum, same order as fold_combine_kernel) instead of being read from `fx`
+    const float *P = nullptr, *P_bias = nullptr;
+    int pC = 0, pKH = 0, pPad = 0, pH = 0, pW = 0;
 };
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st);
 hipError_t copy_channels_launch(const float *src, long long src_bs, float *dst, long long dst_bs,
