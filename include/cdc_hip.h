@@ -80,12 +80,13 @@ const char *cdc_version(void);
  * 16-bit matrix cores from split operands (no reference counterpart -- torch delegates to oneDNN / cuDNN fp32):
  *   CDC_ARITH_F16X2 (default)  a = h + l*2^-11 as two fp16 numbers, w*2^s as {WH, WL}: three
  *                              v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulation; operands carry 22-23 significant
- *                              bits for 6e-5 <= |a| < 65504.  RANGE GUARD: |a| >= 65504 becomes inf / NaN and reaches the
- *                              results of the call, so EVERY entry point that runs the arithmetic (cdc_unet_forward,
- *                              cdc_ddim_step, cdc_decode, cdc_ctxdec_decode, cdc_hyperdec_decode, cdc_encoder_encode,
- *                              cdc_entropy_encode) checks its results (one small kernel + a 4-byte read-back: the call
- *                              synchronises its stream) and repeats a call with non-finite results ONCE in
- *                              CDC_ARITH_BF16X3.  The handle then STAYS in that mode (a warning is printed once;
+ *                              bits for 6e-5 <= |a| < 65504.  RANGE GUARD: |a| >= 65504 makes the accumulators of its
+ *                              convolution inf / NaN.  Every convolution / LayerNorm launch reports that itself, BEFORE a
+ *                              fused LayerNorm + ReLU can turn it into a finite wrong value (round 4), and EVERY entry point
+ *                              that runs the arithmetic (cdc_unet_forward, cdc_ddim_step, cdc_decode, cdc_ctxdec_decode,
+ *                              cdc_hyperdec_decode, cdc_encoder_encode, cdc_entropy_encode, the cdc_op_* operators) also
+ *                              checks its results (one small kernel + a 4-byte read-back: the call synchronises its
+ *                              stream) and repeats a faulting call ONCE in CDC_ARITH_BF16X3.  The handle then STAYS in that mode (a warning is printed once;
  *                              cdc_get_arith / cdc_get_range_faults tell).  Results that are non-finite in the full-range
  *                              arithmetic too (non-finite inputs, parameters beyond fp32) come back as they are, as the
  *                              reference's would (counted by cdc_get_nonfinite_results); the range was not their cause,
