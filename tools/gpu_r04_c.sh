@@ -1,9 +1,10 @@
 #!/bin/bash
 # Round-4: ablation builds of conv_split2_kernel on the stride-2 shapes (what bounds them?), plus a check of the pre_init change.
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04c; mkdir -p $OUT; cd $R
+R=$GRAFT_REPO_ROOT; [ -f $GRAFT_REPO_ROOT/cdc_compression_amd/libcdc_hip_timeline.so ] || bash $GRAFT_REPO_ROOT/tools/build_variant.sh timeline "-DCDC_TIMELINE" > /dev/null 2>&1; OUT=$R/gpurun_out/r04c; mkdir -p $OUT; cd $R
 timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -k "unet_forward or decode_matches_reference or stage_taps or context_decoder or pre_split" > $OUT/pytest.log 2>&1
 echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+for v in NOSTOREX NOLOADX NOW NOMFMA NOEPI; do [ -f $R/cdc_compression_amd/libcdc_hip_ab_$v.so ] || bash $R/tools/build_variant.sh ab_$v "-DCDC_AB_$v" > /dev/null 2>&1; done
 export CDC_DEV=1 TUNE_CHILD=1
 for SHAPE in "32 64 256 256 64 3 2 0" "32 128 128 128 128 3 2 0" "32 64 256 256 64 3 1 0"; do
   echo "== shape $SHAPE"
