@@ -604,7 +604,7 @@ constexpr int kFoldRows = 8;     // rows per workgroup: each WoT / T1 element is
 // factors exp(M[split][d] - max) are computed once per row (not once per element), the C elements of the row are
 // summed by C x SPF threads (SPF interleaved split subsets, combined through LDS) with independent loads.
 __global__ void __launch_bounds__(512) ctx_r0_kernel(const float *S, const float *Zp, int C, int nsplit,
-                                                     float *ctxn, const float *M, int SPF) {
+                                                     float *ctxn, const float *M, int SPF, int transposed) {
     extern __shared__ float r0s[];                    // [nsplit] factors, [nsplit] Z * factor, [SPF][C] partial sums
     float *fs = r0s, *zf = r0s + nsplit, *red = r0s + 2 * nsplit;
     const int b = blockIdx.y, d = blockIdx.x;
@@ -634,7 +634,8 @@ __global__ void __launch_bounds__(512) ctx_r0_kernel(const float *S, const float
         if (q == 0)
             for (int k = 1; k < SPF; ++k) acc += red[k * C + e];
     }
-    if (q == 0) ctxn[((size_t)b * C + d) * C + e] = acc / z;
+    // transposed: [e][d], the A-operand order of fold_r1_mfma_kernel (its lanes walk d)
+    if (q == 0) ctxn[transposed ? ((size_t)b * C + e) * C + d : ((size_t)b * C + d) * C + e] = acc / z;
 }
 
 __global__ void __launch_bounds__(256) ctx_r1_kernel(const float *ctxn, int C, const float *WoT, float *T1) {
@@ -752,16 +753,127 @@ __global__ void __launch_bounds__(256) ctx_r3_kernel(const float *T1, const floa
     biasB[(size_t)b * C + c] = b_out[c] + scale * acc;
 }
 
+// ---- round 4: R1 / R2 (+ R3) on the f32 matrix cores ------------------------------------------------------------------
+// The two per-image C x C x C products of the fold are plain fp32 GEMMs; as FMA loops they ran at 4 - 10 TFLOP/s and made the fold
+// (0.33 ms per DDIM iteration over five attention levels) the slowest "small" step.  v_mfma_f32_32x32x2_f32 multiplies fp32
+// operands exactly as an FMA does, so nothing is split: one wave per 32 x 32 block of the result, K walked two at a time, both
+// operand blocks staged once through LDS in the order the lanes need them (lane = (k parity, row / column)).
+//   R1: T1[b][d][c]  = sum_e ctxnT[b][e][d] * WoT[e][c]                  (ctx_r0_kernel writes the normalised context transposed)
+//   R2: Mt[b][ci][c] = scale g[ci] * sum_d Wq[d][ci] * T1[b][d][c]       (+ the planes of M' for the split convolution)
+//   R3: bias[b][c]   = b_out[c] + scale * sum_d u[d] T1[b][d][c]         (rides in R2's K loop: the waves of block row 0)
+// Both operand blocks (K x 32 floats each) are fetched with 16-byte loads, all in flight at once, into LDS; the K loop then runs
+// from LDS.  (Fetching the operands per MFMA step straight from L2 was measured slower than the FMA kernels it replaced: 192 dependent
+// 4-byte loads per wave.)
+__device__ __forceinline__ void fold_stage(float *lds, const float *src, int ld, int K) {     // lds[k][32] <- src[k * ld + 0..31]
+    const int lane = threadIdx.x, r8 = lane >> 3, c4 = (lane & 7) * 4;
+    for (int k0 = 0; k0 < K; k0 += 8)
+        *reinterpret_cast<float4 *>(lds + (k0 + r8) * 32 + c4) = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + r8) * ld + c4);
+}
+
+__global__ void __launch_bounds__(64) fold_r1_mfma_kernel(const float *ctxnT, const float *WoT, float *T1, int C) {
+    extern __shared__ __attribute__((aligned(16))) float fold_lds[];       // A block [C][32], B block [C][32]
+    float *As = fold_lds, *Bs = fold_lds + C * 32;
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
+    fold_stage(As, ctxnT + (size_t)b * C * C + m0, C, C);     // A[m = d][k = e] = ctxnT[e][d]
+    fold_stage(Bs, WoT + n0, C, C);                           // B[k = e][n = c]
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int k = half; k < C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], Bs[k * 32 + j], acc, 0, 0, 0);
+    float *o = T1 + (size_t)b * C * C + (size_t)(m0 + 4 * half) * C + n0 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * C] = acc[r];
+}
+
+__global__ void __launch_bounds__(64) fold_r2_mfma_kernel(const float *T1, const float *Wq, int C, float scale, const float *ln_g,
+                                                          float *Mt, int Cin_pad, int COP, unsigned short *Ws, int ws_f16,
+                                                          const float *u, const float *b_out, float *biasB) {
+    extern __shared__ __attribute__((aligned(16))) float fold_lds[];
+    float *As = fold_lds, *Bs = fold_lds + C * 32;
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
+    fold_stage(As, Wq + m0, C, C);                            // A[m = ci][k = d] = Wq[d][ci]
+    fold_stage(Bs, T1 + (size_t)b * C * C + n0, C, C);        // B[k = d][n = c]
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const bool with_bias = blockIdx.y == 0;
+#pragma unroll 8
+    for (int k = half; k < C; k += 2) {
+        const float bv = Bs[k * 32 + j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], bv, acc, 0, 0, 0);
+        if (with_bias) bsum += u[k] * bv;
+    }
+    if (with_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0) biasB[(size_t)b * C + n0 + j] = b_out[n0 + j] + scale * bsum;
+    }
+    const int c = n0 + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ci0 = m0 + 8 * g + 4 * half;               // this lane's 4 consecutive input channels of the 8-channel unit
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = acc[4 * g + i] * scale * ln_g[ci0 + i];   // PreNorm gain folded in (LNMODE 2)
+            Mt[((size_t)b * Cin_pad + ci0 + i) * COP + c] = v[i];
+        }
+        if (Ws) {
+            const int q = (m0 + 8 * g) >> 4, kh = ((m0 + 8 * g) >> 3) & 1;
+            uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(Ws) + (size_t)b * (C / 16) * 6 * C) + half;   // 8-byte half of a unit
+            if (ws_f16) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 wh, wl, wh2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = v[i] * kFoldPlaneScale;
+                    const _Float16 hq = (_Float16)x;
+                    wh[i] = hq; wl[i] = (_Float16)(x - (float)hq); wh2[i] = (_Float16)((float)hq * (1.0f / 2048.0f));
+                }
+                dst[2 * ((size_t)((q * 3 + 0) * 2 + kh) * C + c)] = __builtin_bit_cast(uint2, wh);
+                dst[2 * ((size_t)((q * 3 + 1) * 2 + kh) * C + c)] = __builtin_bit_cast(uint2, wl);
+                dst[2 * ((size_t)((q * 3 + 2) * 2 + kh) * C + c)] = __builtin_bit_cast(uint2, wh2);
+            } else {
+                unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hh[i] = __float_as_uint(v[i]) & 0xFFFF0000u;
+                    const float r1 = v[i] - __uint_as_float(hh[i]);
+                    mm[i] = __float_as_uint(r1) & 0xFFFF0000u;
+                    ll[i] = __float_as_uint(r1 - __uint_as_float(mm[i]));
+                }
+                dst[2 * ((size_t)((q * 3 + 0) * 2 + kh) * C + c)] = make_uint2((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3]);
+                dst[2 * ((size_t)((q * 3 + 1) * 2 + kh) * C + c)] = make_uint2((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3]);
+                dst[2 * ((size_t)((q * 3 + 2) * 2 + kh) * C + c)] = make_uint2((ll[0] >> 16) | (ll[1] & 0xFFFF0000u), (ll[2] >> 16) | (ll[3] & 0xFFFF0000u));
+            }
+        }
+    }
+}
+
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
-                           float *biasB, int B, hipStream_t st, const float *M, unsigned short *Ws, int ws_f16) {
+                           float *biasB, int B, hipStream_t st, const float *M, unsigned short *Ws, int ws_f16, const float *Wq) {
     const int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     // Mt doubles as scratch for the normalised context (C*C <= Cin_pad*COP) until R2 overwrites it
     int spf = 1;
     while (2 * spf * C <= 512 && 2 * spf <= nsplit) spf *= 2;
+    // whole 32 x 32 blocks (the folded levels of the full-width models: C = 64, 128, 192): R1 / R2 / R3 on the f32 matrix cores
+    const bool mfma = Wq && (C % 32) == 0 && Cin_pad == C && COP == C && !dev_env("CDC_NO_FOLD_MFMA");
     hipLaunchKernelGGL(ctx_r0_kernel, dim3(C, B), dim3(C * spf), sizeof(float) * (2 * nsplit + spf * C), st, S, ksum, C, nsplit,
-                       Mt, M, spf);
+                       Mt, M, spf, mfma ? 1 : 0);
+    if (mfma) {
+        const size_t lds = sizeof(float) * 2 * C * 32;
+        hipLaunchKernelGGL(fold_r1_mfma_kernel, dim3(C / 32, C / 32, B), dim3(64), lds, st, Mt, WoT, T1, C);
+        hipLaunchKernelGGL(fold_r2_mfma_kernel, dim3(C / 32, C / 32, B), dim3(64), lds, st, T1, Wq, C, scale, ln_g, Mt, Cin_pad, COP, Ws,
+                           ws_f16, u, b_out, biasB);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),
                        sizeof(float) * kFoldRows * C, st, Mt, C, WoT, T1);
     hipLaunchKernelGGL(ctx_r2_kernel, dim3(ceil_div(Cin_pad, kFoldRows), B), dim3(blk),

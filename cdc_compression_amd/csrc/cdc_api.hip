@@ -60,7 +60,7 @@ struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift
                   ConvW c1u; bool has_unfold = false; bool has_mlp = true; };   // c1x as a KH x 1 conv over KW*cx unfolded channels
 struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                // qkv / kv: to_qkv (all rows / k,v rows) with the PreNorm affine folded in (g*W, W.b)
-               ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr;
+               ConvW kv; float *WoT = nullptr, *WqT = nullptr, *uq = nullptr, *Wq = nullptr;   // Wq [d][ci]: the A operand of fold_r2_mfma_kernel
                float *kvWt = nullptr, *kvb = nullptr; unsigned short *kvWs = nullptr;
                unsigned short *kvWh = nullptr; float kv_scale_inv = 1.f; };   // fp16 planes {WH, WL, WH2} of W' 2^s   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
@@ -87,6 +87,7 @@ struct Op {
     LnConvArgs lnc;
     int at_ws_f16 = 0;                 // CTXF: the planes are fp16 {WH, WL, WH2} of M' 2^8 (split convolution) instead of bf16
     unsigned short *at_Ws = nullptr;   // CTXF: also emit M' as bf16 planes for lnconv_kernel
+    const float *at_Wq = nullptr;      // CTXF: Wq [d][ci] (fold_r2_mfma_kernel)
     const float *at_M = nullptr;  // CTXF after KVCTX: per-split row maxima   // COPY: dst = sum of cp_parts planes of src
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
     struct { const float *src; long long src_bs; void *dst; long long dst_bs; int C, H, W; } pk;   // PFPACK
@@ -560,6 +561,7 @@ int pack_attn(cdc_handle *h, const std::string &p, int c) {
             }
         if ((rc = upload(h, woT.data(), woT.size(), &a.WoT, &h->weight_allocs))) return rc;
         if ((rc = upload(h, wqT.data(), wqT.size(), &a.WqT, &h->weight_allocs))) return rc;
+        if ((rc = upload(h, wq.data(), (size_t)c * c, &a.Wq, &h->weight_allocs))) return rc;       // rows 0..C-1 of to_qkv
         const auto &bn = hostp(h, p + ".fn.norm.b");
         std::vector<float> uq(c);
         for (int d = 0; d < c; ++d) {
@@ -788,6 +790,7 @@ struct Builder {
         bool emit_pf = false;                          // `out` holds final values: also write its PF twin (if it has one)
         bool pf_only = false;                          // plan with conv_pf_kernel or return false
         bool no_f32 = false;                           // PF path only: nobody reads the fp32 copy of `out`
+        int uf_c = 0, uf_pad = 0;                      // unfold on load (ConvArgs::uf_c): s0 is the uf_c-channel image, w a KH x 1 layer over KW*uf_c channels
     };
     int last_ksplit = 1;                               // slices the last conv() call really used
     bool last_pf_only = false;                         // the last conv() call wrote its result as planes only (no fp32 copy exists)
@@ -989,9 +992,9 @@ struct Builder {
             s.Wo = (W + 2 * pad_x - w.KW) / w.stride + 1;
         }
         s.B = pb(); s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
-        if (try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
+        if (!o.uf_c && try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
-        if (try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
+        if (!o.uf_c && try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
         if (!dev_env("CDC_NO_KSPLIT") && !dev_env("CDC_NO_KSPLIT_PLAN"))
@@ -1004,6 +1007,8 @@ struct Builder {
                       w.Cin, w.Cout, w.KH, w.KW, s.Ho, s.Wo);
             return true;
         }
+        if (o.uf_c && !(plan.split == 2 && plan.arith == 1 && plan.xu == 1 && plan.lnmode == 0 && !plan.pipe &&
+                        conv_lookup_split2hu(plan.MB, plan.NPW))) return false;                       // only that kernel unfolds on load
         last_ksplit = 1;
         last_pf_only = false;
         if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !dev_env("CDC_NO_KSPLIT")) {
@@ -1070,6 +1075,10 @@ struct Builder {
         a.out_ks = (long long)B * out_bs;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
         a.fault = fault_flag();
+        if (o.uf_c) {
+            a.uf_c = o.uf_c; a.uf_pad = o.uf_pad;
+            a.uf_magic = o.uf_c > 1 ? (unsigned)(((1ull << 32) + o.uf_c - 1) / o.uf_c) : 0u;
+        }
         if (o.emit_pf && !ks_scratch && plan.ksplit <= 1 && (w.Cout % 32) == 0)
             if (PfTwin *to = twin(out)) {
                 const int Ht = w.transposed ? 2 * H : s.Ho, Wt = w.transposed ? 2 * W : s.Wo;
@@ -1155,11 +1164,14 @@ struct Builder {
 
     // conv -> channel LN -> ReLU (+shift) (+resid) (+stats), fused when possible (Block.forward,
     // network_components.py:83-91, plus the adds of ResnetBlock.forward :107-114)
-    void block(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1,
+    // uf_c > 0 (unfold on load, ConvArgs::uf_c): s0 is the uf_c-channel image and w the KH x 1 layer over its kx-unfolded channels; only
+    // the fused register-staged plan can do that -- returns false, with nothing emitted, when it is not available.
+    bool block(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1,
                int H, int W, Act out, const float *g, const float *b, const float *shift,
                const float *pre_add, const float *resid, long long resid_bs, float *sm, float *sr,
-               int prof, bool pf_only_out = false) {
+               int prof, bool pf_only_out = false, int uf_c = 0, int uf_pad = 0) {
         ConvOpts o;
+        o.uf_c = uf_c; o.uf_pad = uf_pad;
         o.no_f32 = pf_only_out;
         o.ln_g = g; o.ln_b = b; o.relu = 1; o.shift = shift; o.pre_add = pre_add;
         o.no_bias = pre_add != nullptr;          // the hoisted partial already carries the bias
@@ -1172,11 +1184,12 @@ struct Builder {
         {   // pre-split operands first: there the fused LayerNorm reduces across waves (up to 256 channels)
             ConvOpts op = o;
             op.pf_only = true;
-            if (conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), op, true, prof)) return;
+            if (conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), op, true, prof)) return true;
         }
         if (prefer_fused(w, H, W) && conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), o, true, prof))
-            return;
-        if (want_res3) { rc = fail(h, CDC_ERR_UNSUPPORTED, "epilogue res_conv needs the fused LayerNorm plan"); return; }
+            return true;
+        if (uf_c) return false;
+        if (want_res3) { rc = fail(h, CDC_ERR_UNSUPPORTED, "epilogue res_conv needs the fused LayerNorm plan"); return true; }
         ConvOpts u;
         u.pre_add = pre_add; u.no_bias = o.no_bias;
         const size_t plane_f = (size_t)B * w.Cout * H * W;
@@ -1187,10 +1200,11 @@ struct Builder {
             u.max_ksplit = kmax;
             conv(w, s0, C0, bs0, s1, bs1, H, W, part, out.bs(), u, false, prof);
             ln(part, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr, last_ksplit);
-            return;
+            return true;
         }
         conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), u, false, prof);
         ln(out.p, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr);
+        return true;
     }
 
     // ResnetBlock.forward (network_components.py:107-114).  a1 = second concat source.  If
@@ -1225,7 +1239,12 @@ struct Builder {
                 copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
             }
             cur = saved;
-            if (rb.has_unfold && (W & 3) == 0) {
+            // first 7x7 layer = 7x1 convolution over the kx-unfolded image: the unfolding happens while the patch is loaded
+            // (round 4); the explicit unfold pass + its 21-channel tensor remain the fall-back
+            if (rb.has_unfold && (W & 3) == 0 && !dev_env("CDC_NO_UNFOLD_ON_LOAD") &&
+                block(rb.c1u, a0.p, a0.C * rb.k, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
+                      nullptr, nullptr, prof1, h1_pf_only, a0.C, rb.k / 2)) {
+            } else if (rb.has_unfold && (W & 3) == 0) {
                 Act u = new_act(a0.C * rb.k, H, W, false);
                 Op uo; uo.kind = Op::UNFOLD; uo.prof = prof1;
                 uo.uf = {a0.p, a0.bs(), u.p, u.bs(), a0.C, rb.k, rb.k / 2, H, W};
@@ -1300,7 +1319,7 @@ struct Builder {
         int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
         nsplit = std::min(nsplit, std::max(1, N / 64));
         if (fused) {        // >= 2.6 rounds of 3 workgroups per CU (C = 64) / 4 rounds of one (C = 128)
-            static const int kv64 = dev_env("CDC_KV64_WGS") ? atoi(dev_env("CDC_KV64_WGS")) : 2048;
+            static const int kv64 = dev_env("CDC_KV64_WGS") ? atoi(dev_env("CDC_KV64_WGS")) : 1024;   // (round 4: 2048 -> 1024: half the partial sums for the fold to add, 13.92 -> 13.89 ms per iteration)
             nsplit = std::min(128, C == 64 ? ceil_div(kv64, B) : ceil_div(1024, B));   // (the fold sums the splits serially)
             while (nsplit > 1 && N % (32 * nsplit)) --nsplit;
         }
@@ -1343,7 +1362,7 @@ struct Builder {
         const bool planes_f16 = (split_out && h->arith == 1) || split_ctxq;
         unsigned short *Ws = (stream_out || split_out || split_ctxq) ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
-        r.at_M = kmaxs; r.at_Ws = Ws; r.at_ws_f16 = planes_f16 ? 1 : 0;
+        r.at_M = kmaxs; r.at_Ws = Ws; r.at_ws_f16 = planes_f16 ? 1 : 0; r.at_Wq = at.Wq;
         r.bytes = 4.0 * B * nsplit * C * C;
         r.flops = fold ? 4.0 * B * (double)C * C * C : 0.0;
         emit(r);
@@ -1695,7 +1714,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
         case Op::CTXF:
             HIP_TRY(h, ctx_fold_launch(op.at.S, op.at.ksum, op.at.C, op.at.nsplit, op.at.scale, op.at.WoT,
                                        op.at.WqT, op.at.T1, op.at.ctxw, op.at.Cin_pad, op.at.COP, op.at.ln_g,
-                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M, op.at_Ws, op.at_ws_f16));
+                                       op.at.ln_b, op.at.b_out, op.at.biasB, B, st, op.at_M, op.at_Ws, op.at_ws_f16, op.at_Wq));
             break;
         case Op::COMBINE:
             HIP_TRY(h, fold_combine_launch(op.cb.P, op.cb.bias, op.cb.out, op.cb.Cout, op.cb.KH, op.cb.pad,
@@ -3186,6 +3205,7 @@ static int op_linear_attention_impl(cdc_handle *h, const float *x, const float *
             }
         if ((rc = sc.up(woT.data(), woT.size(), &at.WoT))) return rc;
         if ((rc = sc.up(wqT.data(), wqT.size(), &at.WqT))) return rc;
+        if ((rc = sc.up(w_qkv, (size_t)C * C, &at.Wq))) return rc;
         std::vector<float> uq(C);
         for (int d = 0; d < C; ++d) {
             double acc = 0;

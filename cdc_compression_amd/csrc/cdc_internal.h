@@ -23,6 +23,7 @@ conv_kernel_fn conv_lookup_split_abl(int MB, int NPW, int abl);
 conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);
 conv_kernel_fn conv_lookup_split2h(int MB, int NPW, int lnmode, int xu = 1);   // AR = 1: two fp16 planes
 conv_kernel_fn conv_lookup_split2hp(int MB, int NPW, int lnmode, int xu = 1);  // AR = 1, software-pipelined tap loop (PIPE = 1)
+conv_kernel_fn conv_lookup_split2hu(int MB, int NPW);                          // AR = 1, unfold on load (UF = 1; ConvArgs::uf_c)
 
 struct ConvShape {
     int Cin, Cout, KH, KW, stride;
@@ -160,7 +161,7 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
                            float *biasB, int B, hipStream_t st, const float *M = nullptr,
-                           unsigned short *Ws = nullptr, int ws_f16 = 0);
+                           unsigned short *Ws = nullptr, int ws_f16 = 0, const float *Wq = nullptr);
 hipError_t fold_combine_launch(const float *P, const float *bias, float *out, int Cout, int KH,
                                int pad, int H, int W, int B, hipStream_t st);
 

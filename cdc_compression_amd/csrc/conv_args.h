@@ -21,6 +21,11 @@ struct ConvArgs {
     // input: channel-concatenation of up to two NCHW sources (torch.cat sites unet.py:109,124)
     const float *src0, *src1;
     long long src0_bs, src1_bs;     // batch strides in floats (0 = broadcast over batch)
+    // conv_split2_kernel, round 4 -- unfold on load (first 7x7 layer as a 7x1 convolution over kx-unfolded channels): uf_c > 0: src0 is the
+    // [uf_c][H][W] image itself and logical input channel cc = kx * uf_c + c reads src0[c][y][x + kx - uf_pad] (zero outside the row);
+    // the unfolded [KW * uf_c][H][W] tensor (unfold_x_kernel) is never written
+    int uf_c, uf_pad;
+    unsigned uf_magic;              // fast division by uf_c
     int C0, Cin;                    // channels taken from src0; total input channels
     int H, W;                       // input spatial size
     // optional LayerNorm applied while staging the input (PreNorm, network_components.py:69-77)

@@ -29,4 +29,12 @@ conv_kernel_fn conv_lookup_split2hp(int MB, int NPW, int lnmode, int xu) {
     }
     return nullptr;          // (lnmode 2 is 1x1 only: one tap per chunk, nothing to pipeline)
 }
+// unfold on load (UF = 1): the first 7x7 layer as a 7x1 convolution over the kx-unfolded image
+conv_kernel_fn conv_lookup_split2hu(int MB, int NPW) {
+    if (MB == 1 && NPW == 1) return conv_split2_kernel<1, 1, 0, 1, 1, 0, 1>;
+    if (MB == 1 && NPW == 2) return conv_split2_kernel<1, 2, 0, 1, 1, 0, 1>;
+    if (MB == 2 && NPW == 1) return conv_split2_kernel<2, 1, 0, 1, 1, 0, 1>;
+    if (MB == 2 && NPW == 2) return conv_split2_kernel<2, 2, 0, 1, 1, 0, 1>;
+    return nullptr;
+}
 }  // namespace cdc

@@ -298,6 +298,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     if (ablate && p.lnmode == 0 && !p.split)
         if (conv_kernel_fn f2 = conv_lookup_abl(p.MB, p.NPW, ablate)) fn = f2;
 #endif
+    if (a.uf_c) fn = (p.split == 2 && p.arith && !p.pipe && p.xu == 1 && p.lnmode == 0) ? conv_lookup_split2hu(p.MB, p.NPW) : nullptr;
     if (!fn) return hipErrorInvalidValue;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn,

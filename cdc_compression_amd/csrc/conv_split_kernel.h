@@ -266,9 +266,13 @@ constexpr int split2_min_wgs(int MB, int NPW, int LNMODE, int XU = 1, int AR = 0
 // between them (cycle timeline of wave 0, stride-2 64->64 @256^2: 1570 cycles per tap for 192 cycles of matrix work).  PIPE keeps two
 // operand register sets: all ds_reads of tap t+1 (activation planes always; weight planes unless the tap opens a new weight stage,
 // which is read right after the stage's barrier) are issued BEFORE the MFMAs of tap t.
-template <int MB, int NPW, int LNMODE = 0, int XU = 1, int AR = 0, int PIPE = 0>
+// UF = 1 (round 4): unfold on load (ConvArgs::uf_c) -- the first 7x7 layer as a 7x1 convolution whose kx-unfolded input channels are
+// gathered from the image while the patch is loaded (a compile-time variant: the same code behind a run-time branch in the common
+// loader made every other layer of this kernel 5 - 25 % slower).
+template <int MB, int NPW, int LNMODE = 0, int XU = 1, int AR = 0, int PIPE = 0, int UF = 0>
 __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR, PIPE)) conv_split2_kernel(const ConvArgs P) {
     static_assert(PIPE == 0 || AR == 1, "the pipelined tap loop exists for the fp16 arithmetic only");
+    static_assert(UF == 0 || (XU == 1 && LNMODE == 0), "unfold on load: stride 1, no LayerNorm on load");
     constexpr int NP = AR == 1 ? 2 : 3;               // B-operand (activation) planes
     static_assert(XU == 1 || LNMODE == 0, "two-unit variant carries no LayerNorm-on-load");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -340,6 +344,8 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR, P
     constexpr bool s2 = XU == 2;                      // the two-unit variant IS the stride-2 variant (host-enforced)
     const int ustep1 = s2 ? PW / 2 : 1, ustep2 = s2 ? 1 : 2;   // LDS position of unit pixel t: base + (t&1)*ustep1 + (t>>1)*ustep2
     int xsp[XU], ukg[XU], urc[XU];                    // xsp -2: no unit, -1: zero padding, else iy*W+ix
+    int uix[UF ? XU : 1];                             // the unit's first image column (unfold on load)
+    uix[0] = 0;
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
         xsp[u] = -2; ukg[u] = 0; urc[u] = 0;
@@ -352,6 +358,7 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR, P
             urc[u] = (int)(r * PW + (s2 ? col >> 1 : col));
             const int iy = iy0 + (int)r, ix = ix0 - P.xshift[z] + (int)col;
             xsp[u] = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? iy * P.W + ix : -1;
+            if constexpr (UF != 0) uix[u] = ix;
         }
     }
     const unsigned HW = (unsigned)(P.H * P.W);
@@ -378,6 +385,26 @@ __global__ void __launch_bounds__(256, split2_min_wgs(MB, NPW, LNMODE, XU, AR, P
     for (int u = 0; u < XU; ++u) xvo[u] = xsp[u] >= 0 ? ((unsigned)(ukg[u] * 8) * HW + (unsigned)xsp[u]) * 4u : 0u;
     auto load_x = [&](int chunk) {
         const int cbase = chunk * KC;
+        if constexpr (UF != 0) {                      // unfold on load (ConvArgs::uf_c): 4-byte loads of the shifted image row
+#pragma unroll
+            for (int u = 0; u < XU; ++u)
+#pragma unroll
+                for (int i = 0; i < kXR; ++i) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int cc = cbase + ukg[u] * 8 + i;
+                    if (xsp[u] >= 0 && cc < P.Cin) {
+                        const int kx = (int)fdiv((unsigned)cc, P.uf_magic), c = cc - kx * P.uf_c;
+                        const float *row = s0 + (size_t)c * HW + (unsigned)(xsp[u] - uix[u]);
+                        const int sx = uix[u] + kx - P.uf_pad;
+                        if (sx >= 0 && sx < P.W) v.x = row[sx];
+                        if (sx + 1 >= 0 && sx + 1 < P.W) v.y = row[sx + 1];
+                        if (sx + 2 >= 0 && sx + 2 < P.W) v.z = row[sx + 2];
+                        if (sx + 3 >= 0 && sx + 3 < P.W) v.w = row[sx + 3];
+                    }
+                    xr[u][i] = v;
+                }
+            return;
+        }
         const float *xbase = cbase < P.C0 ? s0 + (size_t)cbase * HW : s1 + (size_t)(cbase - P.C0) * HW;
         if (cbase + KC <= P.Cin) {
 #pragma unroll
