@@ -50,6 +50,7 @@ struct ConvW {                    // packed convolution weights (device)
 };
 
 struct Act { float *p = nullptr; int C = 0, H = 0, W = 0;
+             const void *pf = nullptr; long long pf_bs = 0;   // set for a planes-only tensor: its PF copy (cdc_unet_tap unpacks it into p)
              long long bs() const { return (long long)C * H * W; } };
 
 struct ResBlockW { std::string prefix; int cin, cout, k; bool has_res; int shift_off;
@@ -662,8 +663,8 @@ struct Builder {
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)
-            snprintf(buf, sizeof buf, "conv %dx%d s1 %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s%s", op.pf.KH, op.pf.KW,
-                     op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s%s", op.pf.KH, op.pf.KW,
+                     op.pf.stride == 2 ? 2 : 1, op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
                      op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
                      op.pf.resid ? " +res" : "", cur == &h->pre_ops ? " HOIST" : "");
         else if (op.kind == Op::LN)
@@ -727,7 +728,7 @@ struct Builder {
     //   Downsample output (next level's first ResnetBlock)             +0.03 / -0.07
     //   attention and Upsample outputs up to 64 x 64 (the two halves of a decoder concat: 384 -> 128 @64^2 -0.19 for
     //   +0.025); at 128^2 the two costs (+0.13) eat the gain (-0.13), the 256^2 skip has no reader at all.
-    enum Site { SITE_NONE, SITE_ALWAYS, SITE_RB_CHAIN, SITE_DOWN, SITE_JOIN };
+    enum Site { SITE_NONE, SITE_ALWAYS, SITE_RB_CHAIN, SITE_DOWN, SITE_JOIN, SITE_ALWAYS_PLANES };
     int pf_mode() const { const char *e = dev_env("CDC_PF"); return h->arith != 1 ? 0 : (e ? atoi(e) : 3); }
     bool pf_site(Site s, int H, int W) const {
         const int m = pf_mode();
@@ -736,7 +737,7 @@ struct Builder {
         // (round 4: up to 128 x 128 -- the Upsample half of a join is written as planes INSTEAD of fp32 when both of its readers take
         //  planes, join_reads_planes, so only the skip half costs a second copy: 256->64 @128^2 0.52 -> 0.37 ms on conv_pf3_kernel)
         const long long join_max = dev_env("CDC_PF_JOIN_MAXPIX") ? atoll(dev_env("CDC_PF_JOIN_MAXPIX")) : 16384;
-        return s == SITE_RB_CHAIN || s == SITE_DOWN || (s == SITE_JOIN && (long long)H * W <= join_max);
+        return s == SITE_RB_CHAIN || s == SITE_DOWN || s == SITE_ALWAYS_PLANES || (s == SITE_JOIN && (long long)H * W <= join_max);
     }
     bool pf_on() const { return pf_mode() != 0; }
     static long long pf_maxpix() { const char *e = dev_env("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
@@ -817,6 +818,16 @@ struct Builder {
         return true;
     }
 
+    // Would a Downsample convolution (3x3 / stride 2 / pad 1) run on conv_pf_kernel<..., STR = 2> given a PF input of H x W?
+    bool pf_s2_would_plan(const ConvW &w, int H, int W) {
+        if (!pf_on() || !w.wsh || w.stride != 2 || w.transposed || w.KH != 3 || w.KW != 3 || (H & 1) || (W & 1) || (w.Cin % 16)) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 1 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 1) return false;
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = 3; ps.KW = 3; ps.Ho = H / 2; ps.Wo = W / 2; ps.B = pb(); ps.stride = 2;
+        PfPlan plan;
+        return pf_make_plan(ps, &plan);
+    }
+
     // Would a single-source 3x3 / 1x1 layer with fused LayerNorm run on conv_pf_kernel (given a PF input)?
     bool pf_would_plan(const ConvW &w, int H, int W) {
         if (!pf_on() || !w.wsh || w.stride != 1 || w.transposed) return false;
@@ -832,7 +843,9 @@ struct Builder {
     // k x k / 1x1 / phase-decomposed transposed convolution with "same" geometry.
     bool try_pf(const ConvW &w, const float *s0, int C0, const float *s1, int H, int W, float *out, long long out_bs,
                 const ConvOpts &o, bool need_all, int prof, const ConvShape &s) {
-        if (!pf_on() || !w.wsh || w.stride != 1 || o.pre_mean || o.w_bs || o.wsp_bs || o.max_ksplit > 1) return false;
+        if (!pf_on() || !w.wsh || (w.stride != 1 && w.stride != 2) || o.pre_mean || o.w_bs || o.wsp_bs || o.max_ksplit > 1) return false;
+        // stride 2: the 3x3 / pad 1 Downsample form on even extents, single source (conv_pf_kernel, STR = 2)
+        if (w.stride == 2 && (w.transposed || w.KH != 3 || w.KW != 3 || s1 || (H & 1) || (W & 1) || o.pre_add || o.res3_w)) return false;
         PfTwin *t0 = twin(s0), *t1 = s1 ? twin(s1) : nullptr;
         if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
         if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
@@ -843,7 +856,7 @@ struct Builder {
         if (!w.transposed && ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2)) return false;
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = w.KH; ps.KW = w.KW; ps.nz = w.nz;
-        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = need_all;
+        ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = need_all; ps.stride = w.stride;
         PfPlan plan;
         if (!pf_make_plan(ps, &plan)) return false;
         Op op;
@@ -854,7 +867,7 @@ struct Builder {
         if (t1) { a.src1 = t1->p; a.src1_bs = t1->bs(); }
         a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
         a.w = w.wsh; a.w_zs = w.wsp_zs / 8;            // planes of 8 halfs = one unit
-        a.KH = w.KH; a.KW = w.KW; a.nz = w.nz;
+        a.KH = w.KH; a.KW = w.KW; a.nz = w.nz; a.stride = w.stride;
         a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout;
         a.acc_scale = w.wscale_inv;
         a.out = o.no_f32 ? nullptr : out; a.out_bs = out_bs;
@@ -915,7 +928,7 @@ struct Builder {
         if (h->arith != 1 || !w.wsh || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
         if (dev_env("CDC_NO_PW")) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0) return false;
-        if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || o.no_f32) return false;
+        if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only) return false;
         if (o.pre_mean && o.pre_mode != 2) return false;
         if (o.w_bs && !o.wsp_bs) return false;              // per-image weights without planes
         PfShape ps;
@@ -947,6 +960,7 @@ struct Builder {
                 a.out_pf = to->p; a.pf_bs = to->bs(); a.pf_ps = to->ps();
                 a.pf_ys = s.Wo + 2; a.pf_xs = 1; a.pf_zoff[0] = (s.Wo + 2) + 1;
                 to->valid = true;
+                if (o.no_f32) a.out = nullptr;          // the planes are the only copy (their reader is a plane-operand kernel)
             }
         a.bias = o.no_bias ? nullptr : w.bias;
         a.pre_add = o.pre_add;
@@ -958,7 +972,7 @@ struct Builder {
         op.flops = 2.0 * px * w.Cout * w.Cin;
         op.bytes = 4.0 * ((double)B * w.Cin * H * W + px * w.Cout);
         last_ksplit = 1;
-        last_pf_only = false;
+        last_pf_only = a.out == nullptr;
         emit(op);
         return true;
     }
@@ -1300,7 +1314,9 @@ struct Builder {
     std::vector<std::pair<const float *, size_t>> dbg_taps;   // debugging aid (CDC_ATTN_TAP)
 
     // Residual(PreNorm(LinearAttention)) (network_components.py:10-16,69-77,117-139)
-    Act attention(const AttnW &at, Act x, float *sm, float *sr, Site out_site = SITE_JOIN) {
+    // out_planes_only: the output's only reader takes planes (the level-0 Downsample) -- no fp32 copy is written where the folded
+    // output runs on the pointwise kernel; Act::pf of the result says whether that happened
+    Act attention(const AttnW &at, Act x, float *sm, float *sr, Site out_site = SITE_JOIN, bool out_planes_only = false) {
         if (rc) return Act();
         const int C = at.C, H = x.H, W = x.W, N = H * W;
         const bool fold = at.WoT && N >= 16 * C && !dev_env("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
@@ -1397,7 +1413,9 @@ struct Builder {
             oy.shift = biasB; oy.shift_bs = C;
             oy.resid = x.p; oy.resid_bs = x.bs(); oy.resid_cs = N;
             oy.emit_pf = true;
+            oy.no_f32 = out_planes_only && split_out && twin(y.p) != nullptr;
             conv(cw, x.p, C, x.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
+            if (last_pf_only) { PfTwin *ty = twin(y.p); y.pf = ty->p; y.pf_bs = ty->bs(); }
             return y;
         }
         // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
@@ -1467,7 +1485,9 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         h->taps[dn + ".1"] = x;
         // (the level-0 skip is never popped -- unet.py:113 pushes six, :123 pops five: its only reader is the Downsample)
-        x = bd.attention(h->attns[ati++], x, sm, sr, i >= 1 ? Builder::SITE_JOIN : Builder::SITE_NONE);
+        // Its output goes to the Downsample as planes INSTEAD of fp32 where that convolution runs on the plane-operand kernel.
+        const bool l0_planes = i == 0 && n > 1 && bd.pf_s2_would_plan(h->downs[0], x.H, x.W) && !dev_env("CDC_NO_PF_S2_L0");
+        x = bd.attention(h->attns[ati++], x, sm, sr, i >= 1 ? Builder::SITE_JOIN : (l0_planes ? Builder::SITE_ALWAYS_PLANES : Builder::SITE_NONE), l0_planes);
         h->taps[dn + ".2"] = x;
         skips.push_back(x);
         if (i < n - 1) {
@@ -1475,6 +1495,8 @@ int build_program(cdc_handle *h, int B, int H, int W) {
             Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2, true, Builder::SITE_DOWN);
             Builder::ConvOpts od; od.emit_pf = true;
             bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), od, false, PC_DOWN);
+            if (x.pf && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
+                return fail(h, CDC_ERR_UNSUPPORTED, "planes-only Downsample input without a plane-operand kernel");
             x = y;
             h->taps[dn + ".3"] = x;
         }
@@ -2740,6 +2762,10 @@ int cdc_unet_tap(cdc_handle *h, const char *name, float *out, int64_t shape[4]) 
     shape[0] = h->pB; shape[1] = a.C; shape[2] = a.H; shape[3] = a.W;
     if (out) {
         HIP_TRY(h, hipDeviceSynchronize());
+        if (a.pf) {         // a planes-only tensor: h + l 2^-11 into its (otherwise unwritten) fp32 buffer
+            HIP_TRY(h, pf_unpack_launch(a.pf, a.pf_bs, a.p, a.bs(), a.C, a.H, a.W, h->pB, nullptr));
+            HIP_TRY(h, hipDeviceSynchronize());
+        }
         HIP_TRY(h, hipMemcpy(out, a.p, (size_t)h->pB * a.bs() * sizeof(float), hipMemcpyDeviceToHost));
     }
     return CDC_OK;
@@ -3136,6 +3162,12 @@ static int op_conv2d_impl(cdc_handle *h, const float *x, const float *w, const f
         bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, o, false, prof);
     }
     if (bd.rc) return bd.rc;
+    // test aid: the layer must have been planned on the plane-operand kernel (a silent fallback would test nothing)
+    if (dev_env("CDC_OP_REQUIRE_PF")) {
+        bool on_pf = false;
+        for (const Op &q : h->ops) on_pf = on_pf || (q.kind == Op::CONVPF && !q.pw);
+        if (!on_pf) return fail(h, CDC_ERR_UNSUPPORTED, "CDC_OP_REQUIRE_PF: the convolution was not planned on conv_pf_kernel");
+    }
     return sc.run(B, y, dy, (size_t)B * Cout * Ho * Wo);
 }
 

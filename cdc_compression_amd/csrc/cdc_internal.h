@@ -48,6 +48,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &plan, int B, int nz, hipStrea
 struct PfShape {
     int Cin, Cout, C0 = 0, KH, KW, nz = 1, Ho, Wo, B;
     bool need_all_cout = false;
+    int stride = 1;      // 2: 3x3 / pad 1 Downsample convolution (conv_pf_kernel, STR = 2)
 };
 struct PfPlan {
     int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; int lin = 0;
@@ -63,6 +64,8 @@ bool pw_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
 hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long long dst_bs, int C, int H, int W, int B,
                           hipStream_t st);
+// PF -> fp32 NCHW (cdc_unet_tap of a planes-only tensor)
+hipError_t pf_unpack_launch(const void *src, long long src_bs, float *dst, long long dst_bs, int C, int H, int W, int B, hipStream_t st);
 
 // Development switches -- the ~45 CDC_* launch-plan / kernel-selection A/B knobs of the planners -- are honoured only in a
 // process started with CDC_DEV=1 (the test-suite and the tuning tools set it).  Every other process runs the default

@@ -106,6 +106,7 @@ struct PfArgs {
     const void *w;                  // fp16 planes {WH, WL, WH2}: [z][tap][Cin/16][3][2][COP] units
     long long w_zs;
     int KH, KW, nz;
+    int stride;                     // 0 / 1, or 2: conv_pf_kernel<..., STR = 2> (3x3 / pad 1; H, W stay the INPUT extent)
     int pad_y[4], pad_x[4];
     int nchunk, COP, Cout;
     float acc_scale;

@@ -17,7 +17,15 @@ static pf_kernel_fn pf_lookup_k(int MB, int NPW, int WM, int WP) {
     if (MB == 2 && NPW == 2 && WM == 4 && WP == 2) return conv_pf_kernel<2, 2, 4, 2, KH, KW>;
     return nullptr;
 }
-static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW) {
+// stride-2 3x3 (Downsample): 4-row tiles, one workgroup per CU
+static pf_kernel_fn pf_lookup_s2(int MB, int NPW, int WM, int WP) {
+    if (MB == 2 && NPW == 1 && WM == 1 && WP == 4) return conv_pf_kernel<2, 1, 1, 4, 3, 3, 2>;
+    if (MB == 2 && NPW == 2 && WM == 2 && WP == 2) return conv_pf_kernel<2, 2, 2, 2, 3, 3, 2>;
+    if (MB == 3 && NPW == 1 && WM == 2 && WP == 4) return conv_pf_kernel<3, 1, 2, 4, 3, 3, 2>;
+    return nullptr;
+}
+static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW, int stride = 1) {
+    if (stride == 2) return (KH == 3 && KW == 3) ? pf_lookup_s2(MB, NPW, WM, WP) : nullptr;
     if (KH == 3 && KW == 3) return pf_lookup_k<3, 3>(MB, NPW, WM, WP);
     if (KH == 1 && KW == 1) return pf_lookup_k<1, 1>(MB, NPW, WM, WP);
     if (KH == 2 && KW == 2) return pf_lookup_k<2, 2>(MB, NPW, WM, WP);
@@ -26,6 +34,11 @@ static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW) {
 
 // Candidate shapes, best first for a given channel-group width COPT = WM*MB*32.
 struct PfCand { int MB, NPW, WM, WP; };
+static const PfCand kCandsS2[] = {
+    {2, 2, 2, 2},   // 128 channels, 4 waves, 4 rows
+    {3, 1, 2, 4},   // 192 channels, 8 waves, 4 rows
+    {2, 1, 1, 4},   //  64 channels, 4 waves, 4 rows
+};
 static const PfCand kCands[] = {
     {2, 2, 4, 2},   // 256 channels, 8 waves, 4 rows
     {3, 2, 2, 4},   // 192 channels, 8 waves, 8 rows
@@ -41,6 +54,31 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
     int f[4] = {0, 0, 0, 0};
     if (force) sscanf(force, "%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3]);
     double best = -1;
+    if (s.stride == 2) {
+        // Downsample: no fused LayerNorm, so any channel-group width divides the work; the widest that fits reads the patch once
+        if (s.KH != 3 || s.KW != 3 || s.nz != 1 || s.C0 || dev_env("CDC_NO_PF_S2")) return false;
+        for (const PfCand &c : kCandsS2) {
+            if (f[0] && (c.MB != f[0] || c.NPW != f[1] || c.WM != f[2] || c.WP != f[3])) continue;
+            const int COPT = c.WM * c.MB * 32, TH = c.WP * c.NPW;
+            if (s.Cout % COPT || (s.need_all_cout && COPT != s.Cout)) continue;
+            const int ring = pf_ring(c.MB, c.NPW, c.WM, c.WP, 3, 3, 2);
+            const int S = (s.Cin / 16) * 9;
+            if (!ring || S < ring - 1) continue;
+            const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * (s.Cout / COPT);
+            static const double min_wgs = dev_env("CDC_PF_S2_MIN_WGS") ? atof(dev_env("CDC_PF_S2_MIN_WGS")) : 256.0;
+            if (wgs < min_wgs) continue;                        // one workgroup per CU: fewer than one round leaves CUs idle
+            const double score = (double)COPT;
+            if (score <= best) continue;
+            best = score;
+            const size_t patch = (size_t)2 * pf_patch_units(c.NPW, c.WP, 3, 3, 2) * 16, wst = (size_t)pf_rows(c.MB, c.NPW) * COPT * 16;
+            p->MB = c.MB; p->NPW = c.NPW; p->WM = c.WM; p->WP = c.WP;
+            p->ring = ring;
+            p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + TH - 1) / TH;
+            p->groups = s.Cout / COPT;
+            p->lds_bytes = std::max(patch + ring * wst, sizeof(float) * (size_t)(4 * COPT + 2 * c.WM * c.WP * c.NPW * 32));
+        }
+        return best >= 0;
+    }
     for (const PfCand &c : kCands) {
         if (f[0] && (c.MB != f[0] || c.NPW != f[1] || c.WM != f[2] || c.WP != f[3])) continue;
         const int COPT = c.WM * c.MB * 32, NW = c.WM * c.WP;
@@ -79,7 +117,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
 
 hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     if (p.pf3_epv) return pf3_launch(a, p, B, st);
-    pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW);
+    pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW, a.stride == 2 ? 2 : 1);
     if (!fn) return hipErrorInvalidValue;
     a.lognbw = 5;
     { static const char *e = dev_env("CDC_PF_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -123,6 +161,30 @@ hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long lo
     const long long n = (long long)(C / 8) * H * W;
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
     hipLaunchKernelGGL(pf_pack_kernel, grid, dim3(256), 0, st, src, src_bs, reinterpret_cast<uint4 *>(dst), dst_bs, C, H, W);
+    return hipGetLastError();
+}
+
+// PF -> fp32 NCHW: a = h + l' 2^-11 (interior only).  One thread = one unit pair.
+__global__ void __launch_bounds__(256) pf_unpack_kernel(const uint4 *src, long long src_bs, float *dst, long long dst_bs, int C, int H, int W) {
+    const int b = blockIdx.y;
+    const long long n = (long long)(C / 8) * H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % W);
+    const long long t = i / W;
+    const int y = (int)(t % H), g = (int)(t / H);
+    const long long ps = (long long)(H + 2) * (W + 2);
+    const uint4 *sp = src + (size_t)b * src_bs + (long long)g * 2 * ps + (long long)(y + 1) * (W + 2) + x + 1;
+    const f16x8 hv = __builtin_bit_cast(f16x8, sp[0]), lv = __builtin_bit_cast(f16x8, sp[ps]);
+    float *dp = dst + (size_t)b * dst_bs + ((size_t)g * 8 * H + y) * W + x;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dp[(size_t)q * H * W] = (float)hv[q] + (float)lv[q] * (1.0f / 2048.0f);
+}
+
+hipError_t pf_unpack_launch(const void *src, long long src_bs, float *dst, long long dst_bs, int C, int H, int W, int B, hipStream_t st) {
+    const long long n = (long long)(C / 8) * H * W;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(pf_unpack_kernel, grid, dim3(256), 0, st, reinterpret_cast<const uint4 *>(src), src_bs, dst, dst_bs, C, H, W);
     return hipGetLastError();
 }
 

@@ -55,12 +55,13 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
 // the planes {WH, WL} and a second accumulator set (see mma); the others the three planes {WH, WL, WH2}.
 __host__ __device__ constexpr bool pf_acc2(int MB, int NPW) { return MB * NPW <= 4; }
 __host__ __device__ constexpr int pf_rows(int MB, int NPW) { return pf_acc2(MB, NPW) ? 4 : 6; }
-__host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW) {
-    return ((4 * (WP * NPW + KH - 1) * (32 + KW - 1) + 63) / 64) * 64;
+__host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW, int STR = 1) {
+    return ((4 * ((WP * NPW - 1) * STR + KH) * (31 * STR + KW) + 63) / 64) * 64;
 }
-__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW) {
-    const size_t budget = WM * WP == 8 ? 156 * 1024 : 80 * 1024;
-    const size_t patch = (size_t)(KH * KW == 1 ? 3 : 2) * pf_patch_units(NPW, WP, KH, KW) * 16;
+// (stride 2: the patch of a 4-row tile is 9 x 65 pixels -- two buffers of it leave room for ONE workgroup per CU)
+__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1) {
+    const size_t budget = (WM * WP == 8 || STR == 2) ? 156 * 1024 : 80 * 1024;
+    const size_t patch = (size_t)(KH * KW == 1 ? 3 : 2) * pf_patch_units(NPW, WP, KH, KW, STR) * 16;
     const size_t wst = (size_t)pf_rows(MB, NPW) * WM * MB * 32 * 16;
 #ifndef CDC_PF_RING_MAX
 #define CDC_PF_RING_MAX 5
@@ -75,8 +76,12 @@ __host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int K
 
 // KH x KW are compile-time (3x3, 1x1, 2x2 phases): tap offsets become ds_read immediates, the tap loop and the
 // patch-issue schedule are unrolled, and the per-tap scalar work shrinks to the ring counters.
-template <int MB, int NPW, int WM, int WP, int KH, int KW>
-__global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) ? 2 : 1) conv_pf_kernel(const PfArgs P) {
+//
+// STR = 2 (3x3 / pad 1 Downsample convolutions, network_components.py:51-53): the tile's patch is (2 TH + 1) x 65 pixels; the DMA
+// lanes de-interleave its columns -- even columns first, then the odd ones -- so that the B operand of a tap (pixel 2j + kx of
+// lane j) is again one contiguous run of units: column position kx/2 of the even (kx even) or odd (kx odd) half-row.
+template <int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1>
+__global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 || MB * NPW <= 4) ? 2 : 1)) conv_pf_kernel(const PfArgs P) {
     constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
     static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
     constexpr bool ACC2 = pf_acc2(MB, NPW);
@@ -87,7 +92,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     constexpr int TAPS = KH * KW;
     constexpr int NBW = 32, NBH = 1;                    // a 32-pixel block is a row segment (host: lognbw = 5)
     constexpr int TH = WP * NPW * NBH;
-    constexpr int PH = TH + KH - 1, PW = NBW + KW - 1, PLANE = PH * PW;
+    constexpr int PH = (TH - 1) * STR + KH, PW = (NBW - 1) * STR + KW, PLANE = PH * PW;
+    constexpr int NE = (PW + 1) / 2;                    // STR = 2: even patch columns sit at positions [0, NE), odd ones behind
     constexpr int NX = 4 * PLANE;                       // units per chunk
     constexpr int XSW = (NX + 63) / 64;                 // DMA instructions per chunk
     constexpr int KX = (XSW + 1) / 2;                   // ... per patch wave (even / odd instructions)
@@ -95,7 +101,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     // 1x1 layers have one tap per chunk: their patches run two chunks ahead through three buffers
     constexpr int LA = TAPS == 1 ? 2 : 1, NPB = LA + 1;
     constexpr int WST = ROWS * COPT;                       // units per weight stage
-    static_assert(KX <= kPfXS, "patch too large for two patch waves");
+    static_assert(KX <= (STR == 2 ? 20 : kPfXS), "patch too large for two patch waves");
+    static_assert(STR == 1 || (STR == 2 && KH == 3 && KW == 3), "stride 2 is the 3x3 Downsample form");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,21 +119,22 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     const int b = bid / P.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * NBW;
     const int S = P.nchunk * TAPS;
-    constexpr int R = pf_ring(MB, NPW, WM, WP, KH, KW);   // weight ring slots (host: S >= R - 1)
+    constexpr int R = pf_ring(MB, NPW, WM, WP, KH, KW, STR);   // weight ring slots (host: S >= R - 1)
     static_assert(R >= 3, "no room for a weight ring");
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
     const unsigned wl_lds = lds0 + (unsigned)(NPB * PST) * 16u;
 
     // ---- patch waves: per-lane source offsets of their DMA instructions (constant over chunks) --------------
     const int Hp = P.H + 2, Wp = P.W + 2;
-    const int iy0 = oy0 - P.pad_y[z] + 1, ix0 = ox0 - P.pad_x[z] + 1;      // +1: halo origin
+    const int iy0 = oy0 * STR - P.pad_y[z] + 1, ix0 = ox0 * STR - P.pad_x[z] + 1;      // +1: halo origin
     unsigned xoff[KX];
 #pragma unroll
     for (int i = 0; i < KX; ++i) {
         int e = (2 * i + (pwi & 1)) * 64 + lane;
         if (e >= NX) e = 0;
         const int q = e / PLANE, rem = e - q * PLANE;    // q = k-half * 2 + plane: the order of the tensor
-        const int r = rem / PW, c = rem - r * PW;
+        const int r = rem / PW, cp = rem - r * PW;
+        const int c = STR == 2 ? (cp < NE ? 2 * cp : 2 * (cp - NE) + 1) : cp;
         const int iy = min(max(iy0 + r, 0), Hp - 1), ix = min(max(ix0 + c, 0), Wp - 1);
         xoff[i] = (unsigned)((q * Hp + iy) * Wp + ix) * 16u;
     }
@@ -185,14 +193,15 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
     const int pr = 0, pc = j;
     // A: stage[(pl*2 + half)*COPT + wm*MB*32 + m*32 + j];  B: buf[(half*2 + pl)*PLANE + (row + ky)*PW + pc + kx]
     const uint4 *a_base = smem_u + NPB * PST + half * COPT + wm * MB * 32 + j;
-    const uint4 *b_base = smem_u + (half * 2) * PLANE + (wp * NPW) * PW + j;
+    const uint4 *b_base = smem_u + (half * 2) * PLANE + (wp * NPW * STR) * PW + j;
 
     typedef f16x8 OpsA[NPL][MB];
     typedef f16x8 OpsB[2][NPW];
     // operands of tap t (compile-time: immediates) from patch buffer xb and ring slot wa
     auto fetch = [&](auto tc, const uint4 *xb, const uint4 *wa, OpsA &A, OpsB &Bv) {
         constexpr int t = decltype(tc)::value;
-        constexpr int koff = (t / KW) * PW + (t % KW);
+        constexpr int kx = t % KW;
+        constexpr int koff = (t / KW) * PW + (STR == 2 ? (kx & 1) * NE + kx / 2 : kx);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -200,7 +209,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (WM * WP == 8 || MB * NPW <= 4) 
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) Bv[pl][n] = __builtin_bit_cast(f16x8, xb[pl * PLANE + n * PW + koff]);
+            for (int n = 0; n < NPW; ++n) Bv[pl][n] = __builtin_bit_cast(f16x8, xb[pl * PLANE + n * STR * PW + koff]);
     };
     // a = h + l' 2^-11, w 2^s = WH + WL:  acc += WL.h + WH.h,  acc2 += WH.l'  (result = acc + acc2 2^-11).  The second
     // accumulator set replaces a third weight plane WH 2^-11: a third fewer A-operand bytes through LDS-DMA, the

@@ -146,6 +146,26 @@ def test_conv2d_pre_split_operand_kernel(O, case, monkeypatch):
     _conv_check(O, Ops(0), case)
 
 
+PF_S2_CASES = [
+    # conv_pf_kernel<..., STR = 2> (3x3 / stride 2 / pad 1 Downsample on plane operands), one case per tile shape
+    (2, 64, 64, 128, 64, 3, 2, 1, False),    # 64 channels: four waves, one pixel block each
+    (1, 128, 36, 64, 128, 3, 2, 1, False),   # 128 channels: two channel parts, ragged rows (18 = 4 * 4 + 2)
+    (1, 192, 32, 96, 192, 3, 2, 1, False),   # 192 channels: eight waves, ragged columns (48 = 32 + 16)
+    (1, 64, 64, 64, 128, 3, 2, 1, False),    # Cin != Cout
+    (1, 32, 64, 64, 192, 3, 2, 1, False),    # two chunks only
+]
+
+
+@pytest.mark.parametrize("case", PF_S2_CASES)
+def test_conv2d_stride2_on_plane_operands(O, case, monkeypatch):
+    """Downsample convolutions on conv_pf_kernel (STR = 2): de-interleaved patch columns, 4-row tiles."""
+    monkeypatch.setenv("CDC_PF", "1")
+    monkeypatch.setenv("CDC_PF_MAXPIX", "0")
+    monkeypatch.setenv("CDC_PF_S2_MIN_WGS", "1")
+    monkeypatch.setenv("CDC_OP_REQUIRE_PF", "1")      # fails instead of falling back to the register-staged kernel
+    _conv_check(O, Ops(0), case)
+
+
 PW_CASES = [  # B, Cin, H, W, Cout: every tile shape of conv_pw_kernel's planner, ragged rows, linear (narrow-map) tiles
     (2, 64, 36, 64, 64), (1, 128, 20, 32, 128), (2, 256, 32, 32, 256), (1, 96, 64, 64, 192), (1, 64, 40, 96, 384),
     (3, 320, 16, 16, 128), (4, 384, 8, 8, 256), (1, 48, 12, 16, 64)]
@@ -254,7 +274,8 @@ def test_unet_forward_matches_reference_golden(name):
 @pytest.mark.parametrize("name,env", [("full_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}), ("small_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),
                                       ("full_eps", {"CDC_PF": "1", "CDC_PF_MAXPIX": "16384"}),
                                       ("full_x", {"CDC_PF": "2"}), ("full_x", {"CDC_PF": "0"}), ("full_eps", {"CDC_PF": "2"}),
-                                      ("full_x", {"CDC_PF_JOIN_MAXPIX": "65536"}),
+                                      ("full_x", {"CDC_PF_JOIN_MAXPIX": "65536"}), ("full_x", {"CDC_PF_S2_MIN_WGS": "1"}),
+                                      ("full_eps", {"CDC_PF_S2_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_S2": "1"}),
                                       ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
                                       ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
                                       ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
@@ -764,6 +785,18 @@ def test_unet_stage_taps_match_reference(name):
     """Per-stage activations (forward hooks on the reference modules, stored by gen_unet as arrays for the small
     configurations and as digests for the full-width ones) against cdc_unet_tap of the same forward: a wrong
     ResnetBlock / attention / resampler shows up at its own stage, not only in the final output."""
+    _check_taps(name)
+
+
+def test_unet_stage_taps_of_a_planes_only_tensor(monkeypatch):
+    """With the level-0 Downsample on the plane-operand kernel its input (downs.0.2, the attention output) exists as planes only:
+    cdc_unet_tap unpacks h + l 2^-11."""
+    monkeypatch.setenv("CDC_PF_S2_MIN_WGS", "1")
+    _check_taps("full_x")
+    _check_taps("full_eps")
+
+
+def _check_taps(name):
     un, kw, sd, x, time, ctx, g = make_unet(name)
     un(x, time, ctx)
     checked = 0
