@@ -62,15 +62,16 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
             const int COPT = c.WM * c.MB * 32, TH = c.WP * c.NPW;
             if (s.Cout % COPT || (s.need_all_cout && COPT != s.Cout)) continue;
             const int ring = pf_ring(c.MB, c.NPW, c.WM, c.WP, 3, 3, 2);
-            const int S = (s.Cin / 16) * 9;
+            const int tps = pf_tps(c.MB, c.NPW, c.WM, c.WP, 3, 3, 2);
+            const int S = (s.Cin / 16) * 9 / tps;                // weight stages of a tile
             if (!ring || S < ring - 1) continue;
             const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * (s.Cout / COPT);
-            static const double min_wgs = dev_env("CDC_PF_S2_MIN_WGS") ? atof(dev_env("CDC_PF_S2_MIN_WGS")) : 256.0;
+            const double min_wgs = dev_env("CDC_PF_S2_MIN_WGS") ? atof(dev_env("CDC_PF_S2_MIN_WGS")) : 256.0;
             if (wgs < min_wgs) continue;                        // one workgroup per CU: fewer than one round leaves CUs idle
             const double score = (double)COPT;
             if (score <= best) continue;
             best = score;
-            const size_t patch = (size_t)2 * pf_patch_units(c.NPW, c.WP, 3, 3, 2) * 16, wst = (size_t)pf_rows(c.MB, c.NPW) * COPT * 16;
+            const size_t patch = (size_t)pf_patch_bufs(3, 3, 2) * pf_patch_units(c.NPW, c.WP, 3, 3, 2) * 16, wst = (size_t)tps * pf_rows(c.MB, c.NPW) * COPT * 16;
             p->MB = c.MB; p->NPW = c.NPW; p->WM = c.WM; p->WP = c.WP;
             p->ring = ring;
             p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + TH - 1) / TH;

@@ -58,17 +58,36 @@ __host__ __device__ constexpr int pf_rows(int MB, int NPW) { return pf_acc2(MB, 
 __host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW, int STR = 1) {
     return ((4 * ((WP * NPW - 1) * STR + KH) * (31 * STR + KW) + 63) / 64) * 64;
 }
-// (stride 2: the patch of a 4-row tile is 9 x 65 pixels -- two buffers of it leave room for ONE workgroup per CU)
-__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1) {
+// Patch buffers: the patch of chunk c + LA streams in while chunk c is multiplied, LA = buffers - 1.  1x1 layers (one tap per chunk)
+// and stride-2 layers (one workgroup of one wave per SIMD on the CU: nothing else hides the HBM latency of a patch) run two
+// chunks ahead.
+#ifndef CDC_PF_S2_NPB
+#define CDC_PF_S2_NPB 2      // (3 = two chunks ahead was measured: not faster, 0.281 -> 0.305 ms on 64 -> 64 @256^2 -> 128^2)
+#endif
+__host__ __device__ constexpr int pf_patch_bufs(int KH, int KW, int STR = 1) { return STR == 2 ? CDC_PF_S2_NPB : (KH * KW == 1 ? 3 : 2); }
+// (stride 2: the patch of a 4-row tile is 9 x 65 pixels = 37 KB -- ONE workgroup per CU)
+// tps = taps per weight stage (one s_barrier per stage)
+__host__ __device__ constexpr int pf_ring_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR, int tps) {
     const size_t budget = (WM * WP == 8 || STR == 2) ? 156 * 1024 : 80 * 1024;
-    const size_t patch = (size_t)(KH * KW == 1 ? 3 : 2) * pf_patch_units(NPW, WP, KH, KW, STR) * 16;
-    const size_t wst = (size_t)pf_rows(MB, NPW) * WM * MB * 32 * 16;
+    const size_t patch = (size_t)pf_patch_bufs(KH, KW, STR) * pf_patch_units(NPW, WP, KH, KW, STR) * 16;
+    const size_t wst = (size_t)tps * pf_rows(MB, NPW) * WM * MB * 32 * 16;
 #ifndef CDC_PF_RING_MAX
 #define CDC_PF_RING_MAX 5
 #endif
     for (int r = CDC_PF_RING_MAX; r >= 3; --r)
         if (patch + r * wst <= budget) return r;
     return 0;
+}
+// Taps per weight stage.  The stride-2 form runs ONE wave per SIMD with 3 - 12 MFMAs per tap: a barrier per tap leaves the
+// matrix pipe idle most of the time, so a stage holds a whole kernel row where the ring still fits.
+#ifndef CDC_PF_S2_TPS
+#define CDC_PF_S2_TPS 3
+#endif
+__host__ __device__ constexpr int pf_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1) {
+    return (STR == 2 && CDC_PF_S2_TPS > 1 && pf_ring_tps(MB, NPW, WM, WP, KH, KW, STR, CDC_PF_S2_TPS) >= 3) ? CDC_PF_S2_TPS : 1;
+}
+__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1) {
+    return pf_ring_tps(MB, NPW, WM, WP, KH, KW, STR, pf_tps(MB, NPW, WM, WP, KH, KW, STR));
 }
 #ifndef CDC_PF_ABLATE
 #define CDC_PF_ABLATE 0      // 1: honour PfArgs::dbg (timing experiments with wrong results)
@@ -99,8 +118,12 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     constexpr int KX = (XSW + 1) / 2;                   // ... per patch wave (even / odd instructions)
     constexpr int PST = XSW * 64;                       // units per patch buffer (tail lanes land in the slack)
     // 1x1 layers have one tap per chunk: their patches run two chunks ahead through three buffers
-    constexpr int LA = TAPS == 1 ? 2 : 1, NPB = LA + 1;
-    constexpr int WST = ROWS * COPT;                       // units per weight stage
+    constexpr int NPB = pf_patch_bufs(KH, KW, STR), LA = NPB - 1;
+    constexpr int TPS = pf_tps(MB, NPW, WM, WP, KH, KW, STR);   // taps per weight stage
+    static_assert(TAPS % TPS == 0, "a weight stage is a whole number of taps of one chunk");
+    constexpr int SPC = TAPS / TPS;                        // stages per chunk
+    constexpr int TAPW = ROWS * COPT;                      // units per tap of a stage
+    constexpr int WST = TPS * TAPW;                        // units per weight stage
     static_assert(KX <= (STR == 2 ? 20 : kPfXS), "patch too large for two patch waves");
     static_assert(STR == 1 || (STR == 2 && KH == 3 && KW == 3), "stride 2 is the 3x3 Downsample form");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
@@ -118,7 +141,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     const int ty = bid % P.tiles_y;
     const int b = bid / P.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * NBW;
-    const int S = P.nchunk * TAPS;
+    const int S = P.nchunk * SPC;                          // weight stages of the tile
     constexpr int R = pf_ring(MB, NPW, WM, WP, KH, KW, STR);   // weight ring slots (host: S >= R - 1)
     static_assert(R >= 3, "no room for a weight ring");
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
@@ -167,14 +190,17 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
         wdo[k] = __builtin_amdgcn_readfirstlane((unsigned)jj * 1024u);
     }
     const long long w_dt = (long long)P.nchunk * 6 * P.COP * 16;          // next tap, same chunk
-    const long long w_dc = (long long)6 * P.COP * 16 - (TAPS - 1) * w_dt;  // first tap of the next chunk
-    const char *wptr = wsrc;                              // stage to be issued next
-    int tw = 0, sw = 0;                                   // its tap and ring slot
+    const long long w_dc = (long long)6 * P.COP * 16 - (TAPS - TPS) * w_dt;  // first tap of the next chunk (from the chunk's last stage)
+    const char *wptr = wsrc;                              // stage to be issued next (its first tap)
+    int tw = 0, sw = 0;                                   // its first tap and ring slot
     auto issue_w = [&]() {
         const unsigned dst = wl_lds + (unsigned)(sw * WST) * 16u;
 #pragma unroll
-        for (int k = 0; k < NWW; ++k) dma16(wvo[k], wptr, dst + wdo[k]);
-        if (++tw == TAPS) { tw = 0; wptr += w_dc; } else wptr += w_dt;
+        for (int q = 0; q < TPS; ++q)
+#pragma unroll
+            for (int k = 0; k < NWW; ++k) dma16(wvo[k], wptr + q * w_dt, dst + (unsigned)(q * TAPW) * 16u + wdo[k]);
+        tw += TPS;
+        if (tw == TAPS) { tw = 0; wptr += w_dc; } else wptr += TPS * w_dt;
         if (++sw == R) sw = 0;
     };
 
@@ -253,24 +279,40 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     OpsA A0, A1;
     OpsB B0, B1;
     fetch(std::integral_constant<int, 0>{}, b_base, a_base, A0, B0);
-    int rem = S - 1;                                      // taps after the one being multiplied
-    int sn = 0;                                           // ring slot of the tap being fetched
+    int rem = S - 1;                                      // weight stages after the one being multiplied
+    int sn = 0;                                           // ring slot of the stage being fetched from
     // One tap.  TAIL = false: a tap of any chunk but the last -- every condition of the pipeline holds (the host
     // guarantees TAPS >= ring - 1 or handles short tiles through the tail variant), so the body is straight-line
     // code apart from the wave-role branch.  TAIL = true: the last chunk, with the end-of-tile conditions.
+    // A weight stage holds TPS taps: its last tap does the ring work (wait, barrier, slot recycling); the others only fetch the
+    // next tap's operands from the same slot and patch buffer.
     auto tap = [&](auto tc, auto tailc, int chunk, const uint4 *xb_cur, const uint4 *xb_nxt, OpsA &Ac, OpsB &Bc, OpsA &An,
                    OpsB &Bn) {
         constexpr int t = decltype(tc)::value;
         constexpr bool TAIL = decltype(tailc)::value;
+        constexpr bool SEND = (t % TPS) == TPS - 1;       // last tap of its stage
+        if constexpr (!SEND) {
+            if (!(CDC_PF_ABLATE && (P.dbg & 64)))
+                fetch(std::integral_constant<int, t + 1>{}, xb_cur, a_base + sn * WST + ((t + 1) % TPS) * TAPW, An, Bn);
+            if (patch_wave) {
+                if constexpr (t < ISSUE_TAPS)
+                    if (chunk + LA < P.nchunk && !(CDC_PF_ABLATE && (P.dbg & 2))) issue_patch(chunk + LA, tc);
+            }
+        } else {
         if (!(TAIL && t == TAPS - 1) || rem > 0) {        // (the very last tap has nothing left to fetch)
             if (++sn == R) sn = 0;
             // W(s+1) (and, at a chunk seam, the patch of the next chunk) must have landed before anyone reads it
             if (CDC_PF_ABLATE && (P.dbg & 8)) {
             } else if (patch_wave) {
-                if constexpr (t == TAPS - 1) dma_wait();
+                if constexpr (t == TAPS - 1) {
+                    // two chunks ahead with several taps per chunk: the instructions issued during THIS chunk (patch of chunk
+                    // c + 2, at least XSW / 2 per patch wave) stay in flight, everything older -- the patch of chunk c + 1 -- has landed
+                    if (LA == 2 && TAPS > 1 && chunk + LA < P.nchunk) vm_wait<XSW / 2>();
+                    else dma_wait();
+                }
             } else if (!TAIL || rem >= R - 2) {
                 // newer than W(s+1) in this wave's queue: W(s+2) .. W(s+R-2) = (R-3) stages
-                vm_wait<(R - 3) * NWW>();
+                vm_wait<(R - 3) * NWW * TPS>();
             } else {
                 dma_wait();                               // tail of the tile: everything in flight is needed next
             }
@@ -287,6 +329,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
             }
         }
         --rem;
+        }
         __builtin_amdgcn_s_setprio(2);
         if (!(CDC_PF_ABLATE && (P.dbg & 32))) mma(Ac, Bc);
         __builtin_amdgcn_s_setprio(0);
@@ -307,7 +350,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     // chunks whose taps all satisfy rem >= ring - 1 run the straight-line variant
-    const int n_main = max(0, min(P.nchunk - 1, (S - R + 1) / TAPS));
+    const int n_main = max(0, min(P.nchunk - 1, (S - R + 1) / SPC));
     if constexpr ((TAPS & 1) == 0) {
         int chunk = 0;
         for (; chunk < n_main; ++chunk) chunk_body(P0{}, std::false_type{}, chunk);
