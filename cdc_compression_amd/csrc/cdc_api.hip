@@ -663,10 +663,10 @@ struct Builder {
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)
-            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s%s", op.pf.KH, op.pf.KW,
+            snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s%s%s", op.pf.KH, op.pf.KW,
                      op.pf.stride == 2 ? 2 : 1, op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
                      op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
-                     op.pf.resid ? " +res" : "", cur == &h->pre_ops ? " HOIST" : "");
+                     op.pf.resid ? " +res" : "", cur == &h->pre_ops ? " HOIST" : "", op.pf.tz == 4 ? " TZ4" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -828,6 +828,15 @@ struct Builder {
         return pf_make_plan(ps, &plan);
     }
 
+    // Would an Upsample (ConvTranspose2d 4x4 / stride 2 / pad 1) run on conv_pf_kernel<..., TZ = 4> given a PF input of H x W?
+    bool pf_tz_would_plan(const ConvW &w, int H, int W) {
+        if (!pf_on() || !w.wsh || !w.transposed || w.tk != 4 || w.KH != 2 || w.KW != 2 || (w.Cin % 16) || dev_env("CDC_PF_TRANSPOSED")) return false;
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = 2; ps.KW = 2; ps.nz = w.nz; ps.Ho = H; ps.Wo = W; ps.B = pb(); ps.tz = 4;
+        PfPlan plan;
+        return pf_make_plan(ps, &plan);
+    }
+
     // Would a single-source 3x3 / 1x1 layer with fused LayerNorm run on conv_pf_kernel (given a PF input)?
     bool pf_would_plan(const ConvW &w, int H, int W) {
         if (!pf_on() || !w.wsh || w.stride != 1 || w.transposed) return false;
@@ -850,13 +859,16 @@ struct Builder {
         if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
         if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
         if (s1 ? (t0->C != C0 || t0->C + t1->C != w.Cin) : t0->C != w.Cin) return false;
-        static const bool pf_t = dev_env("CDC_PF_TRANSPOSED") != nullptr;   // measured slower than the phase-folded split kernel
-        const bool k3 = w.KH == 3 && w.KW == 3 && !w.transposed, k1 = w.KH == 1 && w.KW == 1, k2 = w.transposed && w.tk == 4 && pf_t;
+        // transposed 4x4: the four 2x2 phases fused in one workgroup (TZ = 4); CDC_PF_TRANSPOSED=1 selects the older
+        // phase-per-workgroup form (measured slower than the phase-folded split kernel)
+        static const bool pf_t = dev_env("CDC_PF_TRANSPOSED") != nullptr;
+        const bool k3 = w.KH == 3 && w.KW == 3 && !w.transposed, k1 = w.KH == 1 && w.KW == 1, k2 = w.transposed && w.tk == 4 && !s1;
         if (!(k3 || k1 || k2)) return false;
         if (!w.transposed && ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2)) return false;
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = w.KH; ps.KW = w.KW; ps.nz = w.nz;
         ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = need_all; ps.stride = w.stride;
+        ps.tz = (k2 && !pf_t) ? 4 : 1;
         PfPlan plan;
         if (!pf_make_plan(ps, &plan)) return false;
         Op op;
@@ -867,7 +879,7 @@ struct Builder {
         if (t1) { a.src1 = t1->p; a.src1_bs = t1->bs(); }
         a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.W = W;
         a.w = w.wsh; a.w_zs = w.wsp_zs / 8;            // planes of 8 halfs = one unit
-        a.KH = w.KH; a.KW = w.KW; a.nz = w.nz; a.stride = w.stride;
+        a.KH = w.KH; a.KW = w.KW; a.nz = w.nz; a.stride = w.stride; a.tz = ps.tz;
         a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout;
         a.acc_scale = w.wscale_inv;
         a.out = o.no_f32 ? nullptr : out; a.out_bs = out_bs;
@@ -1522,7 +1534,11 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         x = bd.resblock(h->rbs[rbi++], x, &skip, false, nullptr, nullptr, Builder::SITE_RB_CHAIN);
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         // (an Upsample reads fp32: planes of its input only with the development switch that runs it on conv_pf_kernel)
-        x = bd.attention(h->attns[ati++], x, sm, sr, dev_env("CDC_PF_TRANSPOSED") ? Builder::SITE_JOIN : Builder::SITE_NONE);
+        // ... or, where the fused-phase plane-operand kernel takes it, planes INSTEAD of fp32 (the Upsample is the only reader)
+        const bool up_planes = bd.pf_tz_would_plan(h->ups[i], x.H, x.W) && !dev_env("CDC_NO_PF_TZ_PLANES");
+        x = bd.attention(h->attns[ati++], x, sm, sr, up_planes ? Builder::SITE_ALWAYS_PLANES : (dev_env("CDC_PF_TRANSPOSED") ? Builder::SITE_JOIN : Builder::SITE_NONE), up_planes);
+        const bool x_planes_only = x.pf != nullptr;
+        const size_t ops_before = h->ops.size();
         const ConvW &uw = h->ups[i];
         Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2, true, Builder::SITE_JOIN);
         Builder::ConvOpts ou;
@@ -1557,6 +1573,11 @@ int build_program(cdc_handle *h, int B, int H, int W) {
                 if (!fsm) { fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl); }
                 bd.ln(y.p, nullptr, y.C, y.H * y.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
             }
+        }
+        if (x_planes_only) {
+            bool on_pf = false;
+            for (size_t q = ops_before; q < h->ops.size(); ++q) on_pf = on_pf || (h->ops[q].kind == Op::CONVPF && !h->ops[q].pw);
+            if (!on_pf) return fail(h, CDC_ERR_UNSUPPORTED, "planes-only Upsample input without a plane-operand kernel");
         }
         x = y;
         if (!final_ln_done && !up_pf_only) h->taps["ups." + std::to_string(i)] = x;   // (the last one may hold LN(up(x)) instead; a planes-only tensor has no fp32 tap)
@@ -3192,6 +3213,11 @@ static int op_conv_transpose2d_impl(cdc_handle *h, const float *x, const float *
     bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, (long long)Cout * 4 * H * W,
             Builder::ConvOpts(), false, PC_UP);
     if (bd.rc) return bd.rc;
+    if (dev_env("CDC_OP_REQUIRE_PF")) {       // test aid, see op_conv2d_impl
+        bool on_pf = false;
+        for (const Op &q : h->ops) on_pf = on_pf || (q.kind == Op::CONVPF && !q.pw);
+        if (!on_pf) return fail(h, CDC_ERR_UNSUPPORTED, "CDC_OP_REQUIRE_PF: the convolution was not planned on conv_pf_kernel");
+    }
     return sc.run(B, y, dy, ny);
 }
 

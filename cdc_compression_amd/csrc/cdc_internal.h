@@ -49,6 +49,7 @@ struct PfShape {
     int Cin, Cout, C0 = 0, KH, KW, nz = 1, Ho, Wo, B;
     bool need_all_cout = false;
     int stride = 1;      // 2: 3x3 / pad 1 Downsample convolution (conv_pf_kernel, STR = 2)
+    int tz = 1;          // 4: 4x4 / stride 2 transposed convolution, its four 2x2 phases fused in one workgroup (conv_pf_kernel, TZ = 4)
 };
 struct PfPlan {
     int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; int lin = 0;

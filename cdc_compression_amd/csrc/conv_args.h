@@ -107,6 +107,7 @@ struct PfArgs {
     long long w_zs;
     int KH, KW, nz;
     int stride;                     // 0 / 1, or 2: conv_pf_kernel<..., STR = 2> (3x3 / pad 1; H, W stay the INPUT extent)
+    int tz;                         // 4: conv_pf_kernel<..., TZ = 4>: the four phases z of a transposed convolution inside one workgroup
     int pad_y[4], pad_x[4];
     int nchunk, COP, Cout;
     float acc_scale;

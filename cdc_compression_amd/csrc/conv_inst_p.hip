@@ -24,7 +24,14 @@ static pf_kernel_fn pf_lookup_s2(int MB, int NPW, int WM, int WP) {
     if (MB == 3 && NPW == 1 && WM == 2 && WP == 4) return conv_pf_kernel<3, 1, 2, 4, 3, 3, 2>;
     return nullptr;
 }
-static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW, int stride = 1) {
+// fused-phase transposed form (TZ = 4): one 32-channel block x two pixel rows per wave, four accumulator sets
+static pf_kernel_fn pf_lookup_tz(int MB, int NPW, int WM, int WP) {
+    if (MB == 1 && NPW == 2 && WM == 2 && WP == 2) return conv_pf_kernel<1, 2, 2, 2, 2, 2, 1, 4>;
+    if (MB == 1 && NPW == 2 && WM == 4 && WP == 2) return conv_pf_kernel<1, 2, 4, 2, 2, 2, 1, 4>;
+    return nullptr;
+}
+static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW, int stride = 1, int tz = 1) {
+    if (tz == 4) return (KH == 2 && KW == 2 && stride != 2) ? pf_lookup_tz(MB, NPW, WM, WP) : nullptr;
     if (stride == 2) return (KH == 3 && KW == 3) ? pf_lookup_s2(MB, NPW, WM, WP) : nullptr;
     if (KH == 3 && KW == 3) return pf_lookup_k<3, 3>(MB, NPW, WM, WP);
     if (KH == 1 && KW == 1) return pf_lookup_k<1, 1>(MB, NPW, WM, WP);
@@ -38,6 +45,10 @@ static const PfCand kCandsS2[] = {
     {2, 2, 2, 2},   // 128 channels, 4 waves, 4 rows
     {3, 1, 2, 4},   // 192 channels, 8 waves, 4 rows
     {2, 1, 1, 4},   //  64 channels, 4 waves, 4 rows
+};
+static const PfCand kCandsTZ[] = {
+    {1, 2, 4, 2},   // 128 channels, 8 waves, 4 input rows
+    {1, 2, 2, 2},   //  64 channels, 4 waves, 4 input rows
 };
 static const PfCand kCands[] = {
     {2, 2, 4, 2},   // 256 channels, 8 waves, 4 rows
@@ -80,6 +91,31 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         }
         return best >= 0;
     }
+    if (s.tz == 4) {
+        // ConvTranspose2d 4x4 / stride 2 / pad 1, the four phases fused in one workgroup (Ho x Wo = the INPUT extent)
+        if (s.KH != 2 || s.KW != 2 || s.C0 || dev_env("CDC_NO_PF_TZ")) return false;
+        for (const PfCand &c : kCandsTZ) {
+            if (f[0] && (c.MB != f[0] || c.NPW != f[1] || c.WM != f[2] || c.WP != f[3])) continue;
+            const int COPT = c.WM * c.MB * 32, TH = c.WP * c.NPW;
+            if (COPT != s.Cout) continue;                       // (a channel LayerNorm may be fused: one group)
+            const int ring = pf_ring(c.MB, c.NPW, c.WM, c.WP, 2, 2, 1, 4);
+            const int tps = pf_tps(c.MB, c.NPW, c.WM, c.WP, 2, 2, 1, 4);
+            const int S = (s.Cin / 16) * 16 / tps;               // weight stages of a tile
+            if (!ring || S < ring - 1) continue;
+            const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B;
+            const double min_wgs = dev_env("CDC_PF_TZ_MIN_WGS") ? atof(dev_env("CDC_PF_TZ_MIN_WGS")) : 256.0;
+            if (wgs < min_wgs) continue;
+            best = COPT;
+            const size_t patch = (size_t)2 * pf_patch_units(c.NPW, c.WP, 2, 2, 1, 4) * 16, wst = (size_t)tps * pf_rows(c.MB, 4 * c.NPW) * COPT * 16;
+            p->MB = c.MB; p->NPW = c.NPW; p->WM = c.WM; p->WP = c.WP;
+            p->ring = ring;
+            p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + TH - 1) / TH;
+            p->groups = 1;
+            p->lds_bytes = std::max(patch + ring * wst, sizeof(float) * (size_t)(4 * COPT + 2 * c.WM * c.WP * 4 * c.NPW * 32));
+            break;
+        }
+        return best >= 0;
+    }
     for (const PfCand &c : kCands) {
         if (f[0] && (c.MB != f[0] || c.NPW != f[1] || c.WM != f[2] || c.WP != f[3])) continue;
         const int COPT = c.WM * c.MB * 32, NW = c.WM * c.WP;
@@ -118,8 +154,9 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
 
 hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     if (p.pf3_epv) return pf3_launch(a, p, B, st);
-    pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW, a.stride == 2 ? 2 : 1);
+    pf_kernel_fn fn = pf_lookup(p.MB, p.NPW, p.WM, p.WP, a.KH, a.KW, a.stride == 2 ? 2 : 1, a.tz == 4 ? 4 : 1);
     if (!fn) return hipErrorInvalidValue;
+    if (a.tz == 4) nz = 1;                                   // the phases are evaluated inside the workgroup
     a.lognbw = 5;
     { static const char *e = dev_env("CDC_PF_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;

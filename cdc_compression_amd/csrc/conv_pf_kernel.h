@@ -55,8 +55,9 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
 // the planes {WH, WL} and a second accumulator set (see mma); the others the three planes {WH, WL, WH2}.
 __host__ __device__ constexpr bool pf_acc2(int MB, int NPW) { return MB * NPW <= 4; }
 __host__ __device__ constexpr int pf_rows(int MB, int NPW) { return pf_acc2(MB, NPW) ? 4 : 6; }
-__host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW, int STR = 1) {
-    return ((4 * ((WP * NPW - 1) * STR + KH) * (31 * STR + KW) + 63) / 64) * 64;
+// (TZ = 4: the four phases of a transposed convolution share the 3x3 neighbourhood patch of their input tile)
+__host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW, int STR = 1, int TZ = 1) {
+    return TZ == 4 ? ((4 * (WP * NPW + 2) * 34 + 63) / 64) * 64 : ((4 * ((WP * NPW - 1) * STR + KH) * (31 * STR + KW) + 63) / 64) * 64;
 }
 // Patch buffers: the patch of chunk c + LA streams in while chunk c is multiplied, LA = buffers - 1.  1x1 layers (one tap per chunk)
 // and stride-2 layers (one workgroup of one wave per SIMD on the CU: nothing else hides the HBM latency of a patch) run two
@@ -67,10 +68,10 @@ __host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW
 __host__ __device__ constexpr int pf_patch_bufs(int KH, int KW, int STR = 1) { return STR == 2 ? CDC_PF_S2_NPB : (KH * KW == 1 ? 3 : 2); }
 // (stride 2: the patch of a 4-row tile is 9 x 65 pixels = 37 KB -- ONE workgroup per CU)
 // tps = taps per weight stage (one s_barrier per stage)
-__host__ __device__ constexpr int pf_ring_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR, int tps) {
+__host__ __device__ constexpr int pf_ring_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR, int tps, int TZ = 1) {
     const size_t budget = (WM * WP == 8 || STR == 2) ? 156 * 1024 : 80 * 1024;
-    const size_t patch = (size_t)pf_patch_bufs(KH, KW, STR) * pf_patch_units(NPW, WP, KH, KW, STR) * 16;
-    const size_t wst = (size_t)tps * pf_rows(MB, NPW) * WM * MB * 32 * 16;
+    const size_t patch = (size_t)pf_patch_bufs(KH, KW, STR) * pf_patch_units(NPW, WP, KH, KW, STR, TZ) * 16;
+    const size_t wst = (size_t)tps * pf_rows(MB, TZ * NPW) * WM * MB * 32 * 16;
 #ifndef CDC_PF_RING_MAX
 #define CDC_PF_RING_MAX 5
 #endif
@@ -83,11 +84,18 @@ __host__ __device__ constexpr int pf_ring_tps(int MB, int NPW, int WM, int WP, i
 #ifndef CDC_PF_S2_TPS
 #define CDC_PF_S2_TPS 3
 #endif
-__host__ __device__ constexpr int pf_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1) {
+#ifndef CDC_PF_TZ_MINB
+#define CDC_PF_TZ_MINB 2     // workgroups per CU the 4-wave fused-phase shape is compiled for (2: 256 registers per lane)
+#endif
+#ifndef CDC_PF_TZ_TPS
+#define CDC_PF_TZ_TPS 2      // fused-phase transposed form: a stage = one kernel row of one phase
+#endif
+__host__ __device__ constexpr int pf_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1, int TZ = 1) {
+    if (TZ == 4) return (CDC_PF_TZ_TPS > 1 && pf_ring_tps(MB, NPW, WM, WP, KH, KW, STR, CDC_PF_TZ_TPS, TZ) >= 3) ? CDC_PF_TZ_TPS : 1;
     return (STR == 2 && CDC_PF_S2_TPS > 1 && pf_ring_tps(MB, NPW, WM, WP, KH, KW, STR, CDC_PF_S2_TPS) >= 3) ? CDC_PF_S2_TPS : 1;
 }
-__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1) {
-    return pf_ring_tps(MB, NPW, WM, WP, KH, KW, STR, pf_tps(MB, NPW, WM, WP, KH, KW, STR));
+__host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1, int TZ = 1) {
+    return pf_ring_tps(MB, NPW, WM, WP, KH, KW, STR, pf_tps(MB, NPW, WM, WP, KH, KW, STR, TZ), TZ);
 }
 #ifndef CDC_PF_ABLATE
 #define CDC_PF_ABLATE 0      // 1: honour PfArgs::dbg (timing experiments with wrong results)
@@ -99,19 +107,26 @@ __host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int K
 // STR = 2 (3x3 / pad 1 Downsample convolutions, network_components.py:51-53): the tile's patch is (2 TH + 1) x 65 pixels; the DMA
 // lanes de-interleave its columns -- even columns first, then the odd ones -- so that the B operand of a tap (pixel 2j + kx of
 // lane j) is again one contiguous run of units: column position kx/2 of the even (kx even) or odd (kx odd) half-row.
-template <int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1>
-__global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 || MB * NPW <= 4) ? 2 : 1)) conv_pf_kernel(const PfArgs P) {
+//
+// TZ = 4 (ConvTranspose2d 4x4 / stride 2 / pad 1 as four 2x2 phase convolutions, network_components.py:34-48, KH = KW = 2): ONE
+// workgroup evaluates all four phases of its input tile from one shared 3x3-neighbourhood patch -- 16 taps per chunk (phase-major),
+// four accumulator sets per wave (block q = phase * NPW + n); one prologue, one patch and one epilogue per 4 x 128 output pixels
+// instead of four of each (the phase-per-workgroup form, gridDim.z = 4, was slower than the register-staged kernel).
+template <int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1, int TZ = 1>
+__global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 || MB * NPW * TZ <= 4 || (TZ == 4 && MB * NPW <= 2 && CDC_PF_TZ_MINB == 2)) ? 2 : 1)) conv_pf_kernel(const PfArgs P) {
     constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
     static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
-    constexpr bool ACC2 = pf_acc2(MB, NPW);
+    static_assert(TZ == 1 || (TZ == 4 && KH == 2 && KW == 2 && STR == 1), "fused phases: the 2x2 phase form of the 4x4 transposed convolution");
+    constexpr int NB = TZ * NPW;                         // accumulator blocks per wave and channel block
+    constexpr bool ACC2 = pf_acc2(MB, NB);
     constexpr int NPL = ACC2 ? 2 : 3, ROWS = 2 * NPL;     // weight planes / rows per stage
     constexpr int WI = ROWS * COPT / 64;                   // DMA instructions per weight stage
     constexpr int NWV = NW - 2;                         // weight waves 0 .. NW-3; patch waves NW-2, NW-1
     constexpr int NWW = (WI + NWV - 1) / NWV;           // DMA instructions per stage and weight wave
-    constexpr int TAPS = KH * KW;
+    constexpr int TAPZ = KH * KW, TAPS = TAPZ * TZ;      // taps per phase / per chunk
     constexpr int NBW = 32, NBH = 1;                    // a 32-pixel block is a row segment (host: lognbw = 5)
     constexpr int TH = WP * NPW * NBH;
-    constexpr int PH = (TH - 1) * STR + KH, PW = (NBW - 1) * STR + KW, PLANE = PH * PW;
+    constexpr int PH = TZ == 4 ? TH + 2 : (TH - 1) * STR + KH, PW = TZ == 4 ? NBW + 2 : (NBW - 1) * STR + KW, PLANE = PH * PW;
     constexpr int NE = (PW + 1) / 2;                    // STR = 2: even patch columns sit at positions [0, NE), odd ones behind
     constexpr int NX = 4 * PLANE;                       // units per chunk
     constexpr int XSW = (NX + 63) / 64;                 // DMA instructions per chunk
@@ -119,8 +134,8 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     constexpr int PST = XSW * 64;                       // units per patch buffer (tail lanes land in the slack)
     // 1x1 layers have one tap per chunk: their patches run two chunks ahead through three buffers
     constexpr int NPB = pf_patch_bufs(KH, KW, STR), LA = NPB - 1;
-    constexpr int TPS = pf_tps(MB, NPW, WM, WP, KH, KW, STR);   // taps per weight stage
-    static_assert(TAPS % TPS == 0, "a weight stage is a whole number of taps of one chunk");
+    constexpr int TPS = pf_tps(MB, NPW, WM, WP, KH, KW, STR, TZ);   // taps per weight stage
+    static_assert(TAPZ % TPS == 0, "a weight stage is a whole number of taps of one chunk (and of one phase)");
     constexpr int SPC = TAPS / TPS;                        // stages per chunk
     constexpr int TAPW = ROWS * COPT;                      // units per tap of a stage
     constexpr int WST = TPS * TAPW;                        // units per weight stage
@@ -142,7 +157,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     const int b = bid / P.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * NBW;
     const int S = P.nchunk * SPC;                          // weight stages of the tile
-    constexpr int R = pf_ring(MB, NPW, WM, WP, KH, KW, STR);   // weight ring slots (host: S >= R - 1)
+    constexpr int R = pf_ring(MB, NPW, WM, WP, KH, KW, STR, TZ);   // weight ring slots (host: S >= R - 1)
     static_assert(R >= 3, "no room for a weight ring");
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) uint4 *)smem_u);
     const unsigned wl_lds = lds0 + (unsigned)(NPB * PST) * 16u;
@@ -190,7 +205,8 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
         wdo[k] = __builtin_amdgcn_readfirstlane((unsigned)jj * 1024u);
     }
     const long long w_dt = (long long)P.nchunk * 6 * P.COP * 16;          // next tap, same chunk
-    const long long w_dc = (long long)6 * P.COP * 16 - (TAPS - TPS) * w_dt;  // first tap of the next chunk (from the chunk's last stage)
+    const long long w_dz = (long long)P.w_zs * 16 - (TAPZ - TPS) * w_dt;     // TZ = 4: first tap of the next phase (from the phase's last stage)
+    const long long w_dc = (long long)6 * P.COP * 16 - (TAPZ - TPS) * w_dt - (TZ - 1) * (long long)P.w_zs * 16;  // first tap of the next chunk (from the chunk's last stage)
     const char *wptr = wsrc;                              // stage to be issued next (its first tap)
     int tw = 0, sw = 0;                                   // its first tap and ring slot
     auto issue_w = [&]() {
@@ -200,15 +216,17 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
 #pragma unroll
             for (int k = 0; k < NWW; ++k) dma16(wvo[k], wptr + q * w_dt, dst + (unsigned)(q * TAPW) * 16u + wdo[k]);
         tw += TPS;
-        if (tw == TAPS) { tw = 0; wptr += w_dc; } else wptr += TPS * w_dt;
+        if (tw == TAPS) { tw = 0; wptr += w_dc; }
+        else if (TZ > 1 && (tw % TAPZ) == 0) wptr += w_dz;
+        else wptr += TPS * w_dt;
         if (++sw == R) sw = 0;
     };
 
-    f32x16 acc[MB][NPW], acc2[ACC2 ? MB : 1][ACC2 ? NPW : 1];
+    f32x16 acc[MB][NB], acc2[ACC2 ? MB : 1][ACC2 ? NB : 1];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < NPW; ++n)
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[m][n][r] = 0.f;
@@ -226,8 +244,11 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     // operands of tap t (compile-time: immediates) from patch buffer xb and ring slot wa
     auto fetch = [&](auto tc, const uint4 *xb, const uint4 *wa, OpsA &A, OpsB &Bv) {
         constexpr int t = decltype(tc)::value;
-        constexpr int kx = t % KW;
-        constexpr int koff = (t / KW) * PW + (STR == 2 ? (kx & 1) * NE + kx / 2 : kx);
+        constexpr int tz = t % TAPZ, ph = t / TAPZ;          // tap inside its phase; phase (py, px) = (ph >> 1, ph & 1)
+        constexpr int kx = tz % KW;
+        // TZ = 4: phase (py, px) reads input rows y - 1 + py + dy, columns x - 1 + px + dx of the shared patch
+        constexpr int koff = TZ == 4 ? (tz / KW + (ph >> 1)) * PW + kx + (ph & 1)
+                                     : (tz / KW) * PW + (STR == 2 ? (kx & 1) * NE + kx / 2 : kx);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -240,20 +261,21 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     // a = h + l' 2^-11, w 2^s = WH + WL:  acc += WL.h + WH.h,  acc2 += WH.l'  (result = acc + acc2 2^-11).  The second
     // accumulator set replaces a third weight plane WH 2^-11: a third fewer A-operand bytes through LDS-DMA, the
     // ring and ds_read (the LDS read rate is the co-limiter of this loop), and no fp16 underflow of small weights.
-    auto mma = [&](const OpsA &A, const OpsB &Bv) {
+    auto mma = [&](const OpsA &A, const OpsB &Bv, auto phc) {     // phc: phase of the tap (TZ = 4), selects the accumulator blocks
+        constexpr int q0 = decltype(phc)::value * NPW;
         if constexpr (ACC2) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < NPW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], Bv[0][n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NPW; ++n) acc[m][q0 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], Bv[0][n], acc[m][q0 + n], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < NPW; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[1][n], acc2[m][n], 0, 0, 0);
+                for (int n = 0; n < NPW; ++n) acc2[m][q0 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[1][n], acc2[m][q0 + n], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < NPW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[0][n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NPW; ++n) acc[m][q0 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], Bv[0][n], acc[m][q0 + n], 0, 0, 0);
         } else {                                          // smallest terms first: WL.h, WH2.l', WH.h
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -263,7 +285,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int n = 0; n < NPW; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term] % NPL][m], Bv[PB[term]][n], acc[m][n], 0, 0, 0);
+                        acc[m][q0 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[term] % NPL][m], Bv[PB[term]][n], acc[m][q0 + n], 0, 0, 0);
             }
         }
     };
@@ -331,7 +353,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
         --rem;
         }
         __builtin_amdgcn_s_setprio(2);
-        if (!(CDC_PF_ABLATE && (P.dbg & 32))) mma(Ac, Bc);
+        if (!(CDC_PF_ABLATE && (P.dbg & 32))) mma(Ac, Bc, std::integral_constant<int, t / TAPZ>{});
         __builtin_amdgcn_s_setprio(0);
     };
     int pbc = 0;                                          // patch buffer of the current chunk
@@ -372,7 +394,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     __builtin_amdgcn_s_barrier();                         // every wave is done with the operand buffers
     if (CDC_PF_ABLATE && (P.dbg & 256)) return;
     float *ep = reinterpret_cast<float *>(smem_u);        // [4][COPT]: bias, ln g, ln b, shift   + reduction scratch
-    float *red = ep + 4 * COPT;                           // [2][WM][WP*NPW*32]
+    float *red = ep + 4 * COPT;                           // [2][WM][WP*NB*32]
     for (int i = tid; i < COPT; i += NT) {
         const int co = cog * COPT + i;
         const bool ok = co < P.Cout;
@@ -386,14 +408,16 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     const int cobase = cog * COPT + wm * MB * 32;         // first channel of this wave
     const float *epl = ep + wm * MB * 32 + 4 * half;
     const bool ch_ok = cobase + MB * 32 <= P.Cout;        // host guarantees Cout % (MB*32) == 0 per wave part
-    float mean_v[NPW], rinv_v[NPW];
-    bool valid_v[NPW];
-    size_t pix_v[NPW];
+    // block n of the wave: pixel row (n % NPW) of its stack, phase n / NPW (TZ = 4; otherwise the workgroup's z)
+    float mean_v[NB], rinv_v[NB];
+    bool valid_v[NB];
+    unsigned pix_v[NB];                                   // offset inside one image's channel plane set (< 2^31: host)
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) {
-        const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+    for (int n = 0; n < NB; ++n) {
+        const int oy = oy0 + (wp * NPW + n % NPW) * NBH + pr, ox = ox0 + pc;
+        const int zn = TZ == 4 ? n / NPW : z;
         valid_v[n] = (oy < P.Ho) && (ox < P.Wo) && ch_ok;
-        pix_v[n] = (size_t)oy * P.out_ys + (size_t)ox * P.out_xs + P.out_zoff[z];
+        pix_v[n] = (unsigned)(oy * P.out_ys + ox * P.out_xs + P.out_zoff[zn]);
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -410,10 +434,10 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     }
     // channel statistics of one pixel: in-lane sum over MB*16 values, lane^32, then across the WM channel parts
     auto chan_stats = [&](float *mean_o, float *rinv_o) {
-        const int slot = (wp * NPW) * 32 + j;             // + n*32
-        float part[NPW];
+        const int slot = (wp * NB) * 32 + j;              // + n*32
+        float part[NB];
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) {
+        for (int n = 0; n < NB; ++n) {
             float sm = 0.f;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -425,19 +449,19 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
         if constexpr (WM > 1) {
             __syncthreads();
 #pragma unroll
-            for (int n = 0; n < NPW; ++n)
-                if (half == 0) red[wm * (WP * NPW * 32) + slot + n * 32] = part[n];
+            for (int n = 0; n < NB; ++n)
+                if (half == 0) red[wm * (WP * NB * 32) + slot + n * 32] = part[n];
             __syncthreads();
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) {
+            for (int n = 0; n < NB; ++n) {
                 float sm = 0.f;
 #pragma unroll
-                for (int q = 0; q < WM; ++q) sm += red[q * (WP * NPW * 32) + slot + n * 32];
+                for (int q = 0; q < WM; ++q) sm += red[q * (WP * NB * 32) + slot + n * 32];
                 part[n] = sm;
             }
         }
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) {
+        for (int n = 0; n < NB; ++n) {
             mean_o[n] = part[n] * inv_c;
             float sq = 0.f;
 #pragma unroll
@@ -448,21 +472,21 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
             part[n] = sq;
         }
         if constexpr (WM > 1) {
-            float *red2 = red + WM * (WP * NPW * 32);
+            float *red2 = red + WM * (WP * NB * 32);
 #pragma unroll
-            for (int n = 0; n < NPW; ++n)
-                if (half == 0) red2[wm * (WP * NPW * 32) + slot + n * 32] = part[n];
+            for (int n = 0; n < NB; ++n)
+                if (half == 0) red2[wm * (WP * NB * 32) + slot + n * 32] = part[n];
             __syncthreads();
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) {
+            for (int n = 0; n < NB; ++n) {
                 float sq = 0.f;
 #pragma unroll
-                for (int q = 0; q < WM; ++q) sq += red2[q * (WP * NPW * 32) + slot + n * 32];
+                for (int q = 0; q < WM; ++q) sq += red2[q * (WP * NB * 32) + slot + n * 32];
                 part[n] = sq;
             }
         }
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) {
+        for (int n = 0; n < NB; ++n) {
             // range guard (ConvArgs::fault): a non-finite accumulator shows in the variance, before LayerNorm + ReLU can hide it
             if (P.fault && !(part[n] < 3.0e38f)) *P.fault = 1;
             rinv_o[n] = 1.0f / sqrtf(part[n] * inv_c + P.eps);
@@ -471,7 +495,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     if (P.ep_g) {
         chan_stats(mean_v, rinv_v);
 #pragma unroll
-        for (int n = 0; n < NPW; ++n)
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -481,7 +505,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
                 }
     } else if (P.fault) {
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) {
+        for (int n = 0; n < NB; ++n) {
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -491,7 +515,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
         }
     }
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) {
+    for (int n = 0; n < NB; ++n) {
         if (P.relu) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -515,8 +539,8 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     if (P.res3_w) {        // res_conv over the 3 image channels of the first ResnetBlock: 3 FMAs per value
         const size_t hw = (size_t)P.Ho * P.Wo;
 #pragma unroll
-        for (int n = 0; n < NPW; ++n) {
-            const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+        for (int n = 0; n < NB; ++n) {
+            const int oy = oy0 + (wp * NPW + n % NPW) * NBH + pr, ox = ox0 + pc;
             const float *xp = P.res3_x + (size_t)b * P.res3_bs + (size_t)oy * P.Wo + ox;
             const float x0 = valid_v[n] ? xp[0] : 0.f, x1 = valid_v[n] ? xp[hw] : 0.f, x2 = valid_v[n] ? xp[2 * hw] : 0.f;
 #pragma unroll
@@ -531,14 +555,65 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     if (P.stat_mean) {
         chan_stats(mean_v, rinv_v);
 #pragma unroll
-        for (int n = 0; n < NPW; ++n)
+        for (int n = 0; n < NB; ++n)
             if (valid_v[n] && half == 0 && wm == 0) {
                 P.stat_mean[(size_t)b * P.out_cs + pix_v[n]] = mean_v[n];
                 P.stat_rstd[(size_t)b * P.out_cs + pix_v[n]] = rinv_v[n];
             }
     }
+    if constexpr (TZ == 4) {
+        // The phases px = 0 / 1 of a lane are horizontally adjacent output pixels (2x, 2x + 1): stored together, a wave writes whole
+        // runs instead of every other element -- fp32 as 8-byte pairs (256-byte runs per channel row), planes as whole 16-byte
+        // units after lanes l and l + 32 (channels 0..3 / 4..7 of a group) have exchanged halves: lane l completes the unit of
+        // pixel 2x, lane l + 32 the unit of pixel 2x + 1 (1-KiB runs).
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) {
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+                const int q0 = (py * 2) * NPW + n, q1 = q0 + NPW;
+                if (!valid_v[q0] || (CDC_PF_ABLATE && (P.dbg & 16))) continue;
+                if (P.out) {
+                    float *op = P.out + (size_t)b * P.out_bs + pix_v[q0] + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            *reinterpret_cast<float2 *>(op + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs) = make_float2(acc[m][q0][r], acc[m][q1][r]);
+                }
+                if (P.out_pf) {
+                    const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+                    const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[py * 2] + half;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            _Float16 h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                split2h(acc[m][q0][g * 4 + i], h0[i], l0[i]);
+                                split2h(acc[m][q1][g * 4 + i], h1[i], l1[i]);
+                            }
+                            const f16x4 hv0 = {h0[0], h0[1], h0[2], h0[3]}, lv0 = {l0[0], l0[1], l0[2], l0[3]};
+                            const f16x4 hv1 = {h1[0], h1[1], h1[2], h1[3]}, lv1 = {l1[0], l1[1], l1[2], l1[3]};
+                            const uint2 a0 = __builtin_bit_cast(uint2, hv0), a1 = __builtin_bit_cast(uint2, hv1);
+                            const uint2 c0 = __builtin_bit_cast(uint2, lv0), c1 = __builtin_bit_cast(uint2, lv1);
+                            // lane l (half 0) keeps its pixel-2x half and receives the partner's; lane l + 32 likewise for pixel 2x + 1
+                            const uint2 sh = half ? a0 : a1, sl = half ? c0 : c1;
+                            uint2 rh, rl;
+                            rh.x = __shfl_xor(sh.x, 32); rh.y = __shfl_xor(sh.y, 32);
+                            rl.x = __shfl_xor(sl.x, 32); rl.y = __shfl_xor(sl.y, 32);
+                            const uint4 uh = half ? make_uint4(rh.x, rh.y, a1.x, a1.y) : make_uint4(a0.x, a0.y, rh.x, rh.y);
+                            const uint4 ul = half ? make_uint4(rl.x, rl.y, c1.x, c1.y) : make_uint4(c0.x, c0.y, rl.x, rl.y);
+                            uint4 *pu = reinterpret_cast<uint4 *>(P.out_pf) + u0 + (long long)((cobase >> 3) + m * 4 + g) * 2 * P.pf_ps;
+                            pu[0] = uh;
+                            pu[P.pf_ps] = ul;
+                        }
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
         if (!valid_v[n] || (CDC_PF_ABLATE && (P.dbg & 16))) continue;
         if (P.out) {
             float *op = P.out + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
@@ -548,8 +623,8 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
                 for (int r = 0; r < 16; ++r) op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
         }
         if (P.out_pf) {
-            const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
-            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[z];
+            const int oy = oy0 + (wp * NPW + n % NPW) * NBH + pr, ox = ox0 + pc;
+            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[TZ == 4 ? n / NPW : z];
 #pragma unroll
             for (int m = 0; m < MB; ++m)
                 pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps, P.pf_ps, half, acc[m][n]);

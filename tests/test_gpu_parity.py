@@ -207,6 +207,29 @@ def test_conv_transpose2d_matches_oracle(O, G, case):
     assert relerr(got, ref) < 1e-5, relerr(got, ref)
 
 
+PF_TZ_CASES = [  # B, Cin, H, W, Cout: ConvTranspose2d 4x4 / stride 2 / pad 1 with its four phases fused on conv_pf_kernel (TZ = 4)
+    (2, 64, 32, 64, 64),     # 64 channels: two channel parts x two row pairs
+    (1, 128, 18, 32, 128),   # 128 channels, eight waves, ragged rows (18 = 4 * 4 + 2)
+    (1, 64, 16, 48, 64),     # ragged columns (48 = 32 + 16)
+    (1, 32, 8, 32, 64),      # two chunks only
+]
+
+
+@pytest.mark.parametrize("case", PF_TZ_CASES)
+def test_conv_transpose2d_fused_phases_on_plane_operands(O, case, monkeypatch):
+    monkeypatch.setenv("CDC_PF", "1")
+    monkeypatch.setenv("CDC_PF_MAXPIX", "0")
+    monkeypatch.setenv("CDC_PF_TZ_MIN_WGS", "1")
+    monkeypatch.setenv("CDC_OP_REQUIRE_PF", "1")
+    B, Ci, H, W, Co = case
+    x = synth.normal("tx", (B, Ci, H, W), 22)
+    w = synth.normal("tw", (Ci, Co, 4, 4), 22, 1.0 / np.sqrt(Ci * 4))
+    b = synth.normal("tb", (Co,), 22, 0.1)
+    ref = O.conv_transpose2d(x, w, b, 2, 1)
+    got = Ops(0).conv_transpose2d(x, w, b)
+    assert relerr(got, ref) < 1e-5, relerr(got, ref)
+
+
 def test_layernorm_matches_oracle(O, G):
     x = synth.normal("lx", (2, 48, 9, 7), 23, 2.0, 0.5)
     g = synth.normal("lg", (48,), 23, 0.2, 1.0)
@@ -276,6 +299,8 @@ def test_unet_forward_matches_reference_golden(name):
                                       ("full_x", {"CDC_PF": "2"}), ("full_x", {"CDC_PF": "0"}), ("full_eps", {"CDC_PF": "2"}),
                                       ("full_x", {"CDC_PF_JOIN_MAXPIX": "65536"}), ("full_x", {"CDC_PF_S2_MIN_WGS": "1"}),
                                       ("full_eps", {"CDC_PF_S2_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_S2": "1"}),
+                                      ("full_x", {"CDC_PF_TZ_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_TZ_MIN_WGS": "1", "CDC_PF_S2_MIN_WGS": "1"}),
+                                      ("full_x", {"CDC_NO_PF_TZ": "1"}),
                                       ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
                                       ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
                                       ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
