@@ -837,6 +837,16 @@ struct Builder {
         return pf_make_plan(ps, &plan);
     }
 
+    // Would the row-folded final convolution (1x7) run on conv_pf_kernel given a PF input of H x W?
+    bool pf_17_would_plan(const ConvW &w, int H, int W) {
+        if (!pf_on() || !w.wsh || w.KH != 1 || w.KW != 7 || w.stride != 1 || w.transposed || (w.Cin % 16)) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 3) return false;
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = 1; ps.KW = 7; ps.Ho = H; ps.Wo = W; ps.B = pb(); ps.cop = w.COP;
+        PfPlan plan;
+        return pf_make_plan(ps, &plan);
+    }
+
     // Would a single-source 3x3 / 1x1 layer with fused LayerNorm run on conv_pf_kernel (given a PF input)?
     bool pf_would_plan(const ConvW &w, int H, int W) {
         if (!pf_on() || !w.wsh || w.stride != 1 || w.transposed) return false;
@@ -863,12 +873,14 @@ struct Builder {
         // phase-per-workgroup form (measured slower than the phase-folded split kernel)
         static const bool pf_t = dev_env("CDC_PF_TRANSPOSED") != nullptr;
         const bool k3 = w.KH == 3 && w.KW == 3 && !w.transposed, k1 = w.KH == 1 && w.KW == 1, k2 = w.transposed && w.tk == 4 && !s1;
-        if (!(k3 || k1 || k2)) return false;
+        const bool k17 = w.KH == 1 && w.KW == 7 && !w.transposed && w.stride == 1 && !s1 && !o.ln_g && !o.emit_pf;   // row-folded final convolution
+        if (!(k3 || k1 || k2 || k17)) return false;
         if (!w.transposed && ((w.pad_y >= 0 ? w.pad_y : w.pad) != w.KH / 2 || (w.pad_x >= 0 ? w.pad_x : w.pad) != w.KW / 2)) return false;
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = w.KH; ps.KW = w.KW; ps.nz = w.nz;
         ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = need_all; ps.stride = w.stride;
         ps.tz = (k2 && !pf_t) ? 4 : 1;
+        ps.cop = w.COP;
         PfPlan plan;
         if (!pf_make_plan(ps, &plan)) return false;
         Op op;
@@ -1540,9 +1552,13 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         const bool x_planes_only = x.pf != nullptr;
         const size_t ops_before = h->ops.size();
         const ConvW &uw = h->ups[i];
-        Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2, true, Builder::SITE_JOIN);
+        // the last Upsample feeds the final convolution only: planes INSTEAD of fp32 when that runs on the plane-operand kernel
+        // (which needs the final LayerNorm applied here, in this epilogue)
+        const bool fin_planes = i == n - 2 && !dev_env("CDC_NO_FINAL_LN_FUSE") && !dev_env("CDC_NO_PF_17_PLANES") &&
+                                bd.pf_17_would_plan(h->fin_conv, x.H * 2, x.W * 2);
+        Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2, true, fin_planes ? Builder::SITE_ALWAYS_PLANES : Builder::SITE_JOIN);
         Builder::ConvOpts ou;
-        ou.emit_pf = i < n - 2;              // (the last Upsample feeds the final convolution only)
+        ou.emit_pf = i < n - 2;
         // the next level's join is this tensor's only reader: planes INSTEAD of fp32 when block1 and res_conv both take planes
         if (i < n - 2 && !skips.empty())
             ou.no_f32 = bd.join_reads_planes(h->rbs[rbi], y.p, y.C, skips.back().p, y.H, y.W);
@@ -1556,8 +1572,10 @@ int build_program(cdc_handle *h, int B, int H, int W) {
             if (!dev_env("CDC_NO_FINAL_LN_FUSE")) {
                 Builder::ConvOpts ol;
                 ol.ln_g = h->fin_g; ol.ln_b = h->fin_b;
+                ol.emit_pf = ol.no_f32 = fin_planes;
                 done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ol, true, PC_UP);
                 final_ln_done = done;
+                if (done && bd.last_pf_only) { Builder::PfTwin *ty = bd.twin(y.p); y.pf = ty->p; y.pf_bs = ty->bs(); }
             }
             if (!done) {
                 fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl);
@@ -1598,6 +1616,8 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     of.no_bias = true;
     bd.conv(h->fin_conv, x.p, x.C, x.bs(), nullptr, 0, H, W, h->fin_P, (long long)h->out_dim * KHf * H * W,
             of, false, PC_CONV7);
+    if (x.pf && !bd.rc && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
+        return fail(h, CDC_ERR_UNSUPPORTED, "planes-only final-convolution input without a plane-operand kernel");
     Op cb; cb.kind = Op::COMBINE; cb.prof = PC_SMALL;
     cb.cb = {h->fin_P, h->fin_bias, h->out_fx, h->out_dim, KHf, 3, H, W};
     cb.bytes = 4.0 * B * h->out_dim * (KHf + 1) * H * W;

@@ -36,6 +36,7 @@ static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW, i
     if (KH == 3 && KW == 3) return pf_lookup_k<3, 3>(MB, NPW, WM, WP);
     if (KH == 1 && KW == 1) return pf_lookup_k<1, 1>(MB, NPW, WM, WP);
     if (KH == 2 && KW == 2) return pf_lookup_k<2, 2>(MB, NPW, WM, WP);
+    if (KH == 1 && KW == 7 && MB == 1 && NPW == 2 && WM == 1 && WP == 4) return conv_pf_kernel<1, 2, 1, 4, 1, 7>;   // row-folded final convolution
     return nullptr;
 }
 
@@ -59,6 +60,21 @@ static const PfCand kCands[] = {
 };
 
 bool pf_make_plan(const PfShape &s, PfPlan *p) {
+    if (s.KH == 1 && s.KW == 7) {
+        // the row-folded final convolution (unet.py:104: 7x7 to out_dim channels as 1x7 to 7 * out_dim <= 32 virtual channels):
+        // one 32-channel block, 8-row tiles, three workgroups per CU; plain fp32 output with masked channel stores
+        if (s.Cout > 32 || s.cop != 32 || s.Cin % 16 || s.C0 || s.nz != 1 || s.stride != 1 || s.tz != 1 || s.need_all_cout || s.Wo < 32 ||
+            dev_env("CDC_NO_PF_17"))
+            return false;
+        const int ring = pf_ring(1, 2, 1, 4, 1, 7);
+        const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + 7) / 8) * s.B;
+        const double min_wgs = dev_env("CDC_PF_17_MIN_WGS") ? atof(dev_env("CDC_PF_17_MIN_WGS")) : 768.0;
+        if (!ring || (s.Cin / 16) * 7 < ring - 1 || wgs < min_wgs) return false;
+        p->MB = 1; p->NPW = 2; p->WM = 1; p->WP = 4; p->ring = ring;
+        p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + 7) / 8; p->groups = 1;
+        p->lds_bytes = (size_t)2 * pf_patch_units(2, 4, 1, 7) * 16 + (size_t)ring * pf_rows(1, 2) * 32 * 16;
+        return true;
+    }
     if (s.Cout % 32 || s.Cin % 16 || (s.C0 % 16)) return false;
     if (s.Wo < 32) return false;                              // 32-pixel blocks are rows of the image (lognbw = 5)
     static const char *force = dev_env("CDC_PF_PLAN");         // tuning aid: "MB,NPW,WM,WP"

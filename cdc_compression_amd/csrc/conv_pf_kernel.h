@@ -113,14 +113,16 @@ __host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int K
 // four accumulator sets per wave (block q = phase * NPW + n); one prologue, one patch and one epilogue per 4 x 128 output pixels
 // instead of four of each (the phase-per-workgroup form, gridDim.z = 4, was slower than the register-staged kernel).
 template <int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1, int TZ = 1>
-__global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 || MB * NPW * TZ <= 4 || (TZ == 4 && MB * NPW <= 2 && CDC_PF_TZ_MINB == 2)) ? 2 : 1)) conv_pf_kernel(const PfArgs P) {
+__global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR == 2 ? 1 : ((WM * WP == 8 || MB * NPW * TZ <= 4 || (TZ == 4 && MB * NPW <= 2 && CDC_PF_TZ_MINB == 2)) ? 2 : 1)) conv_pf_kernel(const PfArgs P) {
     constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
-    static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
+    // (COPT = 32: the row-folded final convolution, 21 of 32 channels real -- host: COP == 32, so the rows of a stage are contiguous
+    //  in the source as well and an instruction simply covers two of them)
+    static_assert(COPT % 64 == 0 || COPT == 32, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
     static_assert(TZ == 1 || (TZ == 4 && KH == 2 && KW == 2 && STR == 1), "fused phases: the 2x2 phase form of the 4x4 transposed convolution");
     constexpr int NB = TZ * NPW;                         // accumulator blocks per wave and channel block
     constexpr bool ACC2 = pf_acc2(MB, NB);
     constexpr int NPL = ACC2 ? 2 : 3, ROWS = 2 * NPL;     // weight planes / rows per stage
-    constexpr int WI = ROWS * COPT / 64;                   // DMA instructions per weight stage
+    constexpr int WI = (ROWS * COPT + 63) / 64;            // DMA instructions per weight stage
     constexpr int NWV = NW - 2;                         // weight waves 0 .. NW-3; patch waves NW-2, NW-1
     constexpr int NWW = (WI + NWV - 1) / NWV;           // DMA instructions per stage and weight wave
     constexpr int TAPZ = KH * KW, TAPS = TAPZ * TZ;      // taps per phase / per chunk
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     const char *s1 = P.src1 ? reinterpret_cast<const char *>(P.src1) + (size_t)b * P.src1_bs * 16 : nullptr;
     const int c0_chunks = P.C0 >> 4;
     // patch instruction i of this wave is issued at tap `i / PER` of the previous chunk (PER per tap, early taps)
-    constexpr int ISSUE_TAPS = TAPS >= 9 ? 6 : (TAPS >= 4 ? 2 : 1);
+    constexpr int ISSUE_TAPS = TAPS >= 9 ? 6 : (TAPS == 7 ? 5 : (TAPS >= 4 ? 2 : 1));
     constexpr int PER = (KX + ISSUE_TAPS - 1) / ISSUE_TAPS;
     auto issue_patch = [&](int chunk, auto tc) {          // instructions scheduled at tap tc of the chunk before
         constexpr int t = decltype(tc)::value;
@@ -200,8 +202,12 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
 #pragma unroll
     for (int k = 0; k < NWW; ++k) {
         const int jj = min(wave + k * NWV, WI - 1);       // clamped duplicates are harmless
-        const int row = jj / (COPT / 64), seg = jj - row * (COPT / 64);
-        wvo[k] = (unsigned)(row * P.COP + seg * 64 + lane) * 16u;
+        if constexpr (COPT == 32) {
+            wvo[k] = (unsigned)(jj * 64 + lane) * 16u;
+        } else {
+            const int row = jj / (COPT / 64), seg = jj - row * (COPT / 64);
+            wvo[k] = (unsigned)(row * P.COP + seg * 64 + lane) * 16u;
+        }
         wdo[k] = __builtin_amdgcn_readfirstlane((unsigned)jj * 1024u);
     }
     const long long w_dt = (long long)P.nchunk * 6 * P.COP * 16;          // next tap, same chunk
@@ -407,7 +413,10 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
     const float inv_c = 1.0f / (float)P.Cout;
     const int cobase = cog * COPT + wm * MB * 32;         // first channel of this wave
     const float *epl = ep + wm * MB * 32 + 4 * half;
-    const bool ch_ok = cobase + MB * 32 <= P.Cout;        // host guarantees Cout % (MB*32) == 0 per wave part
+    // host guarantees Cout % (MB*32) == 0 per wave part -- except for the COPT = 32 shape (plain fp32 output only), whose
+    // stores are masked per channel
+    const bool ch_ok = cobase + MB * 32 <= P.Cout || COPT == 32;
+    const int nvalid = P.Cout - cobase;
     // block n of the wave: pixel row (n % NPW) of its stack, phase n / NPW (TZ = 4; otherwise the workgroup's z)
     float mean_v[NB], rinv_v[NB];
     bool valid_v[NB];
@@ -620,7 +629,10 @@ __global__ void __launch_bounds__(64 * WM * WP, STR == 2 ? 1 : ((WM * WP == 8 ||
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) op[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs] = acc[m][n][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (COPT != 32 || ci + 4 * half < nvalid) op[(size_t)ci * P.out_cs] = acc[m][n][r];
+                }
         }
         if (P.out_pf) {
             const int oy = oy0 + (wp * NPW + n % NPW) * NBH + pr, ox = ox0 + pc;

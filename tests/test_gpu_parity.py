@@ -301,6 +301,8 @@ def test_unet_forward_matches_reference_golden(name):
                                       ("full_eps", {"CDC_PF_S2_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_S2": "1"}),
                                       ("full_x", {"CDC_PF_TZ_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_TZ_MIN_WGS": "1", "CDC_PF_S2_MIN_WGS": "1"}),
                                       ("full_x", {"CDC_NO_PF_TZ": "1"}),
+                                      ("full_x", {"CDC_PF_17_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_17_MIN_WGS": "1", "CDC_PF_TZ_MIN_WGS": "1"}),
+                                      ("small_x", {"CDC_PF_17_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_17": "1"}),
                                       ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
                                       ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
                                       ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
