@@ -14,6 +14,7 @@ static pf_kernel_fn pf_lookup_k(int MB, int NPW, int WM, int WP) {
     if (MB == 2 && NPW == 2 && WM == 2 && WP == 2) return conv_pf_kernel<2, 2, 2, 2, KH, KW>;
     if (MB == 2 && NPW == 2 && WM == 2 && WP == 4) return conv_pf_kernel<2, 2, 2, 4, KH, KW>;
     if (MB == 3 && NPW == 2 && WM == 2 && WP == 4) return conv_pf_kernel<3, 2, 2, 4, KH, KW>;
+    if (MB == 3 && NPW == 1 && WM == 2 && WP == 4 && KH == 3) return conv_pf_kernel<3, 1, 2, 4, KH, KW>;
     if (MB == 2 && NPW == 2 && WM == 4 && WP == 2) return conv_pf_kernel<2, 2, 4, 2, KH, KW>;
     return nullptr;
 }
@@ -54,6 +55,7 @@ static const PfCand kCandsTZ[] = {
 static const PfCand kCands[] = {
     {2, 2, 4, 2},   // 256 channels, 8 waves, 4 rows
     {3, 2, 2, 4},   // 192 channels, 8 waves, 8 rows
+    {3, 1, 2, 4},   // 192 channels, 8 waves, 4 rows: twice the workgroups where 8-row tiles leave half the CUs idle (32 x 32 maps at batch 32)
     {2, 2, 2, 2},   // 128 channels, 4 waves, 4 rows
     {2, 2, 2, 4},   // 128 channels, 8 waves, 8 rows
     {2, 2, 1, 4},   //  64 channels, 4 waves, 8 rows
