@@ -16,6 +16,9 @@ template <int MB, int NPW, int WM, int WP> static pf_kernel_fn pf3_lookup_shape(
     case 7: return conv_pf3_kernel<MB, NPW, WM, WP, 7, true>;
     case 11: return conv_pf3_kernel<MB, NPW, WM, WP, 11, true>;      // + LayerNorm statistics of the result
     case 15: return conv_pf3_kernel<MB, NPW, WM, WP, 15, true>;
+    case 37:                                                          // kPf3Pre: hoisted partial sums before the LayerNorm, planes out (128-channel shape)
+        if constexpr (WM == 2) return conv_pf3_kernel<MB, NPW, WM, WP, 37, true>;
+        else return nullptr;
     case 23:                                                          // + the 3-channel res_conv of the first ResnetBlock (64-channel shape)
         if constexpr (WM == 1) return conv_pf3_kernel<MB, NPW, WM, WP, 23, true>;
         else return nullptr;

@@ -50,7 +50,9 @@ namespace cdc {
 #define CDC_PF3_D 5          // weight stages are issued D steps ahead; ring = D + 2 slots (a slot is rewritten two steps after its last reader)
 #endif
 
-constexpr int kPf3Resid = 1, kPf3F32 = 2, kPf3Pf = 4, kPf3Stat = 8, kPf3Res3 = 16;     // EPV: which vector-memory operations the epilogue issues
+constexpr int kPf3Resid = 1, kPf3F32 = 2, kPf3Pf = 4, kPf3Stat = 8, kPf3Res3 = 16, kPf3Pre = 32;     // EPV: which vector-memory operations the epilogue issues
+// (kPf3Pre, with kPf3Resid: the "residual" operand is a hoisted partial sum (ConvArgs::pre_add, the step-invariant context half of a
+//  concatenated input): same loads, but added to the accumulators BEFORE the LayerNorm)
 // (kPf3Res3: the 3-channel res_conv of the first ResnetBlock in the epilogue, conv_args.h: res3_w / res3_x; 64-channel shape only)
 
 __host__ __device__ constexpr int pf3_xsw(int NPW, int WP) { return (4 * (WP * NPW + 2) * 34 + 63) / 64; }
@@ -153,6 +155,8 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
     static_assert(WM * WP == 4, "a group is four waves");
     static_assert(MB * NPW <= 4, "two accumulator sets per wave tile");
     constexpr bool RESID = (EPV & kPf3Resid) != 0, F32 = (EPV & kPf3F32) != 0, PF = (EPV & kPf3Pf) != 0, STAT = (EPV & kPf3Stat) != 0;
+    constexpr bool PRE = (EPV & kPf3Pre) != 0;          // the loaded rows are partial sums that enter before the LayerNorm
+    static_assert(!PRE || (RESID && SYNC), "kPf3Pre rides on the residual loads of the free-running epilogue");
     constexpr bool RES3 = (EPV & kPf3Res3) != 0;
     static_assert(!STAT || SYNC, "LayerNorm statistics of the result: free-running epilogue only");
     static_assert(!RES3 || (SYNC && WM == 1 && NPW == 2), "epilogue res_conv: free-running epilogue, 64-channel shape");
@@ -567,7 +571,7 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             auto fin_pf = [&](auto qc) {                  // + residual; PF planes of block q
                 constexpr int q = decltype(qc)::value, n = q / MB, m = q % MB;
                 if constexpr (q < NBLK) {
-                    if constexpr (RESID) {
+                    if constexpr (RESID && !PRE) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][n][r] += rv[q & 1][r];
                     }
@@ -654,16 +658,26 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                 ldT(Q0{}); ldT(Q1{}); ldT(Q2{}); ldT(Q3{});   // (both groups are here in the same interval: the counts match)
                 ldX();
                 merge();
+                if constexpr (PRE) {                    // hoisted partial sums: into the accumulators (which are in units of acc_scale) first
+                    pf3_wait_rows<0>(rvT);
+                    const float inv_scale = 1.0f / acc_scale;
+                    static_for<NBLK>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value, n = q / MB, m = q % MB;
+                        wT_rN(qc);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = __builtin_fmaf(rv[q & 1][r], inv_scale, acc[m][n][r]);
+                    });
+                }
                 sums();
                 if constexpr (WM > 1) bar();
                 devs(Q0{}); devs(Q1{});
                 if constexpr (WM > 1) bar();
-                if constexpr (RESID) pf3_wait_rows<0>(rvT);
-                wT_rN(Q0{}); wT_rN(Q1{});
+                if constexpr (RESID && !PRE) pf3_wait_rows<0>(rvT);
+                if constexpr (!PRE) { wT_rN(Q0{}); wT_rN(Q1{}); }
                 norm(Q0{}); norm(Q1{});
                 fin_pf(Q0{}); fin_pf(Q1{});
                 wN_rT_st(Q0{}); wN_rT_st(Q1{});
-                wT_rN(Q2{}); wT_rN(Q3{});
+                if constexpr (!PRE) { wT_rN(Q2{}); wT_rN(Q3{}); }
                 norm(Q2{}); norm(Q3{});
                 fin_pf(Q2{}); fin_pf(Q3{});
                 wN_rT_st(Q2{}); wN_rT_st(Q3{});
