@@ -147,6 +147,9 @@ struct PfArgs {
     int dbg;                        // CDC_PF_DBG (timing experiments, wrong results): 1 no weight DMA in the loop, 2 no patch
                                     // DMA in the loop, 4 no barrier in the loop, 8 no DMA waits, 16 no epilogue stores
     int *fault;                     // range guard: set to 1 when an accumulator is inf / NaN (see ConvArgs::fault; may be null)
+#ifdef CDC_TIMELINE
+    unsigned long long *tl;         // tools/build_variant.sh timeline -DCDC_TIMELINE: 16 values per workgroup (conv_pf_kernel)
+#endif
 };
 
 constexpr int kPfXS = 12;   // patch DMA instructions per chunk and patch wave (two patch waves: <= 24 per chunk)

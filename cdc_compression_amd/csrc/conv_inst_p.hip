@@ -1,6 +1,9 @@
 // conv_inst_p.hip -- instantiations, launch-plan chooser and launcher of conv_pf_kernel (pre-split fp16 operands
 // by LDS-DMA), plus the fp32 NCHW -> PF packing kernel for tensors whose producer does not emit planes.
 #include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
 #include <stdlib.h>
 
 #include "cdc_internal.h"
@@ -184,7 +187,50 @@ hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
     a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+#ifdef CDC_TIMELINE
+    // Development build only (tools/build_variant.sh timeline -DCDC_TIMELINE): per-workgroup cycle categories of conv_pf_kernel, start /
+    // end stamps and the CU each workgroup ran on, summarised on stderr for the first launches of every layer shape.
+    static unsigned long long *tl_dev = nullptr;
+    static std::map<std::string, int> seen;
+    const size_t tl_wgs = (size_t)grid.x * grid.y * grid.z;
+    char key[96];
+    snprintf(key, sizeof key, "%dx%d s%d tz%d %d->%d out %dx%d", a.KH, a.KW, a.stride == 2 ? 2 : 1, a.tz == 4 ? 4 : 1, a.Cin, a.Cout, a.Ho, a.Wo);
+    a.tl = nullptr;
+    if (tl_wgs <= (1u << 18) && seen[key]++ < 3) {
+        if (!tl_dev) hipMalloc(&tl_dev, sizeof(unsigned long long) * 16 * (1u << 18));
+        hipMemsetAsync(tl_dev, 0, sizeof(unsigned long long) * 16 * tl_wgs, st);
+        a.tl = tl_dev;
+    }
+#endif
     hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
+#ifdef CDC_TIMELINE
+    if (a.tl) {
+        hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(16 * tl_wgs);
+        hipMemcpy(h.data(), tl_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double cat[7] = {0}, life = 0;
+        std::map<unsigned long long, int> per_cu;
+        std::vector<unsigned long long> starts;
+        for (size_t w = 0; w < tl_wgs; ++w) {
+            const unsigned long long *r = &h[w * 16];
+            for (int c = 0; c < 7; ++c) cat[c] += (double)r[c];
+            t0 = std::min(t0, r[7]); t1 = std::max(t1, r[8]);
+            life += (double)(r[8] - r[7]);
+            per_cu[(r[10] & 0xf) << 32 | (r[9] & 0xffff00)]++;      // XCC id, SE / SH / CU bits of HW_ID
+            starts.push_back(r[7]);
+        }
+        std::sort(starts.begin(), starts.end());
+        int cu_min = 1 << 30, cu_max = 0;
+        for (auto &kv : per_cu) { cu_min = std::min(cu_min, kv.second); cu_max = std::max(cu_max, kv.second); }
+        static const char *names[7] = {"setup", "prologue issue", "prologue wait", "main loop", "epilogue parameters", "epilogue arithmetic", "epilogue stores"};
+        fprintf(stderr, "[pf timeline] conv %s: %zu workgroups x %d threads, lds %zu; kernel span %llu cycles, mean workgroup life %.0f; %zu CUs used, %d .. %d workgroups per CU;"
+                        " start of the median / last workgroup at %llu / %llu; per workgroup (wave 0):", key, tl_wgs, 64 * p.WM * p.WP, p.lds_bytes, t1 - t0, life / tl_wgs,
+                per_cu.size(), cu_min, cu_max, starts[starts.size() / 2] - t0, starts.back() - t0);
+        for (int c = 0; c < 7; ++c) fprintf(stderr, "  %s %.0f", names[c], cat[c] / tl_wgs);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 

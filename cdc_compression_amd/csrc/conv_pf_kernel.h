@@ -144,6 +144,20 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     static_assert(KX <= (STR == 2 ? 20 : kPfXS), "patch too large for two patch waves");
     static_assert(STR == 1 || (STR == 2 && KH == 3 && KW == 3), "stride 2 is the 3x3 Downsample form");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+#ifdef CDC_TIMELINE
+    // development build: cycles of wave 0 per category -- 0 setup (tile decode, DMA offsets), 1 prologue DMA issue, 2 prologue wait +
+    // barrier, 3 main loop, 4 epilogue parameters (loads + barrier), 5 epilogue arithmetic, 6 epilogue stores; 7 / 8 start / end stamp
+    unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_readcyclecounter();
+    const unsigned long long tl_start = tl_last;
+#define PFTL(c) do { const unsigned long long n_ = __builtin_readcyclecounter(); tl_acc[c] += n_ - tl_last; tl_last = n_; } while (0)
+#define PFTL_END() do { if (P.tl && threadIdx.x == 0) { unsigned long long *r_ = P.tl + 16 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)); \
+        for (int c_ = 0; c_ < 7; ++c_) r_[c_] = tl_acc[c_]; r_[7] = tl_start; r_[8] = __builtin_readcyclecounter(); \
+        unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); r_[9] = hw_; \
+        unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); r_[10] = xcc_; } } while (0)
+#else
+#define PFTL(c) do { } while (0)
+#define PFTL_END() do { } while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WP, wp = wave % WP;
@@ -297,13 +311,16 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     };
 
     // ---- prologue: patches of the first LA chunks, weight stages 0 .. R-2 -------------------------------------
+    PFTL(0);
     if (patch_wave) {
         for (int c = 0; c < LA && c < P.nchunk; ++c) issue_patch(c, std::integral_constant<int, -1>{});
     } else {
         for (int q = 0; q < R - 1 && q < S; ++q) issue_w();
     }
+    PFTL(1);
     dma_wait();
     __builtin_amdgcn_s_barrier();
+    PFTL(2);
     OpsA A0, A1;
     OpsB B0, B1;
     fetch(std::integral_constant<int, 0>{}, b_base, a_base, A0, B0);
@@ -398,7 +415,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_barrier();                         // every wave is done with the operand buffers
-    if (CDC_PF_ABLATE && (P.dbg & 256)) return;
+    PFTL(3);
+    if (CDC_PF_ABLATE && (P.dbg & 256)) { PFTL_END(); return; }
     float *ep = reinterpret_cast<float *>(smem_u);        // [4][COPT]: bias, ln g, ln b, shift   + reduction scratch
     float *red = ep + 4 * COPT;                           // [2][WM][WP*NB*32]
     for (int i = tid; i < COPT; i += NT) {
@@ -410,6 +428,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
         ep[3 * COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
     }
     __syncthreads();
+    PFTL(4);
     const float inv_c = 1.0f / (float)P.Cout;
     const int cobase = cog * COPT + wm * MB * 32;         // first channel of this wave
     const float *epl = ep + wm * MB * 32 + 4 * half;
@@ -570,6 +589,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                 P.stat_rstd[(size_t)b * P.out_cs + pix_v[n]] = rinv_v[n];
             }
     }
+    PFTL(5);
     if constexpr (TZ == 4) {
         // The phases px = 0 / 1 of a lane are horizontally adjacent output pixels (2x, 2x + 1): stored together, a wave writes whole
         // runs instead of every other element -- fp32 as 8-byte pairs (256-byte runs per channel row), planes as whole 16-byte
@@ -619,6 +639,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                         }
                 }
             }
+        PFTL(6);
+        PFTL_END();
         return;
     }
 #pragma unroll
@@ -642,6 +664,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                 pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps, P.pf_ps, half, acc[m][n]);
         }
     }
+    PFTL(6);
+    PFTL_END();
 }
 
 typedef void (*pf_kernel_fn)(const PfArgs);
