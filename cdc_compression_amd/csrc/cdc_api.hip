@@ -666,7 +666,7 @@ struct Builder {
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WM%d WP%d g%d R%d %s%s%s%s%s%s", op.pf.KH, op.pf.KW,
                      op.pf.stride == 2 ? 2 : 1, op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
                      op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
-                     op.pf.resid ? " +res" : "", cur == &h->pre_ops ? " HOIST" : "", op.pf.tz == 4 ? " TZ4" : "");
+                     op.pf.resid ? " +res" : (op.pf.resid_pf ? " +resP" : ""), cur == &h->pre_ops ? " HOIST" : "", op.pf.tz == 4 ? " TZ4" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -711,6 +711,7 @@ struct Builder {
     // ---- PF twins: a second copy of an activation as two fp16 planes with a zero halo (conv_pf_kernel.h),
     // keyed by the fp32 tensor's address; `valid` once a producer of this program has emitted it.
     struct PfTwin { void *p = nullptr; int C = 0, H = 0, W = 0; bool valid = false;
+                    bool only = false;          // the planes are the ONLY copy: the producer wrote no fp32 (readers must take planes)
                     long long ps() const { return (long long)(H + 2) * (W + 2); }
                     long long bs() const { return (long long)(C / 8) * 2 * ps(); } };
     std::map<const float *, PfTwin> pfmap;
@@ -926,6 +927,16 @@ struct Builder {
         a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu; a.relu_slope = o.relu_slope;
         a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
+        if (PfTwin *tr = o.resid ? twin(o.resid) : nullptr)
+            if (tr->only) {     // the residual exists as planes only (a ResnetBlock-chain output): read it from there
+                if (!tr->valid || tr->C != w.Cout || tr->H != s.Ho || tr->W != s.Wo || w.transposed || w.stride != 1 ||
+                    o.resid_bs != (long long)w.Cout * s.Ho * s.Wo || o.resid_cs != (long long)s.Ho * s.Wo) {
+                    rc = fail(h, CDC_ERR_UNSUPPORTED, "planes-only residual of a shape the plane-operand kernels do not read");
+                    return true;
+                }
+                a.resid = nullptr;
+                a.resid_pf = tr->p; a.rpf_bs = tr->bs(); a.rpf_ps = tr->ps(); a.rpf_ys = s.Wo + 2; a.rpf_zoff = (s.Wo + 2) + 1;
+            }
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
         a.fault = fault_flag();
@@ -1032,6 +1043,9 @@ struct Builder {
         s.B = pb(); s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
         if (!o.uf_c && try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
+        for (const float *q : {s0, s1, o.resid})
+            if (PfTwin *tq = q ? twin(q) : nullptr)
+                if (tq->only && !rc) { rc = fail(h, CDC_ERR_UNSUPPORTED, "a planes-only tensor reached a kernel that reads fp32"); return true; }
         if (!o.uf_c && try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
@@ -1248,8 +1262,15 @@ struct Builder {
     // ResnetBlock.forward (network_components.py:107-114).  a1 = second concat source.  If
     // `a1_is_context` the block was packed with split weights: the context halves are evaluated into
     // h->pre_ops (once per decode) and enter the per-step convolutions as `pre_add`.
+    // Would a ResnetBlock read its input x ONLY as planes -- block1 on a plane-operand kernel, identity residual read from planes in
+    // block2's epilogue (round 4: PfArgs::resid_pf)?  Then the block that produces x writes no fp32 copy (out_planes_only below).
+    bool rb_reads_planes_only(const ResBlockW &rb, int C, int H, int W) {
+        if (!pf_on() || rb.has_res || rb.hoist_cx || rb.cin != C || rb.cout != C || dev_env("CDC_NO_RESID_PF")) return false;
+        return pf_would_plan(rb.c1, H, W) && pf_would_plan(rb.c2, H, W);
+    }
+
     Act resblock(const ResBlockW &rb, Act a0, const Act *a1, bool a1_is_context, float *sm, float *sr,
-                 Site out_site = SITE_ALWAYS) {
+                 Site out_site = SITE_ALWAYS, bool out_planes_only = false) {
         if (rc) return Act();
         const int H = a0.H, W = a0.W, HW = H * W;
         const int prof1 = rb.k == 7 ? PC_CONV7 : PC_CONV3;
@@ -1309,7 +1330,8 @@ struct Builder {
                 res = cat.p; res_bs = cat.bs();
             }
             block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
-                  res_bs, sm, sr, PC_CONV3);
+                  res_bs, sm, sr, PC_CONV3, out_planes_only && twin(out.p));
+            mark_planes_only(out);
             return out;
         }
         const float *s0 = a0.p, *s1 = a1 ? a1->p : nullptr;
@@ -1331,8 +1353,16 @@ struct Builder {
             res = r.p; res_bs = r.bs();
         }
         block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
-              res_bs, sm, sr, PC_CONV3);
+              res_bs, sm, sr, PC_CONV3, out_planes_only && twin(out.p));
+        mark_planes_only(out);
         return out;
+    }
+    // after the block() call that produced `a`: if it wrote planes only, say so on the twin (its readers must take planes) and on the Act
+    void mark_planes_only(Act &a) {
+        if (!last_pf_only) return;
+        PfTwin *t = twin(a.p);
+        t->only = true;
+        a.pf = t->p; a.pf_bs = t->bs();
     }
 
     std::vector<std::pair<const float *, size_t>> dbg_taps;   // debugging aid (CDC_ATTN_TAP)
@@ -1504,7 +1534,10 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
         const bool has_ctx = i < n_ctx;
         const std::string dn = "downs." + std::to_string(i);
-        x = bd.resblock(h->rbs[rbi++], x, has_ctx ? &h->in_ctx[i] : nullptr, true, nullptr, nullptr, Builder::SITE_RB_CHAIN);
+        // (its output goes to the second ResnetBlock only: planes INSTEAD of fp32 where that block reads nothing else)
+        x = bd.resblock(h->rbs[rbi], x, has_ctx ? &h->in_ctx[i] : nullptr, true, nullptr, nullptr, Builder::SITE_RB_CHAIN,
+                        bd.rb_reads_planes_only(h->rbs[rbi + 1], h->rbs[rbi].cout, x.H, x.W));
+        ++rbi;
         h->taps[dn + ".0"] = x;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         h->taps[dn + ".1"] = x;
@@ -1543,7 +1576,9 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         skips.pop_back();
         const int HWl = x.H * x.W;
         float *sm = bd.dalloc((size_t)B * HWl), *sr = bd.dalloc((size_t)B * HWl);
-        x = bd.resblock(h->rbs[rbi++], x, &skip, false, nullptr, nullptr, Builder::SITE_RB_CHAIN);
+        x = bd.resblock(h->rbs[rbi], x, &skip, false, nullptr, nullptr, Builder::SITE_RB_CHAIN,
+                        bd.rb_reads_planes_only(h->rbs[rbi + 1], h->rbs[rbi].cout, x.H, x.W));
+        ++rbi;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         // (an Upsample reads fp32: planes of its input only with the development switch that runs it on conv_pf_kernel)
         // ... or, where the fused-phase plane-operand kernel takes it, planes INSTEAD of fp32 (the Upsample is the only reader)

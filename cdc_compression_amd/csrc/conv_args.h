@@ -134,6 +134,11 @@ struct PfArgs {
     int shift_bs;
     const float *resid;
     long long resid_bs, resid_cs;
+    // the residual as a PF tensor (round 4: a ResnetBlock-chain output that exists as planes only; replaces `resid`):
+    // unit index b*rpf_bs + ((co/8)*2 + plane)*rpf_ps + oy*rpf_ys + ox + rpf_zoff (the zoff includes the +1,+1 halo origin)
+    const void *resid_pf;
+    long long rpf_bs, rpf_ps;
+    int rpf_ys, rpf_zoff;
     float *stat_mean, *stat_rstd;
     const float *res3_w, *res3_x;   // 3-channel res_conv in the epilogue (see ConvArgs)
     long long res3_bs;

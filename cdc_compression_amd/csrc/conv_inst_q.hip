@@ -38,11 +38,12 @@ bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *p) {
     if ((a.Ho % TH) || (a.Wo % 32) || a.Ho != a.H || a.Wo != a.W) return false;
     if ((a.stat_mean != nullptr) != (a.stat_rstd != nullptr)) return false;
     // hoisted partial sums ride on the residual loads (kPf3Pre): not together with a residual
-    if (a.pre_add && (a.resid || a.res3_w || a.stat_mean || !a.ep_g || dev_env("CDC_NO_PF3_PRE"))) return false;
+    if (a.pre_add && (a.resid || a.resid_pf || a.res3_w || a.stat_mean || !a.ep_g || dev_env("CDC_NO_PF3_PRE"))) return false;
+    if (a.resid_pf && (a.resid || a.res3_w || a.rpf_ps * 16 >= (1ll << 31))) return false;
     if (a.res3_w && (!a.res3_x || a.Ho * (long long)a.Wo * 3 >= (1ll << 30))) return false;
     if (a.out_xs != 1 || a.out_ys != a.Wo || a.out_zoff[0] != 0) return false;
     if (a.out_pf && (a.pf_xs != 1)) return false;
-    const int epv = (a.resid ? kPf3Resid : 0) | (a.out ? kPf3F32 : 0) | (a.out_pf ? kPf3Pf : 0) | (a.stat_mean ? kPf3Stat : 0) |
+    const int epv = (a.resid ? kPf3Resid : 0) | (a.resid_pf ? (kPf3Resid | kPf3ResPf) : 0) | (a.out ? kPf3F32 : 0) | (a.out_pf ? kPf3Pf : 0) | (a.stat_mean ? kPf3Stat : 0) |
                     (a.res3_w ? kPf3Res3 : 0) | (a.pre_add ? (kPf3Pre | kPf3Resid) : 0);
     if (!pf3_lookup(COPT, epv)) return false;
     if (COPT == 64 ? pf3_lds_used(2, 2, 1, 4, B) > pf3_lds_bytes() : pf3_lds_used(2, 2, 2, 2, B) > pf3_lds_bytes()) return false;
@@ -68,7 +69,7 @@ hipError_t pf3_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
         a.resid = a.pre_add; a.resid_bs = a.out_bs; a.resid_cs = a.out_cs;
         a.pre_add = nullptr;
     }
-    static bool attr_done[16][2][64];                     // per device: a function attribute belongs to the device's copy of the code
+    static bool attr_done[16][2][128];                     // per device: a function attribute belongs to the device's copy of the code
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_done[dev][COPT == 128][p.pf3_epv]) {

@@ -50,7 +50,9 @@ namespace cdc {
 #define CDC_PF3_D 5          // weight stages are issued D steps ahead; ring = D + 2 slots (a slot is rewritten two steps after its last reader)
 #endif
 
-constexpr int kPf3Resid = 1, kPf3F32 = 2, kPf3Pf = 4, kPf3Stat = 8, kPf3Res3 = 16, kPf3Pre = 32;     // EPV: which vector-memory operations the epilogue issues
+constexpr int kPf3Resid = 1, kPf3F32 = 2, kPf3Pf = 4, kPf3Stat = 8, kPf3Res3 = 16, kPf3Pre = 32, kPf3ResPf = 64;     // EPV: which vector-memory operations the epilogue issues
+// (kPf3ResPf, with kPf3Resid: the residual is read from a PF tensor (PfArgs::resid_pf) -- 8-byte half-units straight in the accumulator
+//  layout, value = h + l' 2^-11: 8 loads per block instead of 4 row loads + an LDS transposition)
 // (kPf3Pre, with kPf3Resid: the "residual" operand is a hoisted partial sum (ConvArgs::pre_add, the step-invariant context half of a
 //  concatenated input): same loads, but added to the accumulators BEFORE the LayerNorm)
 // (kPf3Res3: the 3-channel res_conv of the first ResnetBlock in the epilogue, conv_args.h: res3_w / res3_x; 64-channel shape only)
@@ -78,7 +80,7 @@ __host__ __device__ constexpr Pf3Ops pf3_ops_epi(int nblk, int epv) {
 }
 // SYNC mode: the whole epilogue runs between two slots -- as if it were the B piece of the previous slot's last step
 __host__ __device__ constexpr Pf3Ops pf3_ops_epi_sync(int nblk, int epv) {
-    const int n = 4 * nblk * (((epv & kPf3Resid) ? 1 : 0) + ((epv & kPf3F32) ? 1 : 0) + ((epv & kPf3Pf) ? 2 : 0)) + ((epv & kPf3Stat) ? 4 : 0) +
+    const int n = 4 * nblk * (((epv & kPf3Resid) ? ((epv & kPf3ResPf) ? 2 : 1) : 0) + ((epv & kPf3F32) ? 1 : 0) + ((epv & kPf3Pf) ? 2 : 0)) + ((epv & kPf3Stat) ? 4 : 0) +
                   ((epv & kPf3Res3) ? 6 : 0);
     return Pf3Ops{{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, n}};
 }
@@ -135,6 +137,12 @@ __device__ __forceinline__ void pf3_st4(char *sbase, unsigned voff, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// (a 64-bit scalar, not a 2-vector: one virtual register that hipcc has no reason to take apart -- or copy -- before the data has landed)
+__device__ __forceinline__ unsigned long long pf3_ld2(const char *sbase, unsigned voff) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
 __device__ __forceinline__ void pf3_st2u(char *sbase, unsigned voff, unsigned a, unsigned b) {
     const u32x2 v = {a, b};
     asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
@@ -148,6 +156,15 @@ template <int N, int NB> __device__ __forceinline__ void pf3_wait_rows(f32x4 (&v
     if constexpr (NB > 3) asm volatile("" : "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3]));
 }
 
+// the same for the half-units of a PF residual (kPf3ResPf)
+template <int N, int NB> __device__ __forceinline__ void pf3_wait_units(unsigned long long (&h)[NB][4], unsigned long long (&l)[NB][4]) {
+    static_assert(NB >= 1 && NB <= 4, "blocks per wave tile");
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[0][2]), "+v"(h[0][3]), "+v"(l[0][0]), "+v"(l[0][1]), "+v"(l[0][2]), "+v"(l[0][3]) : "n"(N) : "memory");
+    if constexpr (NB > 1) asm volatile("" : "+v"(h[1][0]), "+v"(h[1][1]), "+v"(h[1][2]), "+v"(h[1][3]), "+v"(l[1][0]), "+v"(l[1][1]), "+v"(l[1][2]), "+v"(l[1][3]));
+    if constexpr (NB > 2) asm volatile("" : "+v"(h[2][0]), "+v"(h[2][1]), "+v"(h[2][2]), "+v"(h[2][3]), "+v"(l[2][0]), "+v"(l[2][1]), "+v"(l[2][2]), "+v"(l[2][3]));
+    if constexpr (NB > 3) asm volatile("" : "+v"(h[3][0]), "+v"(h[3][1]), "+v"(h[3][2]), "+v"(h[3][3]), "+v"(l[3][0]), "+v"(l[3][1]), "+v"(l[3][2]), "+v"(l[3][3]));
+}
+
 // SYNC: both groups walk the SAME tile phase (one interval apart): nchunk main slots, then the whole epilogue as free-running
 // code (no barriers, no DMAs inside); the weight stream is exactly one tile long, no rotated chunk order, no idle slots.
 template <int MB, int NPW, int WM, int WP, int EPV, bool SYNC = false>
@@ -157,6 +174,8 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
     constexpr bool RESID = (EPV & kPf3Resid) != 0, F32 = (EPV & kPf3F32) != 0, PF = (EPV & kPf3Pf) != 0, STAT = (EPV & kPf3Stat) != 0;
     constexpr bool PRE = (EPV & kPf3Pre) != 0;          // the loaded rows are partial sums that enter before the LayerNorm
     static_assert(!PRE || (RESID && SYNC), "kPf3Pre rides on the residual loads of the free-running epilogue");
+    constexpr bool RESPF = (EPV & kPf3ResPf) != 0;      // the residual comes from a PF tensor
+    static_assert(!RESPF || (RESID && SYNC && !PRE), "kPf3ResPf: a residual, free-running epilogue");
     constexpr bool RES3 = (EPV & kPf3Res3) != 0;
     static_assert(!STAT || SYNC, "LayerNorm statistics of the result: free-running epilogue only");
     static_assert(!RES3 || (SYNC && WM == 1 && NPW == 2), "epilogue res_conv: free-running epilogue, 64-channel shape");
@@ -382,7 +401,12 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             const float relu_slope = Pe->relu_slope, acc_scale = Pe->acc_scale;
             const float eps_s = Pe->eps / (acc_scale * acc_scale);
             const size_t row = (size_t)(T.oy0 + wp * NPW) * Pe->out_ys + (size_t)T.ox0 + Pe->out_zoff[0];
-            const char *r_base = RESID ? reinterpret_cast<const char *>(Pe->resid + (size_t)T.b * Pe->resid_bs + (size_t)cobase * r_cs + row) : nullptr;
+            const char *r_base = (RESID && !RESPF) ? reinterpret_cast<const char *>(Pe->resid + (size_t)T.b * Pe->resid_bs + (size_t)cobase * r_cs + row) : nullptr;
+            const long long rp_ps = Pe->rpf_ps, rp_ys = Pe->rpf_ys;
+            const char *rp_base = RESPF ? reinterpret_cast<const char *>(reinterpret_cast<const uint4 *>(Pe->resid_pf) + (long long)T.b * Pe->rpf_bs + (long long)(cobase >> 3) * 2 * rp_ps +
+                                                                       (long long)(T.oy0 + wp * NPW) * rp_ys + (long long)T.ox0 + Pe->rpf_zoff) : nullptr;
+            const unsigned voff_rp = (unsigned)(j * 16 + half * 8);
+            unsigned long long rvH[NBLK][4], rvL[NBLK][4];   // PF residual: this lane's half-units of the two planes, per 8-channel group
             char *o_base = F32 ? reinterpret_cast<char *>(Pe->out + (size_t)T.b * Pe->out_bs + (size_t)cobase * o_cs + row) : nullptr;
             char *p_base = PF ? reinterpret_cast<char *>(reinterpret_cast<uint4 *>(Pe->out_pf) + (long long)T.b * Pe->pf_bs + (long long)(cobase >> 3) * 2 * p_ps +
                                                          (long long)(T.oy0 + wp * NPW) * Pe->pf_ys + (long long)T.ox0 * Pe->pf_xs + Pe->pf_zoff[0]) : nullptr;
@@ -420,7 +444,15 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             };
             auto ldT = [&](auto qc) {                     // residual rows of block q: 4 x 16 bytes per lane
                 constexpr int q = decltype(qc)::value, n = q / MB, m = q % MB;
-                if constexpr (q < NBLK && RESID) {
+                if constexpr (q < NBLK && RESPF) {        // ... or its 2 x 4 half-units of a PF tensor
+                    const char *sb = rp_base + ((long long)(m * 4) * 2 * rp_ps + (long long)n * rp_ys) * 16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        rvH[q][g] = pf3_ld2(sb, voff_rp);
+                        rvL[q][g] = pf3_ld2(sb + rp_ps * 16, voff_rp);
+                        sb += 2 * rp_ps * 16;
+                    }
+                } else if constexpr (q < NBLK && RESID) {
                     const char *sb = r_base + ((size_t)(m * 32) * r_cs + (size_t)n * o_ys) * 4;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -432,7 +464,16 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             };
             auto wT_rN = [&](auto qc) {                   // residual of block q: rows -> region -> accumulator layout
                 constexpr int q = decltype(qc)::value;
-                if constexpr (q < NBLK && RESID) {
+                if constexpr (q < NBLK && RESPF) {        // half-units are in the accumulator layout already: a = h + l' 2^-11
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const f16x2 hv = __builtin_bit_cast(f16x2, (unsigned)(rvH[q][g] >> (32 * k))), lv = __builtin_bit_cast(f16x2, (unsigned)(rvL[q][g] >> (32 * k)));
+                            rv[q & 1][g * 4 + 2 * k] = __builtin_fmaf((float)lv[0], 1.0f / 2048.0f, (float)hv[0]);
+                            rv[q & 1][g * 4 + 2 * k + 1] = __builtin_fmaf((float)lv[1], 1.0f / 2048.0f, (float)hv[1]);
+                        }
+                } else if constexpr (q < NBLK && RESID) {
                     float *xr = (q & 1) ? xr1 : xr0;
                     if constexpr ((CDC_PF3_ABL & 8) != 0) {
 #pragma unroll
@@ -672,7 +713,8 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
                 if constexpr (WM > 1) bar();
                 devs(Q0{}); devs(Q1{});
                 if constexpr (WM > 1) bar();
-                if constexpr (RESID && !PRE) pf3_wait_rows<0>(rvT);
+                if constexpr (RESPF) pf3_wait_units<0>(rvH, rvL);
+                else if constexpr (RESID && !PRE) pf3_wait_rows<0>(rvT);
                 if constexpr (!PRE) { wT_rN(Q0{}); wT_rN(Q1{}); }
                 norm(Q0{}); norm(Q1{});
                 fin_pf(Q0{}); fin_pf(Q1{});

@@ -556,7 +556,20 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
         }
-        if (P.resid && valid_v[n]) {
+        if (P.resid_pf && valid_v[n]) {       // the residual as a PF tensor: this lane's 8-byte half-units, a = h + l' 2^-11
+            const int oy = oy0 + (wp * NPW + n % NPW) * NBH + pr, ox = ox0 + pc;
+            const uint2 *up = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint4 *>(P.resid_pf) + (long long)b * P.rpf_bs + (long long)(cobase >> 3) * 2 * P.rpf_ps +
+                                                              (long long)oy * P.rpf_ys + ox + P.rpf_zoff) + half;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint2 hu = up[(long long)((m * 4 + g) * 2) * P.rpf_ps * 2], lu = up[(long long)((m * 4 + g) * 2 + 1) * P.rpf_ps * 2];
+                    const f16x4 hv = __builtin_bit_cast(f16x4, hu), lv = __builtin_bit_cast(f16x4, lu);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[m][n][g * 4 + i] += __builtin_fmaf((float)lv[i], 1.0f / 2048.0f, (float)hv[i]);
+                }
+        } else if (P.resid && valid_v[n]) {
             const float *rp = P.resid + (size_t)b * P.resid_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.resid_cs;
 #pragma unroll
             for (int m = 0; m < MB; ++m)

@@ -303,6 +303,9 @@ def test_unet_forward_matches_reference_golden(name):
                                       ("full_x", {"CDC_NO_PF_TZ": "1"}),
                                       ("full_x", {"CDC_PF_17_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_17_MIN_WGS": "1", "CDC_PF_TZ_MIN_WGS": "1"}),
                                       ("small_x", {"CDC_PF_17_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_17": "1"}),
+                                      # planes-only ResnetBlock-chain outputs, residual read from planes (small launches forced onto conv_pf_kernel)
+                                      ("full_x", {"CDC_PF_MIN_WAVES": "1"}), ("full_eps", {"CDC_PF_MIN_WAVES": "1"}), ("small_x", {"CDC_PF_MIN_WAVES": "1"}),
+                                      ("full_x", {"CDC_NO_RESID_PF": "1"}),
                                       ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
                                       ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
                                       ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
@@ -819,6 +822,7 @@ def test_unet_stage_taps_of_a_planes_only_tensor(monkeypatch):
     """With the level-0 Downsample on the plane-operand kernel its input (downs.0.2, the attention output) exists as planes only:
     cdc_unet_tap unpacks h + l 2^-11."""
     monkeypatch.setenv("CDC_PF_S2_MIN_WGS", "1")
+    monkeypatch.setenv("CDC_PF_MIN_WAVES", "1")       # ... and downs.0.0 (the first ResnetBlock's output, read by the second one only)
     _check_taps("full_x")
     _check_taps("full_eps")
 
