@@ -802,10 +802,15 @@ struct Builder {
     // on the plane-operand kernels, given the twins of the two halves?  Then a0 (an Upsample output, read by nothing else) needs no
     // fp32 copy at all.  Mirrors the conditions of try_pf.
     bool join_reads_planes(const ResBlockW &rb, const float *p0, int C0, const float *p1, int H, int W) {
-        if (!pf_on() || !rb.has_res || rb.hoist_cx || dev_env("CDC_NO_PF_ONLY_JOIN")) return false;
         PfTwin *t0 = twin(p0), *t1 = twin(p1);
         if (!t0 || !t1 || !t1->valid || t0->H != H || t0->W != W || t1->H != H || t1->W != W) return false;
-        if (t0->C != C0 || t0->C + t1->C != rb.c1.Cin || rb.cres.Cin != rb.c1.Cin || (C0 % 16)) return false;
+        if (t0->C != C0 || t0->C + t1->C != rb.c1.Cin) return false;
+        return join_would_read_planes(rb, C0, H, W);
+    }
+    // ... the same question by shapes alone (asked in the encoder path, before the decoder half of the join exists)
+    bool join_would_read_planes(const ResBlockW &rb, int C0, int H, int W) {
+        if (!pf_on() || !rb.has_res || rb.hoist_cx || dev_env("CDC_NO_PF_ONLY_JOIN")) return false;
+        if (rb.cres.Cin != rb.c1.Cin || (C0 % 16) || C0 <= 0 || C0 >= rb.c1.Cin || !pf_site(SITE_JOIN, H, W)) return false;
         for (const ConvW *w : {&rb.c1, &rb.cres}) {
             const bool k3 = w->KH == 3 && w->KW == 3, k1 = w->KH == 1 && w->KW == 1;
             if (!w->wsh || w->stride != 1 || w->transposed || (w->Cin % 16) || !(k3 || k1)) return false;
@@ -1469,7 +1474,7 @@ struct Builder {
             oy.emit_pf = true;
             oy.no_f32 = out_planes_only && split_out && twin(y.p) != nullptr;
             conv(cw, x.p, C, x.bs(), nullptr, 0, H, W, y.p, y.bs(), oy, false, PC_CONV1);
-            if (last_pf_only) { PfTwin *ty = twin(y.p); y.pf = ty->p; y.pf_bs = ty->bs(); }
+            if (last_pf_only) { PfTwin *ty = twin(y.p); ty->only = true; y.pf = ty->p; y.pf_bs = ty->bs(); }
             return y;
         }
         // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
@@ -1544,7 +1549,15 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         // (the level-0 skip is never popped -- unet.py:113 pushes six, :123 pops five: its only reader is the Downsample)
         // Its output goes to the Downsample as planes INSTEAD of fp32 where that convolution runs on the plane-operand kernel.
         const bool l0_planes = i == 0 && n > 1 && bd.pf_s2_would_plan(h->downs[0], x.H, x.W) && !dev_env("CDC_NO_PF_S2_L0");
-        x = bd.attention(h->attns[ati++], x, sm, sr, i >= 1 ? Builder::SITE_JOIN : (l0_planes ? Builder::SITE_ALWAYS_PLANES : Builder::SITE_NONE), l0_planes);
+        // A skip (levels >= 1) has two readers, the Downsample and the decoder join of its level (ResnetBlock 2 n + 2 + 2 (n - 1 - i): block1
+        // and res_conv over cat[upsampled, skip]): planes only where all of them take planes.
+        bool skip_planes = false;
+        if (i >= 1 && i < n - 1 && !dev_env("CDC_NO_PF_SKIP_PLANES")) {
+            const ResBlockW &jrb = h->rbs[(size_t)2 * n + 2 + 2 * (n - 1 - i)];
+            skip_planes = bd.pf_s2_would_plan(h->downs[i], x.H, x.W) && bd.join_would_read_planes(jrb, jrb.c1.Cin - x.C, x.H, x.W);
+        }
+        x = bd.attention(h->attns[ati++], x, sm, sr, i >= 1 ? Builder::SITE_JOIN : (l0_planes ? Builder::SITE_ALWAYS_PLANES : Builder::SITE_NONE),
+                         l0_planes || skip_planes);
         h->taps[dn + ".2"] = x;
         skips.push_back(x);
         if (i < n - 1) {

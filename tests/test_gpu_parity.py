@@ -305,7 +305,10 @@ def test_unet_forward_matches_reference_golden(name):
                                       ("small_x", {"CDC_PF_17_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_17": "1"}),
                                       # planes-only ResnetBlock-chain outputs, residual read from planes (small launches forced onto conv_pf_kernel)
                                       ("full_x", {"CDC_PF_MIN_WAVES": "1"}), ("full_eps", {"CDC_PF_MIN_WAVES": "1"}), ("small_x", {"CDC_PF_MIN_WAVES": "1"}),
-                                      ("full_x", {"CDC_NO_RESID_PF": "1"}),
+                                      ("full_x", {"CDC_NO_RESID_PF": "1"}), ("full_x", {"CDC_NO_PF_SKIP_PLANES": "1"}),
+                                      # ... and planes-only skips (Downsample and decoder join both on plane operands)
+                                      ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_PF_S2_MIN_WGS": "1", "CDC_PF_TZ_MIN_WGS": "1"}),
+                                      ("full_eps", {"CDC_PF_MIN_WAVES": "1", "CDC_PF_S2_MIN_WGS": "1", "CDC_PF_17_MIN_WGS": "1"}),
                                       ("full_x", {"CDC_NO_SPLIT": "1"}), ("full_x", {"CDC_NO_HOIST": "1"}),
                                       ("full_x", {"CDC_NO_KVCTX": "1"}), ("full_x", {"CDC_NO_ATTN_FOLD": "1"}),
                                       ("full_eps", {"CDC_NO_PERIMAGE_SPLIT": "1"}), ("small_x", {"CDC_NO_SPLIT2": "1"}),
