@@ -155,7 +155,7 @@ def op_bytes(label, B):
     cin, cout = (int(v) for v in t[3].split("->"))
     ho, wo = (int(v) for v in t[t.index("out") + 1].split("x"))
     st = int(t[2][1:]) if t[2].startswith("s") else 1
-    return 4.0 * B * (cin * ho * wo * st * st + cout * ho * wo * (2 if "+res" in t else 1))
+    return 4.0 * B * (cin * ho * wo * st * st + cout * ho * wo * (2 if ("+res" in t or "+resP" in t) else 1))     # (+resP: the residual read from a PF tensor, same bytes)
 
 
 def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cfgd, prof_every, full=True):
