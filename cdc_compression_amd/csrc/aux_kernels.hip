@@ -328,12 +328,18 @@ __device__ __forceinline__ void ctx_dma16(const float *g, unsigned lds_byte) {
                  : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
 }
 
-template <bool F16>      // F16: sum_n p v on the fp16 matrix cores with two-plane operands (as kvctx16_kernel, attn_kernels.hip)
+// ONE (round 4, few-pixel levels: N <= 1024, one split): the whole of `softmax(k) v^T` in this launch -- the row maxima are taken
+// here (kmax_kernel's pass), and the epilogue normalises the tile and writes the per-image weights / planes (ctx_reduce_kernel's
+// pass): one launch instead of three on a latency-bound chain, same values as the three with nsplit = 1.
+constexpr float kCtxPlaneScale = 256.0f;
+template <bool F16, bool ONE = false>      // F16: sum_n p v on the fp16 matrix cores with two-plane operands (as kvctx16_kernel, attn_kernels.hip)
 __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const float *v,
                                                           long long kv_bs, int C, int N,
                                                           const float *kmax, float *S, float *Zp,
-                                                          int nsplit, int tiles) {
+                                                          int nsplit, int tiles, float scale = 0.f, float *ctxw = nullptr,
+                                                          int Cin_pad = 0, int COP = 0, unsigned short *Ws = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 stages x (k 64x64 + v 64x64)
+    __shared__ float rows_s[4 * 64];                               // ONE: row maxima, then the waves' row sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dt = blockIdx.x / tiles, et = blockIdx.x % tiles;
@@ -373,8 +379,26 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
 
     const int half = lane >> 5, jj = lane & 31;
     float mrow[2], zrow[2] = {0.f, 0.f};
+    if constexpr (ONE) {        // row maxima of this tile's 64 k rows: four threads per row (N % 4 == 0)
+        const int r = tid >> 2, part = tid & 3;
+        float m = -INFINITY;
+        if (d0 + r < C) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(kb + (size_t)(d0 + r) * N);
+            for (int n = part; n < (N >> 2); n += 4) {
+                const float4 q = r4[n];
+                m = fmaxf(m, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        if (part == 0) rows_s[r] = m;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mrow[i] = (d0 + i * 32 + jj < C) ? rows_s[i * 32 + jj] : 0.f;
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) mrow[i] = (d0 + i * 32 + jj < C) ? kmax[(size_t)b * C + d0 + i * 32 + jj] : 0.f;
+    }
 
     if (n_begin < n_end) issue(n_begin, 0);
     int stage = 0;
@@ -462,6 +486,48 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
                 red[(wave * 64 + d) * 64 + j * 32 + jj] = acc[i][j][r];
             }
     __syncthreads();
+    if constexpr (ONE) {
+        // row sums of exp over all pixels (every workgroup of a tile row has them), then ctx_reduce_kernel's work on this tile:
+        // ctxw[d][e] = scale * S / z, and the fp16 planes {WH, WL, WH2} of ctxw 2^8 in units of 8 rows d
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float z = zrow[i] + __shfl_xor(zrow[i], 32);
+            if (half == 0) rows_s[wave * 64 + i * 32 + jj] = z;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 8 * 64; idx += 256) {
+            const int g = idx >> 6, e = idx & 63;
+            if (d0 + g * 8 >= C || e0 + e >= C) continue;
+            float vals[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int d = g * 8 + r, q = d * 64 + e;
+                float s2 = red[q] + red[4096 + q] + red[8192 + q] + red[12288 + q];
+                const float z = rows_s[d] + rows_s[64 + d] + rows_s[128 + d] + rows_s[192 + d];
+                s2 = (d0 + d < C) ? s2 / z * scale : 0.f;
+                vals[r] = s2;
+                if (d0 + d < Cin_pad) ctxw[((size_t)b * Cin_pad + d0 + d) * COP + e0 + e] = s2;
+            }
+            if (Ws) {
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8 wh, wl, wh2;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float w = vals[r] * kCtxPlaneScale;
+                    const _Float16 hq = (_Float16)w;
+                    wh[r] = hq;
+                    wl[r] = (_Float16)(w - (float)hq);
+                    wh2[r] = (_Float16)((float)hq * (1.0f / 2048.0f));
+                }
+                const int dd = d0 + g * 8, q = dd >> 4, kh = (dd >> 3) & 1;
+                uint4 *dst = reinterpret_cast<uint4 *>(Ws) + (size_t)b * (C / 16) * 6 * C;
+                dst[(size_t)((q * 3 + 0) * 2 + kh) * C + e0 + e] = __builtin_bit_cast(uint4, wh);
+                dst[(size_t)((q * 3 + 1) * 2 + kh) * C + e0 + e] = __builtin_bit_cast(uint4, wl);
+                dst[(size_t)((q * 3 + 2) * 2 + kh) * C + e0 + e] = __builtin_bit_cast(uint4, wh2);
+            }
+        }
+        return;
+    }
     float *out = S + (((size_t)b * nsplit + split) * C) * C;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int d = idx >> 6, e = idx & 63;
@@ -505,6 +571,28 @@ __global__ void __launch_bounds__(256) ctx_partial_generic_kernel(const float *k
     }
 }
 
+// ONE launch for kstats + partial + reduce (see ctx_partial_kernel, ONE): N % 4 == 0, C % 64 == 0, Cin_pad == COP == C
+hipError_t ctx_one_launch(const float *k, const float *v, long long kv_bs, int C, int N, float scale, float *ctxw, int Cin_pad, int COP,
+                          unsigned short *Ws, int B, hipStream_t st, int f16) {
+    if ((N & 3) || (C % 64) || Cin_pad != C || COP != C) return hipErrorInvalidValue;
+    const int tiles = C / 64;
+    const size_t lds = sizeof(float) * 4 * 64 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)ctx_partial_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)ctx_partial_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (f16)
+        hipLaunchKernelGGL((ctx_partial_kernel<true, true>), dim3(tiles * tiles, 1, B), dim3(256), lds, st, k, v, kv_bs, C, N, nullptr, nullptr, nullptr, 1, tiles, scale,
+                           ctxw, Cin_pad, COP, Ws);
+    else
+        hipLaunchKernelGGL((ctx_partial_kernel<false, true>), dim3(tiles * tiles, 1, B), dim3(256), lds, st, k, v, kv_bs, C, N, nullptr, nullptr, nullptr, 1, tiles, scale,
+                           ctxw, Cin_pad, COP, Ws);
+    return hipGetLastError();
+}
+
 hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
                               const float *kmax, float *S, float *Zp, int nsplit, int B,
                               hipStream_t st, int f16) {
@@ -537,7 +625,6 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
 // One workgroup = 8 rows d (= 8 input channels of the per-image 1x1 convolution out[e] = sum_d ctxw[d][e] q[d]): the
 // 8 values of a thread are one 16-byte A-operand unit, so the kernel can also emit the convolution's weight planes
 // (Ws: fp16 {WH, WL, WH2} of ctxw 2^8, layout [C/16][3][2][C][8] per image -- conv_split_kernel.h AR = 1).
-constexpr float kCtxPlaneScale = 256.0f;
 __global__ void __launch_bounds__(256) ctx_reduce_kernel(const float *S, const float *ksum, int C,
                                                          int nsplit, float scale, float *ctxw,
                                                          int Cin_pad, int COP, unsigned short *Ws) {

@@ -90,6 +90,7 @@ struct Op {
     unsigned short *at_Ws = nullptr;   // CTXF: also emit M' as bf16 planes for lnconv_kernel
     const float *at_Wq = nullptr;      // CTXF: Wq [d][ci] (fold_r2_mfma_kernel)
     const float *at_M = nullptr;  // CTXF after KVCTX: per-split row maxima   // COPY: dst = sum of cp_parts planes of src
+    int at_one = 0;                    // CTXP: row maxima, partial context and reduction in this ONE launch (ctx_one_launch)
     struct { const float *src; long long src_bs; float *dst; long long dst_bs; int C, KW, pad, H, W; } uf;
     struct { const float *src; long long src_bs; void *dst; long long dst_bs; int C, H, W; } pk;   // PFPACK
 };
@@ -674,7 +675,7 @@ struct Builder {
         else if (op.kind == Op::LNCONV)
             snprintf(buf, sizeof buf, "lnconv C=%d N=%d nsplit=%d", op.lnc.C, op.lnc.N, op.lnc.nsplit);
         else if (op.kind == Op::KSTATS || op.kind == Op::CTXP || op.kind == Op::CTXR || op.kind == Op::CTXF)
-            snprintf(buf, sizeof buf, "%s C=%d N=%d nsplit=%d", kinds[op.kind], op.at.C, op.at.N, op.at.nsplit);
+            snprintf(buf, sizeof buf, "%s C=%d N=%d nsplit=%d", op.at_one ? "ctx1" : kinds[op.kind], op.at.C, op.at.N, op.at_one ? 1 : op.at.nsplit);
         else
             snprintf(buf, sizeof buf, "%s", kinds[op.kind]);
         h->op_label.push_back(buf);
@@ -1416,7 +1417,10 @@ struct Builder {
             if (h->arith == 1 && at.kvWh && !dev_env("CDC_KVCTX_BF16")) { f.kvc.Ws = at.kvWh; f.kvc.f16 = 1; f.kvc.wscale_inv = at.kv_scale_inv; }
             f.flops = 6.0 * B * (double)C * C * N; f.bytes = 4.0 * B * C * N;
             emit(f);
-        } else {
+        }
+        // few-pixel levels (not folded): kstats + partial context + reduction as ONE launch (round 4; the chain is latency-bound)
+        const bool ctx_one = !fused && !fold && (N & 3) == 0 && N <= 1024 && (C % 64) == 0 && Cin_pad == C && COP == C && !dev_env("CDC_NO_CTX_ONE");
+        if (!fused && !ctx_one) {
             emit(k);
             Op p = k; p.kind = Op::CTXP; p.prof = PC_ATTN_CTX;
             p.flops = 2.0 * B * (double)C * C * N; p.bytes = 8.0 * B * C * N;
@@ -1440,6 +1444,10 @@ struct Builder {
         r.at_M = kmaxs; r.at_Ws = Ws; r.at_ws_f16 = planes_f16 ? 1 : 0; r.at_Wq = at.Wq;
         r.bytes = 4.0 * B * nsplit * C * C;
         r.flops = fold ? 4.0 * B * (double)C * C * C : 0.0;
+        if (ctx_one) {
+            r.kind = Op::CTXP; r.prof = PC_ATTN_CTX; r.at_one = 1;
+            r.flops = 2.0 * B * (double)C * C * N; r.bytes = 8.0 * B * C * N;
+        }
         emit(r);
         ConvW cw;    // per-image weights produced above
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
@@ -1812,6 +1820,11 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             break;
         case Op::CTXP: {
             const bool ctxp_f32 = dev_env("CDC_CTXP_F32") != nullptr;
+            if (op.at_one) {
+                HIP_TRY(h, ctx_one_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.scale, op.at.ctxw, op.at.Cin_pad, op.at.COP,
+                                          op.at_ws_f16 ? op.at_Ws : nullptr, B, st, h->arith == 1 && !ctxp_f32));
+                break;
+            }
             HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
                                           op.at.S, op.at.ksum, op.at.nsplit, B, st, h->arith == 1 && !ctxp_f32));
             break;

@@ -157,6 +157,8 @@ hipError_t kstats_launch(const float *k, long long k_bs, int C, int N, float *km
 hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, int C, int N,
                               const float *kmax, float *S, float *Zp, int nsplit, int B,
                               hipStream_t st, int f16 = 0);
+hipError_t ctx_one_launch(const float *k, const float *v, long long kv_bs, int C, int N, float scale, float *ctxw, int Cin_pad, int COP,
+                          unsigned short *Ws, int B, hipStream_t st, int f16);
 // ctxw[b][d][e] = scale * sum_split S / ksum[d], written as per-image packed 1x1 weights
 // [Cin_pad][COP] (rows d >= C and cols e >= C zeroed)
 hipError_t ctx_reduce_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
