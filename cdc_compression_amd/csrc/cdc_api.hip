@@ -780,6 +780,7 @@ struct Builder {
         float relu_slope = 0.f;                        // LeakyReLU slope (0 = ReLU)
         const float *shift = nullptr;                  // + shift[b][co]
         const float *resid = nullptr; long long resid_bs = 0, resid_cs = 0;
+        const float *resid1 = nullptr; long long resid1_bs = 0; int resid_c0 = 0;   // residual over cat[resid (resid_c0 channels), resid1]: plane-operand kernels only
         const float *pre_add = nullptr;                // hoisted partial sums (same layout as out)
         float *stat_mean = nullptr, *stat_rstd = nullptr;
         const float *pre_mean = nullptr, *pre_rstd = nullptr, *pre_g = nullptr, *pre_b = nullptr;
@@ -933,6 +934,10 @@ struct Builder {
         a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu; a.relu_slope = o.relu_slope;
         a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs; a.resid_cs = o.resid_cs;
+        if (o.resid1) {         // residual over a channel concatenation: every wave's channel part inside one source (64 / 96 / 128-channel parts)
+            if (!o.resid || o.resid_c0 <= 0 || o.resid_c0 >= w.Cout || (o.resid_c0 % 64) || (o.resid_c0 % (plan.MB * 32))) return false;
+            a.resid1 = o.resid1; a.resid1_bs = o.resid1_bs; a.resid_c0 = o.resid_c0;
+        }
         if (PfTwin *tr = o.resid ? twin(o.resid) : nullptr)
             if (tr->only) {     // the residual exists as planes only (a ResnetBlock-chain output): read it from there
                 if (!tr->valid || tr->C != w.Cout || tr->H != s.Ho || tr->W != s.Wo || w.transposed || w.stride != 1 ||
@@ -1049,6 +1054,7 @@ struct Builder {
         s.B = pb(); s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
         if (!o.uf_c && try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
+        if (o.resid1 && !rc) { rc = fail(h, CDC_ERR_UNSUPPORTED, "a two-source residual reached a kernel without it"); return true; }
         for (const float *q : {s0, s1, o.resid})
             if (PfTwin *tq = q ? twin(q) : nullptr)
                 if (tq->only && !rc) { rc = fail(h, CDC_ERR_UNSUPPORTED, "a planes-only tensor reached a kernel that reads fp32"); return true; }
@@ -1227,8 +1233,10 @@ struct Builder {
     bool block(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1,
                int H, int W, Act out, const float *g, const float *b, const float *shift,
                const float *pre_add, const float *resid, long long resid_bs, float *sm, float *sr,
-               int prof, bool pf_only_out = false, int uf_c = 0, int uf_pad = 0) {
+               int prof, bool pf_only_out = false, int uf_c = 0, int uf_pad = 0, const float *resid1 = nullptr, long long resid1_bs = 0,
+               int resid_c0 = 0) {
         ConvOpts o;
+        o.resid1 = resid1; o.resid1_bs = resid1_bs; o.resid_c0 = resid_c0;
         o.uf_c = uf_c; o.uf_pad = uf_pad;
         o.no_f32 = pf_only_out;
         o.ln_g = g; o.ln_b = b; o.relu = 1; o.shift = shift; o.pre_add = pre_add;
@@ -1287,6 +1295,9 @@ struct Builder {
         static const bool keep_h1 = dev_env("CDC_PF_KEEP_H1") != nullptr;
         const bool h1_pf_only = !keep_h1 && twin(h1.p) && pf_would_plan(rb.c2, H, W);
         if (a1 && a1_is_context && rb.hoist_cx == a0.C) {
+            // identity residual over cat[x, context] (downs.1.0): read from its two sources in block2's epilogue where that runs on a
+            // plane-operand kernel (PfArgs::resid1) instead of materialising the concatenation every iteration
+            const bool res2 = !rb.has_res && (a0.C % 64) == 0 && a0.C + a1->C == rb.cout && pf_would_plan(rb.c2, H, W) && !dev_env("CDC_NO_RESID2");
             std::vector<Op> *saved = cur;
             Act p1 = new_act(rb.cout, H, W, false);
             cur = &h->pre_ops;
@@ -1298,7 +1309,7 @@ struct Builder {
                 pr = new_act(rb.cout, H, W, false);
                 conv(rb.cresc, a1->p, a1->C, a1->bs(), nullptr, 0, H, W, pr.p, pr.bs(), ConvOpts(), false,
                      PC_CONV1);
-            } else {
+            } else if (!res2) {
                 // identity residual over the concatenation (downs.1.0): context half copied once
                 cat = new_act(a0.C + a1->C, H, W, false);
                 copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
@@ -1331,12 +1342,14 @@ struct Builder {
                 ConvOpts orr; orr.pre_add = pr.p; orr.no_bias = true;
                 conv(rb.cresx, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, r.p, r.bs(), orr, false, PC_CONV1);
                 res = r.p; res_bs = r.bs();
+            } else if (res2) {
+                res = a0.p; res_bs = a0.bs();
             } else {
                 copy(a0.p, a0.bs(), cat.p, cat.bs(), a0.bs());
                 res = cat.p; res_bs = cat.bs();
             }
             block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
-                  res_bs, sm, sr, PC_CONV3, out_planes_only && twin(out.p));
+                  res_bs, sm, sr, PC_CONV3, out_planes_only && twin(out.p), 0, 0, res2 ? a1->p : nullptr, res2 ? a1->bs() : 0, res2 ? a0.C : 0);
             mark_planes_only(out);
             return out;
         }

@@ -134,6 +134,11 @@ struct PfArgs {
     int shift_bs;
     const float *resid;
     long long resid_bs, resid_cs;
+    // a residual over a channel concatenation (round 4: the identity residual of downs.1.0 over cat[x, context]): channels >= resid_c0
+    // come from resid1 (same channel stride as resid); both boundaries fall on a wave's channel part (host-checked)
+    const float *resid1;
+    long long resid1_bs;
+    int resid_c0;
     // the residual as a PF tensor (round 4: a ResnetBlock-chain output that exists as planes only; replaces `resid`):
     // unit index b*rpf_bs + ((co/8)*2 + plane)*rpf_ps + oy*rpf_ys + ox + rpf_zoff (the zoff includes the +1,+1 halo origin)
     const void *resid_pf;

@@ -401,7 +401,10 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
             const float relu_slope = Pe->relu_slope, acc_scale = Pe->acc_scale;
             const float eps_s = Pe->eps / (acc_scale * acc_scale);
             const size_t row = (size_t)(T.oy0 + wp * NPW) * Pe->out_ys + (size_t)T.ox0 + Pe->out_zoff[0];
-            const char *r_base = (RESID && !RESPF) ? reinterpret_cast<const char *>(Pe->resid + (size_t)T.b * Pe->resid_bs + (size_t)cobase * r_cs + row) : nullptr;
+            // (a residual over a channel concatenation: this wave's channels lie wholly in one of the two sources)
+            const bool r_second = RESID && !RESPF && Pe->resid1 != nullptr && cobase >= Pe->resid_c0;
+            const char *r_base = (RESID && !RESPF) ? reinterpret_cast<const char *>(r_second ? Pe->resid1 + (size_t)T.b * Pe->resid1_bs + (size_t)(cobase - Pe->resid_c0) * r_cs + row
+                                                                                             : Pe->resid + (size_t)T.b * Pe->resid_bs + (size_t)cobase * r_cs + row) : nullptr;
             const long long rp_ps = Pe->rpf_ps, rp_ys = Pe->rpf_ys;
             const char *rp_base = RESPF ? reinterpret_cast<const char *>(reinterpret_cast<const uint4 *>(Pe->resid_pf) + (long long)T.b * Pe->rpf_bs + (long long)(cobase >> 3) * 2 * rp_ps +
                                                                        (long long)(T.oy0 + wp * NPW) * rp_ys + (long long)T.ox0 + Pe->rpf_zoff) : nullptr;

@@ -570,7 +570,10 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                     for (int i = 0; i < 4; ++i) acc[m][n][g * 4 + i] += __builtin_fmaf((float)lv[i], 1.0f / 2048.0f, (float)hv[i]);
                 }
         } else if (P.resid && valid_v[n]) {
-            const float *rp = P.resid + (size_t)b * P.resid_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.resid_cs;
+            // (resid1: a residual over a channel concatenation, this wave's channels wholly in one source)
+            const float *rp = (P.resid1 && cobase >= P.resid_c0)
+                                  ? P.resid1 + (size_t)b * P.resid1_bs + pix_v[n] + (size_t)(cobase - P.resid_c0 + 4 * half) * P.resid_cs
+                                  : P.resid + (size_t)b * P.resid_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.resid_cs;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll

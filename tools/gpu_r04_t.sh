@@ -19,5 +19,5 @@ run_bench() {
 import json; d=json.loads(open('$OUT/bench_$tag.json').read().strip().splitlines()[-1]); print('$tag ms/iter', round(d['roofline']['ms_per_ddim_iter'],3), 'verify', d.get('verify',{}).get('max_rel_err_vs_batch1_decode'), {k:round(v,3) for k,v in d['roofline']['class_ms_per_ddim_iter'].items()}, {k:round(v['ms_per_iteration'],3) for k,v in d['roofline']['families'].items()})"
 }
 run_bench new CDC_X=0
-run_bench old CDC_DEV=1 CDC_NO_RESID_PF=1
+run_bench old CDC_DEV=1 ${OLD_ENV:-CDC_NO_RESID_PF=1}
 grep -E "resP|nof32" $OUT/per_op_new.txt | head -24
