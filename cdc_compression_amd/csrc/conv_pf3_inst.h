@@ -10,7 +10,11 @@ template <int MB, int NPW, int WM, int WP> static pf_kernel_fn pf3_lookup_shape(
     switch (epv) {                                    // kPf3Resid | kPf3F32 | kPf3Pf
     case 2: return conv_pf3_kernel<MB, NPW, WM, WP, 2, true>;
     case 3: return conv_pf3_kernel<MB, NPW, WM, WP, 3, true>;
+#ifdef CDC_PF3_NOSYNC4
+    case 4: return conv_pf3_kernel<MB, NPW, WM, WP, 4, false>;      // (experiment: the epilogue beside the partner group's main loop)
+#else
     case 4: return conv_pf3_kernel<MB, NPW, WM, WP, 4, true>;
+#endif
     case 5: return conv_pf3_kernel<MB, NPW, WM, WP, 5, true>;
     case 6: return conv_pf3_kernel<MB, NPW, WM, WP, 6, true>;
     case 7: return conv_pf3_kernel<MB, NPW, WM, WP, 7, true>;
