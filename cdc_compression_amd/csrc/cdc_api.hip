@@ -967,6 +967,55 @@ struct Builder {
         return true;
     }
 
+    // The first layer (7x1 over the kx-unfolded 3-channel image, ConvOpts::uf_c) on conv_pf_kernel's UF form: the kernel builds its patch
+    // buffers from the image itself, everything else (weight ring, tap loop, epilogue with hoisted partial sums, LayerNorm, planes out)
+    // is the plane-operand kernel.
+    bool try_pf_uf(const ConvW &w, const float *s0, long long bs0, int H, int W, float *out, long long out_bs, const ConvOpts &o,
+                   bool need_all, int prof, const ConvShape &s) {
+        if (!pf_on() || !w.wsh || o.uf_c != 3 || o.uf_pad != 3 || w.KH != 7 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
+        if (o.pre_mean || o.w_bs || o.wsp_bs || o.max_ksplit > 1 || o.resid || o.res3_w || o.stat_mean) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 3 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0 || s.Ho != H || s.Wo != W) return false;
+        PfShape ps;
+        ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = 7; ps.KW = 1; ps.Ho = H; ps.Wo = W; ps.B = pb(); ps.need_all_cout = need_all;
+        ps.uf = 3; ps.cop = w.COP;
+        PfPlan plan;
+        if (!pf_make_plan(ps, &plan)) return false;
+        Op op;
+        op.kind = Op::CONVPF; op.prof = prof; op.pfplan = plan; op.nz = 1;
+        PfArgs &a = op.pf;
+        memset(&a, 0, sizeof a);
+        a.x0 = s0; a.x0_bs = bs0;
+        a.C0 = a.Cin = 32; a.H = H; a.W = W;
+        a.w = w.wsh; a.w_zs = w.wsp_zs / 8;
+        a.KH = 7; a.KW = 1; a.nz = 1;
+        a.nchunk = 2; a.COP = w.COP; a.Cout = w.Cout;
+        a.acc_scale = w.wscale_inv;
+        a.pad_y[0] = 3; a.pad_x[0] = 0;
+        a.out = o.no_f32 ? nullptr : out; a.out_bs = out_bs;
+        a.out_cs = (long long)H * W; a.out_ys = W; a.out_xs = 1;
+        a.Ho = H; a.Wo = W;
+        PfTwin *to = o.emit_pf ? twin(out) : nullptr;
+        if (to && to->C == w.Cout && to->H == H && to->W == W && out_bs == (long long)w.Cout * H * W) {
+            a.out_pf = to->p; a.pf_bs = to->bs(); a.pf_ps = to->ps();
+            a.pf_ys = W + 2; a.pf_xs = 1; a.pf_zoff[0] = (W + 2) + 1;
+            to->valid = true;
+        } else if (o.no_f32) {
+            a.out = out;
+        }
+        a.bias = o.no_bias ? nullptr : w.bias;
+        a.pre_add = o.pre_add;
+        a.ep_g = o.ln_g; a.ep_b = o.ln_b; a.eps = 1e-5f; a.relu = o.relu; a.relu_slope = o.relu_slope;
+        a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
+        a.fault = fault_flag();
+        const double px = (double)B * H * W;
+        op.flops = 2.0 * px * w.Cout * w.Cin * 7;
+        op.bytes = 4.0 * ((double)B * 3 * H * W + px * w.Cout);
+        last_ksplit = 1;
+        last_pf_only = a.out == nullptr;
+        emit(op);
+        return true;
+    }
+
     // Pointwise convolutions at the >= 32-pixel-wide levels on conv_pw_kernel (fp16 arithmetic): activations staged
     // per wave straight from the fp32 sources, PreNorm folded as (x - mean) on load / rstd in the epilogue.
     bool try_pw(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W,
@@ -1053,6 +1102,7 @@ struct Builder {
         }
         s.B = pb(); s.need_all_cout = need_all; s.lnmode = o.pre_mean ? o.pre_mode : 0;
         if (!o.uf_c && try_pf(w, s0, C0, s1, H, W, out, out_bs, o, need_all, prof, s)) return true;
+        if (o.uf_c && !s1 && try_pf_uf(w, s0, bs0, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
         if (o.resid1 && !rc) { rc = fail(h, CDC_ERR_UNSUPPORTED, "a two-source residual reached a kernel without it"); return true; }
         for (const float *q : {s0, s1, o.resid})

@@ -49,6 +49,7 @@ struct PfShape {
     int Cin, Cout, C0 = 0, KH, KW, nz = 1, Ho, Wo, B;
     bool need_all_cout = false;
     int stride = 1;      // 2: 3x3 / pad 1 Downsample convolution (conv_pf_kernel, STR = 2)
+    int uf = 0;          // 3: the first layer as KH x 1 over the kx-unfolded 3-channel image, patches built in the kernel (conv_pf_kernel, UF)
     int cop = 0;         // padded output channels of the packed weights (only the 1x7 final-convolution shape asks)
     int tz = 1;          // 4: 4x4 / stride 2 transposed convolution, its four 2x2 phases fused in one workgroup (conv_pf_kernel, TZ = 4)
 };

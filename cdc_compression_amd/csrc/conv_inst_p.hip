@@ -41,6 +41,7 @@ static pf_kernel_fn pf_lookup(int MB, int NPW, int WM, int WP, int KH, int KW, i
     if (KH == 1 && KW == 1) return pf_lookup_k<1, 1>(MB, NPW, WM, WP);
     if (KH == 2 && KW == 2) return pf_lookup_k<2, 2>(MB, NPW, WM, WP);
     if (KH == 1 && KW == 7 && MB == 1 && NPW == 2 && WM == 1 && WP == 4) return conv_pf_kernel<1, 2, 1, 4, 1, 7>;   // row-folded final convolution
+    if (KH == 7 && KW == 1 && MB == 2 && NPW == 2 && WM == 1 && WP == 4) return conv_pf_kernel<2, 2, 1, 4, 7, 1, 1, 1, 3>;   // first layer, built from the image (UF)
     return nullptr;
 }
 
@@ -65,6 +66,21 @@ static const PfCand kCands[] = {
 };
 
 bool pf_make_plan(const PfShape &s, PfPlan *p) {
+    if (s.uf) {
+        // the first layer as a 7x1 convolution over the 21 kx-unfolded channels of the 3-channel image, patches built in the kernel
+        // (conv_pf_kernel, UF = 3): 64 output channels, 8-row tiles, two workgroups per CU
+        if (s.uf != 3 || s.KH != 7 || s.KW != 1 || s.Cin != 21 || s.Cout != 64 || s.cop != 64 || s.C0 || s.nz != 1 || s.stride != 1 || s.tz != 1 ||
+            s.Wo < 32 || dev_env("CDC_NO_PF_UF"))
+            return false;
+        const int ring = pf_ring(2, 2, 1, 4, 7, 1);
+        const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + 7) / 8) * s.B;
+        const double min_wgs = dev_env("CDC_PF_UF_MIN_WGS") ? atof(dev_env("CDC_PF_UF_MIN_WGS")) : 512.0;
+        if (ring < 3 || wgs < min_wgs) return false;
+        p->MB = 2; p->NPW = 2; p->WM = 1; p->WP = 4; p->ring = ring;
+        p->tiles_x = (s.Wo + 31) / 32; p->tiles_y = (s.Ho + 7) / 8; p->groups = 1;
+        p->lds_bytes = (size_t)2 * pf_patch_units(2, 4, 7, 1) * 16 + (size_t)ring * pf_rows(2, 2) * 64 * 16 + (size_t)pf_uf_stage_floats(2, 4) * 4;
+        return true;
+    }
     if (s.KH == 1 && s.KW == 7) {
         // the row-folded final convolution (unet.py:104: 7x7 to out_dim channels as 1x7 to 7 * out_dim <= 32 virtual channels):
         // one 32-channel block, 8-row tiles, three workgroups per CU; plain fp32 output with masked channel stores

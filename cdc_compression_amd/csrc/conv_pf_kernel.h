@@ -59,6 +59,7 @@ __host__ __device__ constexpr int pf_rows(int MB, int NPW) { return pf_acc2(MB, 
 __host__ __device__ constexpr int pf_patch_units(int NPW, int WP, int KH, int KW, int STR = 1, int TZ = 1) {
     return TZ == 4 ? ((4 * (WP * NPW + 2) * 34 + 63) / 64) * 64 : ((4 * ((WP * NPW - 1) * STR + KH) * (31 * STR + KW) + 63) / 64) * 64;
 }
+__host__ __device__ constexpr int pf_uf_stage_floats(int NPW, int WP) { return ((3 * (WP * NPW + 6) * 38 + 63) / 64) * 64; }
 // Patch buffers: the patch of chunk c + LA streams in while chunk c is multiplied, LA = buffers - 1.  1x1 layers (one tap per chunk)
 // and stride-2 layers (one workgroup of one wave per SIMD on the CU: nothing else hides the HBM latency of a patch) run two
 // chunks ahead.
@@ -69,7 +70,9 @@ __host__ __device__ constexpr int pf_patch_bufs(int KH, int KW, int STR = 1) { r
 // (stride 2: the patch of a 4-row tile is 9 x 65 pixels = 37 KB -- ONE workgroup per CU)
 // tps = taps per weight stage (one s_barrier per stage)
 __host__ __device__ constexpr int pf_ring_tps(int MB, int NPW, int WM, int WP, int KH, int KW, int STR, int tps, int TZ = 1) {
-    const size_t budget = (WM * WP == 8 || STR == 2) ? 156 * 1024 : 80 * 1024;
+    // (KH x 1 with KH = 7: the first layer built from the 3-channel image, UF below -- its fp32 staging area of 3 x PH x 38 floats sits
+    //  behind the ring)
+    const size_t budget = ((WM * WP == 8 || STR == 2) ? 156 * 1024 : 80 * 1024) - ((KH == 7 && KW == 1) ? pf_uf_stage_floats(NPW, WP) * 4 : 0);
     const size_t patch = (size_t)pf_patch_bufs(KH, KW, STR) * pf_patch_units(NPW, WP, KH, KW, STR, TZ) * 16;
     const size_t wst = (size_t)tps * pf_rows(MB, TZ * NPW) * WM * MB * 32 * 16;
 #ifndef CDC_PF_RING_MAX
@@ -112,7 +115,13 @@ __host__ __device__ constexpr int pf_ring(int MB, int NPW, int WM, int WP, int K
 // workgroup evaluates all four phases of its input tile from one shared 3x3-neighbourhood patch -- 16 taps per chunk (phase-major),
 // four accumulator sets per wave (block q = phase * NPW + n); one prologue, one patch and one epilogue per 4 x 128 output pixels
 // instead of four of each (the phase-per-workgroup form, gridDim.z = 4, was slower than the register-staged kernel).
-template <int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1, int TZ = 1>
+//
+// UF = 3 (the first layer, unet.py:78 / network_components.py:83: a 7x7 convolution of the 3-channel image, run as a 7x1 convolution over
+// its 21 kx-unfolded channels = two 16-channel chunks): there is no PF tensor to fetch -- the workgroup stages the image patch
+// (3 x (TH + 6) x 38 floats) and BUILDS the two chunks' patch buffers itself (split into planes, channel kx * 3 + ci of pixel x = image
+// channel ci at x + kx - 3, zero beyond the image and for channels >= 21); the weight ring, the tap loop and the epilogue are the kernel's
+// own.  Replaces conv_split2_kernel's unfold-on-load form where the launch is large enough.
+template <int MB, int NPW, int WM, int WP, int KH, int KW, int STR = 1, int TZ = 1, int UF = 0>
 __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR == 2 ? 1 : ((WM * WP == 8 || MB * NPW * TZ <= 4 || (TZ == 4 && MB * NPW <= 2 && CDC_PF_TZ_MINB == 2)) ? 2 : 1)) conv_pf_kernel(const PfArgs P) {
     constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
     // (COPT = 32: the row-folded final convolution, 21 of 32 channels real -- host: COP == 32, so the rows of a stage are contiguous
@@ -141,7 +150,8 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     constexpr int SPC = TAPS / TPS;                        // stages per chunk
     constexpr int TAPW = ROWS * COPT;                      // units per tap of a stage
     constexpr int WST = TPS * TAPW;                        // units per weight stage
-    static_assert(KX <= (STR == 2 ? 20 : kPfXS), "patch too large for two patch waves");
+    static_assert(UF != 0 || KX <= (STR == 2 ? 20 : kPfXS), "patch too large for two patch waves");
+    static_assert(UF == 0 || (UF == 3 && KH == 7 && KW == 1 && STR == 1 && TZ == 1 && NPB == 2), "UF: the 7x1 form of the first layer");
     static_assert(STR == 1 || (STR == 2 && KH == 3 && KW == 3), "stride 2 is the 3x3 Downsample form");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
 #ifdef CDC_TIMELINE
@@ -312,7 +322,47 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
 
     // ---- prologue: patches of the first LA chunks, weight stages 0 .. R-2 -------------------------------------
     PFTL(0);
-    if (patch_wave) {
+    if constexpr (UF != 0) {
+        // weight stages first: they fly while the workgroup builds its two patch buffers from the image
+        if (!patch_wave)
+            for (int q = 0; q < R - 1 && q < S; ++q) issue_w();
+        constexpr int XW = NBW + 6;                      // staged image columns: the tile's 32 and three on either side
+        float *xs = reinterpret_cast<float *>(smem_u + NPB * PST + R * WST);      // [UF][PH][XW], behind the ring
+        {   // (all loads first, then the LDS writes: one exposed latency instead of one per element)
+            constexpr int NS = (UF * PH * XW + NT - 1) / NT;
+            float sv[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = tid + k * NT;
+                const int ci = i / (PH * XW), rem = i - ci * (PH * XW), r = rem / XW, cc = rem - r * XW;
+                const int iy = oy0 - 3 + r, ix = ox0 - 3 + cc;
+                sv[k] = (i < UF * PH * XW && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? P.x0[(size_t)b * P.x0_bs + ((size_t)ci * P.H + iy) * P.W + ix] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (tid + k * NT < UF * PH * XW) xs[tid + k * NT] = sv[k];
+        }
+        __syncthreads();
+        // one thread = one pixel of the patch: its 7 x UF image values once, then the four units (chunk, k-half) of both planes
+        for (int px = tid; px < PLANE; px += NT) {
+            const int r = px / PW, c = px - r * PW;
+            _Float16 hq[32], lq[32];
+#pragma unroll
+            for (int ch = 0; ch < 32; ++ch) {                  // unfolded channel kx * UF + ci = image channel ci at column x + kx - 3
+                if (ch < 7 * UF) split2h(xs[((ch % UF) * PH + r) * XW + c + ch / UF], hq[ch], lq[ch]);
+                else { hq[ch] = (_Float16)0.f; lq[ch] = (_Float16)0.f; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                      // q = chunk * 2 + k-half: channels 8 q .. 8 q + 7
+                f16x8 hv, lv;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { hv[t] = hq[8 * q + t]; lv[t] = lq[8 * q + t]; }
+                uint4 *pbuf = smem_u + (q >> 1) * PST + ((q & 1) * 2) * PLANE + px;
+                pbuf[0] = __builtin_bit_cast(uint4, hv);
+                pbuf[PLANE] = __builtin_bit_cast(uint4, lv);
+            }
+        }
+    } else if (patch_wave) {
         for (int c = 0; c < LA && c < P.nchunk; ++c) issue_patch(c, std::integral_constant<int, -1>{});
     } else {
         for (int q = 0; q < R - 1 && q < S; ++q) issue_w();
@@ -341,7 +391,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                 fetch(std::integral_constant<int, t + 1>{}, xb_cur, a_base + sn * WST + ((t + 1) % TPS) * TAPW, An, Bn);
             if (patch_wave) {
                 if constexpr (t < ISSUE_TAPS)
-                    if (chunk + LA < P.nchunk && !(CDC_PF_ABLATE && (P.dbg & 2))) issue_patch(chunk + LA, tc);
+                    if (UF == 0 && chunk + LA < P.nchunk && !(CDC_PF_ABLATE && (P.dbg & 2))) issue_patch(chunk + LA, tc);
             }
         } else {
         if (!(TAIL && t == TAPS - 1) || rem > 0) {        // (the very last tap has nothing left to fetch)
@@ -368,7 +418,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
             else fetch(std::integral_constant<int, t + 1>{}, xb_cur, wa, An, Bn);
             if (patch_wave) {
                 if constexpr (t < ISSUE_TAPS)
-                    if (chunk + LA < P.nchunk && !(CDC_PF_ABLATE && (P.dbg & 2))) issue_patch(chunk + LA, tc);
+                    if (UF == 0 && chunk + LA < P.nchunk && !(CDC_PF_ABLATE && (P.dbg & 2))) issue_patch(chunk + LA, tc);
             } else if ((!TAIL || rem >= R - 1) && !(CDC_PF_ABLATE && (P.dbg & 1))) {
                 issue_w();                                // slot (s-1) % R: its readers passed the barrier above
             }

@@ -309,6 +309,9 @@ def test_unet_forward_matches_reference_golden(name):
                                       # planes-only ResnetBlock-chain outputs, residual read from planes (small launches forced onto conv_pf_kernel)
                                       ("full_x", {"CDC_PF_MIN_WAVES": "1"}), ("full_eps", {"CDC_PF_MIN_WAVES": "1"}), ("small_x", {"CDC_PF_MIN_WAVES": "1"}),
                                       ("full_x", {"CDC_NO_RESID_PF": "1"}), ("full_x", {"CDC_NO_PF_SKIP_PLANES": "1"}),
+                                      # the first layer on conv_pf_kernel's UF form (patch buffers built from the 3-channel image)
+                                      ("full_x", {"CDC_PF_UF_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_UF_MIN_WGS": "1"}), ("small_x", {"CDC_PF_UF_MIN_WGS": "1"}),
+                                      ("odd_x", {"CDC_PF_UF_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_UF": "1"}),
                                       ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_NO_RESID2": "1"}),     # downs.1.0: concatenated residual materialised again
                                       # ... and planes-only skips (Downsample and decoder join both on plane operands)
                                       ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_PF_S2_MIN_WGS": "1", "CDC_PF_TZ_MIN_WGS": "1"}),

@@ -20,4 +20,4 @@ import json; d=json.loads(open('$OUT/bench_$tag.json').read().strip().splitlines
 }
 run_bench new CDC_X=0
 run_bench old CDC_DEV=1 ${OLD_ENV:-CDC_NO_RESID_PF=1}
-grep -E "resP|nof32" $OUT/per_op_new.txt | head -24
+grep -E "7x1|7x7" $OUT/per_op_new.txt $OUT/per_op_old.txt | head
