@@ -67,6 +67,8 @@ bool pw_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
 hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long long dst_bs, int C, int H, int W, int B,
                           hipStream_t st);
+// fp32 NCHW -> [B][C / 4][HW][4] (PfArgs::pre_c4)
+hipError_t c4_pack_launch(const float *src, long long src_bs, float *dst, int C, long long HW, int B, hipStream_t st);
 // PF -> fp32 NCHW (cdc_unet_tap of a planes-only tensor)
 hipError_t pf_unpack_launch(const void *src, long long src_bs, float *dst, long long dst_bs, int C, int H, int W, int B, hipStream_t st);
 

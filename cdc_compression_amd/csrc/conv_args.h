@@ -127,6 +127,7 @@ struct PfArgs {
     int xcd_remap;
     // epilogue (same meaning as ConvArgs)
     const float *bias, *pre_add, *ep_g, *ep_b;
+    int pre_c4;                     // conv_pf_kernel: pre_add is stored in accumulator order, [B][Cout / 4][Ho * Wo][4] (16-byte loads; c4_pack_kernel)
     float eps;
     int relu;
     float relu_slope;

@@ -282,6 +282,24 @@ hipError_t pf_pack_launch(const float *src, long long src_bs, void *dst, long lo
     return hipGetLastError();
 }
 
+// fp32 NCHW -> accumulator order [B][C / 4][HW][4] (a hoisted partial-sum tensor read by conv_pf_kernel's epilogue with 16-byte loads)
+__global__ void __launch_bounds__(256) c4_pack_kernel(const float *src, long long src_bs, float4 *dst, int C, long long HW) {
+    const int b = blockIdx.y;
+    const long long n = (long long)(C / 4) * HW;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long pix = i % HW, g = i / HW;
+    const float *sp = src + (size_t)b * src_bs + (size_t)g * 4 * HW + pix;
+    dst[(size_t)b * n + i] = make_float4(sp[0], sp[HW], sp[2 * HW], sp[3 * HW]);
+}
+
+hipError_t c4_pack_launch(const float *src, long long src_bs, float *dst, int C, long long HW, int B, hipStream_t st) {
+    const long long n = (long long)(C / 4) * HW;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(c4_pack_kernel, grid, dim3(256), 0, st, src, src_bs, reinterpret_cast<float4 *>(dst), C, HW);
+    return hipGetLastError();
+}
+
 // PF -> fp32 NCHW: a = h + l' 2^-11 (interior only).  One thread = one unit pair.
 __global__ void __launch_bounds__(256) pf_unpack_kernel(const uint4 *src, long long src_bs, float *dst, long long dst_bs, int C, int H, int W) {
     const int b = blockIdx.y;

@@ -502,7 +502,18 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
             for (int r = 0; r < 16; ++r)
                 acc[m][n][r] = (ACC2 ? acc[m][n][r] + acc2[ACC2 ? m : 0][ACC2 ? n : 0][r] * (1.0f / 2048.0f) : acc[m][n][r]) * P.acc_scale +
                                epl[m * 32 + (r & 3) + 8 * (r >> 2)];
-        if (P.pre_add && valid_v[n]) {
+        if (P.pre_add && P.pre_c4 && valid_v[n]) {
+            // hoisted partial sums in accumulator order: the lane's 4 consecutive channels of a group are one 16-byte load
+            const size_t hw = (size_t)P.Ho * P.Wo;
+            const float4 *p4 = reinterpret_cast<const float4 *>(P.pre_add) + ((size_t)b * (P.Cout >> 2) + (cobase >> 2) + half) * hw + (size_t)oy * P.Wo + ox;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = p4[(size_t)(m * 8 + 2 * g) * hw];
+                    acc[m][n][4 * g] += v.x; acc[m][n][4 * g + 1] += v.y; acc[m][n][4 * g + 2] += v.z; acc[m][n][4 * g + 3] += v.w;
+                }
+        } else if (P.pre_add && valid_v[n]) {
             const float *pp = P.pre_add + (size_t)b * P.out_bs + pix_v[n] + (size_t)(cobase + 4 * half) * P.out_cs;
 #pragma unroll
             for (int m = 0; m < MB; ++m)

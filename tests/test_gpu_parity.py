@@ -312,6 +312,8 @@ def test_unet_forward_matches_reference_golden(name):
                                       # the first layer on conv_pf_kernel's UF form (patch buffers built from the 3-channel image)
                                       ("full_x", {"CDC_PF_UF_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_UF_MIN_WGS": "1"}), ("small_x", {"CDC_PF_UF_MIN_WGS": "1"}),
                                       ("odd_x", {"CDC_PF_UF_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_UF": "1"}),
+                                      # hoisted partial sums in accumulator order (16-byte loads in conv_pf_kernel's epilogue) on / off
+                                      ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_PF_UF_MIN_WGS": "1"}), ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_NO_PRE_C4": "1"}),
                                       ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_NO_RESID2": "1"}),     # downs.1.0: concatenated residual materialised again
                                       # ... and planes-only skips (Downsample and decoder join both on plane operands)
                                       ("full_x", {"CDC_PF_MIN_WAVES": "1", "CDC_PF_S2_MIN_WGS": "1", "CDC_PF_TZ_MIN_WGS": "1"}),

@@ -20,4 +20,4 @@ import json; d=json.loads(open('$OUT/bench_$tag.json').read().strip().splitlines
 }
 run_bench new CDC_X=0
 run_bench old CDC_DEV=1 ${OLD_ENV:-CDC_NO_RESID_PF=1}
-grep -E "7x1|7x7" $OUT/per_op_new.txt $OUT/per_op_old.txt | head
+grep -E "7x1| 128->192 | 192->256 " $OUT/per_op_new.txt $OUT/per_op_old.txt | grep -v "HOIST" | cut -c1-150 | head -12
