@@ -174,6 +174,9 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         // against 0.038 -- the threshold sits between the two)
         static const double min_waves = dev_env("CDC_PF_MIN_WAVES") ? atof(dev_env("CDC_PF_MIN_WAVES")) : 256.0;
         if (wgs * NW < min_waves) continue;
+        // (the 4-row 192-channel shape exists to fill the chip at batch 32; at batch 1 its 32 workgroups lose to the register-staged
+        //  kernel with split-K: 192 -> 192 @64^2 0.054 against 0.032 ms)
+        if (c.MB == 3 && c.NPW == 1 && wgs < 128.0) continue;
         const double fill = std::min(1.0, wgs * NW / 2048.0);
         const double reads = (3.0 * c.MB + 2.0 * c.NPW) / (3.0 * c.MB * c.NPW);   // ds_read_b128 per MFMA
         const double score = fill * (1.0 - 0.35 * reads) * (s.Cout / COPT > 1 ? 0.9 : 1.0);
