@@ -31,6 +31,7 @@ static pf_kernel_fn pf_lookup_s2(int MB, int NPW, int WM, int WP) {
 // fused-phase transposed form (TZ = 4): one 32-channel block x two pixel rows per wave, four accumulator sets
 static pf_kernel_fn pf_lookup_tz(int MB, int NPW, int WM, int WP) {
     if (MB == 1 && NPW == 2 && WM == 2 && WP == 2) return conv_pf_kernel<1, 2, 2, 2, 2, 2, 1, 4>;
+    if (MB == 2 && NPW == 1 && WM == 1 && WP == 4) return conv_pf_kernel<2, 1, 1, 4, 2, 2, 1, 4>;      // all 64 channels in a wave: in-lane LayerNorm
     if (MB == 1 && NPW == 2 && WM == 4 && WP == 2) return conv_pf_kernel<1, 2, 4, 2, 2, 2, 1, 4>;
     return nullptr;
 }
@@ -54,7 +55,10 @@ static const PfCand kCandsS2[] = {
 };
 static const PfCand kCandsTZ[] = {
     {1, 2, 4, 2},   // 128 channels, 8 waves, 4 input rows
-    {1, 2, 2, 2},   //  64 channels, 4 waves, 4 input rows
+    // 64 channels, 4 waves, 4 input rows: every wave holds all 64 channels of one input row (8 ds_read_b128 per 6 MFMAs instead of
+    // 5.25, but the fused LayerNorm stays inside the lane: no cross-wave exchange, three barriers fewer): 0.41 -> 0.38 ms against ...
+    {2, 1, 1, 4},
+    {1, 2, 2, 2},   // ... two channel parts x two row pairs (kept for CDC_PF_PLAN=1,2,2,2)
 };
 static const PfCand kCands[] = {
     {2, 2, 4, 2},   // 256 channels, 8 waves, 4 rows
@@ -98,7 +102,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
     }
     if (s.Cout % 32 || s.Cin % 16 || (s.C0 % 16)) return false;
     if (s.Wo < 32) return false;                              // 32-pixel blocks are rows of the image (lognbw = 5)
-    static const char *force = dev_env("CDC_PF_PLAN");         // tuning aid: "MB,NPW,WM,WP"
+    const char *force = dev_env("CDC_PF_PLAN");                // tuning aid: "MB,NPW,WM,WP" (read per call: the tests switch it)
     int f[4] = {0, 0, 0, 0};
     if (force) sscanf(force, "%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3]);
     double best = -1;

@@ -215,8 +215,10 @@ PF_TZ_CASES = [  # B, Cin, H, W, Cout: ConvTranspose2d 4x4 / stride 2 / pad 1 wi
 ]
 
 
-@pytest.mark.parametrize("case", PF_TZ_CASES)
-def test_conv_transpose2d_fused_phases_on_plane_operands(O, case, monkeypatch):
+@pytest.mark.parametrize("case,plan", [(c, None) for c in PF_TZ_CASES] + [(PF_TZ_CASES[0], "1,2,2,2"), (PF_TZ_CASES[2], "1,2,2,2")])
+def test_conv_transpose2d_fused_phases_on_plane_operands(O, case, plan, monkeypatch):
+    if plan:
+        monkeypatch.setenv("CDC_PF_PLAN", plan)           # the other 64-channel wave shape (two channel parts x two row pairs)
     monkeypatch.setenv("CDC_PF", "1")
     monkeypatch.setenv("CDC_PF_MAXPIX", "0")
     monkeypatch.setenv("CDC_PF_TZ_MIN_WGS", "1")
