@@ -55,6 +55,7 @@ struct PfShape {
 };
 struct PfPlan {
     int MB, NPW, WM, WP, ring, tiles_x, tiles_y, groups; size_t lds_bytes; int lin = 0;
+    int x16 = 0;                                    // conv_pw_kernel: activations by 16-byte LDS-DMA (W % 4 == 0)
     int pf3_epv = 0, pf3_G = 0, pf3_iters = 0;      // != 0: conv_pf3_kernel (conv_pf3_kernel.h) runs the layer
 };
 bool pf_make_plan(const PfShape &s, PfPlan *plan);

@@ -9,7 +9,14 @@
 namespace cdc {
 
 typedef void (*pw_kernel_fn)(const PfArgs);
-static pw_kernel_fn pw_lookup(int MB, int NPW, int WM, int WP) {
+static pw_kernel_fn pw_lookup(int MB, int NPW, int WM, int WP, bool x16 = false) {
+    if (x16) {      // activations by 16-byte LDS-DMA (conv_pw_kernel.h, X16)
+        if (MB == 2 && NPW == 2 && WM == 1 && WP == 4) return conv_pw_kernel<2, 2, 1, 4, true>;
+        if (MB == 2 && NPW == 2 && WM == 2 && WP == 2) return conv_pw_kernel<2, 2, 2, 2, true>;
+        if (MB == 2 && NPW == 2 && WM == 4 && WP == 2) return conv_pw_kernel<2, 2, 4, 2, true>;
+        if (MB == 3 && NPW == 1 && WM == 2 && WP == 4) return conv_pw_kernel<3, 1, 2, 4, true>;
+        return nullptr;
+    }
     if (MB == 2 && NPW == 2 && WM == 1 && WP == 4) return conv_pw_kernel<2, 2, 1, 4>;
     if (MB == 2 && NPW == 2 && WM == 2 && WP == 2) return conv_pw_kernel<2, 2, 2, 2>;
     if (MB == 2 && NPW == 2 && WM == 4 && WP == 2) return conv_pw_kernel<2, 2, 4, 2>;
@@ -31,12 +38,13 @@ bool pw_make_plan(const PfShape &s, PfPlan *p) {
     const bool lin = s.Wo < 32;
     if (lin && ((s.Ho * s.Wo) % 32)) return false;
     const double min_waves = dev_env("CDC_PW_MIN_WAVES") ? atof(dev_env("CDC_PW_MIN_WAVES")) : 512.0;   // (per call: tests switch it)
+    const bool x16 = (lin || ((s.Wo & 3) == 0 && s.Wo >= 4)) && !dev_env("CDC_NO_PW_X16");          // rows of 4-pixel granularity
     double best = -1;
     for (const PwCand &c : kPwCands) {
         const int COPT = c.WM * c.MB * 32, NW = c.WM * c.WP;
         if (s.Cout % COPT) continue;
         if (s.need_all_cout && COPT != s.Cout) continue;
-        const int ring = pw_ring(c.MB, c.NPW, c.WM, c.WP);
+        const int ring = pw_ring(c.MB, c.NPW, c.WM, c.WP, x16);
         if (ring < 5 || s.Cin / 16 < 2) continue;
         const int TH = c.WP * c.NPW;
         const int groups = s.Cout / COPT;
@@ -55,14 +63,15 @@ bool pw_make_plan(const PfShape &s, PfPlan *p) {
             p->tiles_x = lin ? (int)((nb + TH - 1) / TH) : (s.Wo + 31) / 32;
             p->tiles_y = lin ? 1 : (s.Ho + TH - 1) / TH;
             p->groups = groups;
-            p->lds_bytes = (size_t)ring * pf_rows(c.MB, c.NPW) * COPT * 16 + pw_x_bytes(c.NPW, c.WM, c.WP);
+            p->lds_bytes = (size_t)ring * pf_rows(c.MB, c.NPW) * COPT * 16 + pw_x_bytes(c.NPW, c.WM, c.WP, x16);
+            p->x16 = x16 ? 1 : 0;
         }
     }
     return best >= 0;
 }
 
 hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
-    pw_kernel_fn fn = pw_lookup(p.MB, p.NPW, p.WM, p.WP);
+    pw_kernel_fn fn = pw_lookup(p.MB, p.NPW, p.WM, p.WP, p.x16 != 0);
     if (!fn) return hipErrorInvalidValue;
     a.lognbw = 5;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;

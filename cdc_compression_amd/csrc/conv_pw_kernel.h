@@ -21,9 +21,15 @@
 namespace cdc {
 
 constexpr int kPwPD = 2;                            // activation stages in flight per wave
-__host__ __device__ constexpr size_t pw_x_bytes(int NPW, int WM, int WP) { return (size_t)WM * WP * kPwPD * NPW * 8 * 256; }
-__host__ __device__ constexpr int pw_ring(int MB, int NPW, int WM, int WP) {
-    const size_t budget = (WM * WP == 8 ? 150 * 1024 : 78 * 1024) - pw_x_bytes(NPW, WM, WP);
+// X16 (round 4): the activations of a 16-channel chunk and 32-pixel block arrive as TWO 16-byte LDS-DMA instructions (lane = 4 pixels
+// of one of 8 channel rows: 1 KiB each, the k-halves 32 floats apart so that the two halves of a wave read different banks) instead of
+// eight 4-byte ones -- the wave's LDS-DMA issue was what bounded the kernel.  Needs rows of 4-pixel granularity (W % 4 == 0).
+constexpr int kPwX16N = 2 * 256 + 32;               // floats per block and stage in the X16 layout
+__host__ __device__ constexpr size_t pw_x_bytes(int NPW, int WM, int WP, bool X16 = false) {
+    return (size_t)WM * WP * kPwPD * NPW * (X16 ? kPwX16N * 4 : 8 * 256);
+}
+__host__ __device__ constexpr int pw_ring(int MB, int NPW, int WM, int WP, bool X16 = false) {
+    const size_t budget = (WM * WP == 8 ? 150 * 1024 : 78 * 1024) - pw_x_bytes(NPW, WM, WP, X16);
     const size_t wst = (size_t)pf_rows(MB, NPW) * WM * MB * 32 * 16;
     const int r = (int)(budget / wst);
     return r > 6 ? 6 : r;
@@ -34,7 +40,7 @@ __device__ __forceinline__ void dma4(unsigned voff, const void *sbase, unsigned 
                  : "memory");
 }
 
-template <int MB, int NPW, int WM, int WP>
+template <int MB, int NPW, int WM, int WP, bool X16 = false>
 __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_kernel(const PfArgs P) {
     constexpr int NW = WM * WP, NT = 64 * NW, COPT = WM * MB * 32;
     static_assert(COPT % 64 == 0, "a weight DMA instruction (64 units) must stay inside one (plane, k-half) row");
@@ -43,7 +49,7 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
     constexpr int WI = ROWS * COPT / 64;                // DMA instructions per weight stage
     constexpr int NWW = (WI + NW - 1) / NW;             // ... per wave (every wave issues)
     constexpr int WST = ROWS * COPT;                    // units per weight stage
-    constexpr int R = pw_ring(MB, NPW, WM, WP);
+    constexpr int R = pw_ring(MB, NPW, WM, WP, X16);
     static_assert(R >= 5, "no room for the weight ring");
     constexpr int TH = WP * NPW;
     constexpr int PD = kPwPD;                           // activation stages in flight
@@ -89,6 +95,7 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
     const int half = lane >> 5, j = lane & 31;
     const int HW = P.H * P.W;
     unsigned xvo[NPW];                                  // byte offset of the lane's (k-half, pixel) inside a 16-channel chunk
+                                                        // (X16: of the lane's (channel row lane >> 3, pixel quad lane & 7) inside a k-half)
     float mu[NPW];
     bool valid[NPW];
     unsigned pixo[NPW];
@@ -109,11 +116,22 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
             pixo[n] = (unsigned)(min(oy, P.Ho - 1) * P.W + min(ox, P.Wo - 1));
         }
         xvo[n] = ((unsigned)(8 * half) * (unsigned)HW + pixo[n]) * 4u;
+        if constexpr (X16) {
+            // quad q of the block's 32 pixels (clamped into the row: Wo % 4 == 0), channel row r of the k-half
+            const int r = lane >> 3, q = lane & 7;
+            unsigned p4;
+            if (P.lin) p4 = pixo[n] - (unsigned)j + 4u * q;
+            else {
+                const int oy = oy0 + wp * NPW + n;
+                p4 = (unsigned)(min(oy, P.Ho - 1) * P.W + min(ox0 + 4 * q, P.Wo - 4));
+            }
+            xvo[n] = ((unsigned)r * (unsigned)HW + p4) * 4u;
+        }
         mu[n] = P.pre_mean ? P.pre_mean[(size_t)bimg[n] * HW + pixo[n]] : 0.f;
     }
     const int c0_chunks = P.C0 >> 4;
-    constexpr int L = 8 * NPW;                          // activation pieces per step and wave
-    constexpr int XST = NPW * 8 * 64;                   // floats per activation stage of one wave
+    constexpr int L = (X16 ? 2 : 8) * NPW;              // activation pieces per step and wave
+    constexpr int XST = X16 ? NPW * kPwX16N : NPW * 8 * 64;   // floats per activation stage of one wave
     float *xw = reinterpret_cast<float *>(smem_u + R * WST) + wave * (PD * XST);    // this wave's private stages
     const unsigned xw_lds = lds0 + (unsigned)(R * WST) * 16u + (unsigned)(wave * (PD * XST)) * 4u;
     auto issue_x = [&](int c, int slot) {               // stage layout [n][i][lane]
@@ -123,8 +141,13 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
             const float *src = c < c0_chunks ? P.x0 + (size_t)bimg[n] * P.x0_bs + (size_t)c * 16 * HW
                                              : P.x1 + (size_t)bimg[n] * P.x1_bs + (size_t)(c - c0_chunks) * 16 * HW;
             const char *base = reinterpret_cast<const char *>(uniform_ptr(src));
+            if constexpr (X16) {        // k-half h: channels 8 h .. 8 h + 7 as one instruction, [row][32 pixels], 32 floats behind half 0's
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) dma16(xvo[n], base + (size_t)(8 * hh) * HW * 4, dst + (unsigned)(n * kPwX16N + hh * (256 + 32)) * 4u);
+            } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) dma4(xvo[n], base + (size_t)i * HW * 4, dst + (unsigned)((n * 8 + i) * 64) * 4u);
+            }
         }
     };
 
@@ -148,13 +171,13 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
             for (int m = 0; m < MB; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa[(pl * 2) * COPT + m * 32]);
     };
     auto split_b = [&](int slot, OpsB &Bv) {           // the wave's own stage -> the two fp16 planes
-        const float *src = xw + slot * XST + lane;
+        const float *src = xw + slot * XST + (X16 ? half * (256 + 32) + j : lane);
 #pragma unroll
         for (int n = 0; n < NPW; ++n)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 _Float16 hq, lq;
-                split2h(src[(n * 8 + i) * 64] - mu[n], hq, lq);
+                split2h((X16 ? src[n * kPwX16N + i * 32] : src[(n * 8 + i) * 64]) - mu[n], hq, lq);
                 Bv[0][n][i] = hq; Bv[1][n][i] = lq;
             }
     };

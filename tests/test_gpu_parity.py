@@ -171,6 +171,18 @@ PW_CASES = [  # B, Cin, H, W, Cout: every tile shape of conv_pw_kernel's planner
     (3, 320, 16, 16, 128), (4, 384, 8, 8, 256), (1, 48, 12, 16, 64)]
 
 
+def test_conv2d_pointwise_kernel_4_byte_activation_pieces(O, monkeypatch):
+    """conv_pw_kernel's older activation path (eight 4-byte LDS-DMA pieces per chunk and block; the default is two 16-byte ones)."""
+    monkeypatch.setenv("CDC_PW_MIN_WAVES", "1")
+    monkeypatch.setenv("CDC_NO_PW_X16", "1")
+    G2 = Ops(0)
+    for (B, Ci, H, W, Co) in [(2, 64, 36, 64, 64), (3, 320, 16, 16, 128), (1, 64, 40, 96, 384)]:
+        x = synth.normal("px", (B, Ci, H, W), 25)
+        w = synth.normal("pw", (Co, Ci, 1, 1), 25, 1.0 / np.sqrt(Ci))
+        b = synth.normal("pb", (Co,), 25, 0.1)
+        assert relerr(G2.conv2d(x, w, b, 1, 0), O.conv2d(x, w, b, 1, 0)) < 1e-5
+
+
 @pytest.mark.parametrize("case", PW_CASES)
 def test_conv2d_pointwise_kernel(O, case, monkeypatch):
     """conv_pw_kernel (1x1, activations staged per wave straight from the fp32 tensor), forced also for small launches;
