@@ -1,6 +1,9 @@
 // conv_inst_w.hip -- instantiations, plan chooser and launcher of conv_pw_kernel (pointwise convolution, activations
 // staged per wave by 4-byte LDS-DMA from the fp32 tensor).
 #include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
 #include <stdlib.h>
 
 #include "cdc_internal.h"
@@ -82,7 +85,39 @@ hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
     a.lin = p.lin;
     dim3 grid((unsigned)(p.lin ? p.tiles_x : p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
     a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+#ifdef CDC_TIMELINE
+    // Development build only: cycle categories per workgroup (see pf_launch)
+    static unsigned long long *tl_dev = nullptr;
+    static std::map<std::string, int> seen;
+    const size_t tl_wgs = (size_t)grid.x * grid.y;
+    char key[96];
+    snprintf(key, sizeof key, "pw 1x1 %d->%d out %dx%d", a.Cin, a.Cout, a.Ho, a.Wo);
+    a.tl = nullptr;
+    if (tl_wgs <= (1u << 18) && seen[key]++ < 2) {
+        if (!tl_dev) hipMalloc(&tl_dev, sizeof(unsigned long long) * 16 * (1u << 18));
+        hipMemsetAsync(tl_dev, 0, sizeof(unsigned long long) * 16 * tl_wgs, st);
+        a.tl = tl_dev;
+    }
+#endif
     hipLaunchKernelGGL(fn, grid, dim3(64 * p.WM * p.WP), p.lds_bytes, st, a);
+#ifdef CDC_TIMELINE
+    if (a.tl) {
+        hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(16 * tl_wgs);
+        hipMemcpy(h.data(), tl_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        double cat[7] = {0}, life = 0;
+        for (size_t w = 0; w < tl_wgs; ++w) {
+            const unsigned long long *r = &h[w * 16];
+            for (int c = 0; c < 7; ++c) cat[c] += (double)r[c];
+            life += (double)(r[8] - r[7]);
+        }
+        static const char *names[7] = {"setup", "prologue issue", "prologue wait", "main loop", "epilogue parameters", "-", "epilogue blocks"};
+        fprintf(stderr, "[pf timeline] conv %s: %zu workgroups x %d threads, lds %zu; mean workgroup life %.0f; per workgroup (wave 0):", key, tl_wgs, 64 * p.WM * p.WP, p.lds_bytes,
+                life / tl_wgs);
+        for (int c = 0; c < 7; ++c) fprintf(stderr, "  %s %.0f", names[c], cat[c] / tl_wgs);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -54,6 +54,10 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
     constexpr int TH = WP * NPW;
     constexpr int PD = kPwPD;                           // activation stages in flight
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+#ifdef CDC_TIMELINE
+    unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_readcyclecounter();      // categories as in conv_pf_kernel
+    const unsigned long long tl_start = tl_last;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WP, wp = wave % WP;
@@ -210,12 +214,15 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
     };
 
     // ---- prologue: activations of steps 0 .. PD-1, weight stages 0 .. R-2 ----------------------------------------
+    PFTL(0);
 #pragma unroll
     for (int d = 0; d < PD; ++d)
         if (d < S) issue_x(d, d);
     for (int q = 0; q < R - 1 && q < S; ++q) issue_w();
+    PFTL(1);
     dma_wait();                                         // prologue: everything, once
     __builtin_amdgcn_s_barrier();
+    PFTL(2);
     OpsA A0, A1;
     OpsB B0, B1;
     fetch_a(a_base, A0);
@@ -255,6 +262,7 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_barrier();                         // every wave is done with the ring
+    PFTL(3);
     float *ep = reinterpret_cast<float *>(smem_u);        // [2][COPT]: bias, shift
     for (int i = tid; i < COPT; i += NT) {
         const int co = cog * COPT + i;
@@ -263,6 +271,7 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
         ep[COPT + i] = (ok && P.shift) ? P.shift[(size_t)b * P.shift_bs + co] : 0.f;
     }
     __syncthreads();
+    PFTL(4);
     const int cobase = cog * COPT + wm * MB * 32;
     const float *epl = ep + wm * MB * 32 + 4 * half;
     const bool ch_ok = cobase + MB * 32 <= P.Cout;        // host: Cout % (MB*32) == 0 per wave part
@@ -328,6 +337,8 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
                 pf_store_block(reinterpret_cast<uint4 *>(P.out_pf), u0 + (long long)((cobase >> 3) + m * 4) * 2 * P.pf_ps, P.pf_ps, half, acc[m][n]);
         }
     }
+    PFTL(6);                                              // (development build: the whole per-block epilogue loop counts as "stores")
+    PFTL_END();
 }
 
 }  // namespace cdc
