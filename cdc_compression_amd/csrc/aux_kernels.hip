@@ -195,8 +195,148 @@ __global__ void __launch_bounds__(256) ln_kernel_sliced(const LnArgs a) {
     }
 }
 
+// The same pass on 16-byte accesses (round 4; HW % 4 == 0): COLS float4 columns = 4 COLS pixels x CS = 256 / COLS channel slices per
+// workgroup.  A 16 x 16 or 8 x 8 level is a latency chain, not a bandwidth problem (60 MB / 16 MB per launch): one quarter of the
+// load instructions (all of a thread's loads fit the 64-deep vector-memory queue of its wave: one round trip instead of three), the
+// residual and the per-channel parameters fetched in that same round trip instead of after the statistics, and the cross-slice sums as
+// an in-wave butterfly + 4 LDS values instead of CS LDS reads per thread.
+template <int COLS, int NP>
+__global__ void __launch_bounds__(256) ln_kernel_vec(const LnArgs a) {
+    constexpr int CS = 256 / COLS, NV = 8 * kLnCache / CS;
+    __shared__ float4 red[2][4][COLS];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int col = tid % COLS, cs = tid / COLS, wave = tid >> 6;
+    const int p = (blockIdx.x * COLS + col) * 4;
+    const bool pv = p < a.HW;
+    const size_t base = (size_t)b * a.C * a.HW + (pv ? p : 0);
+    const float *x = a.in + base;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 t[NP][NV], rv[NV];
+    float gv[NV], bv[NV], sv[NV];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)                      // split-K slices of the producing convolution
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = cs + CS * i;
+            t[k][i] = (pv && c < a.C) ? *reinterpret_cast<const float4 *>(x + (size_t)k * a.part_stride + (size_t)c * a.HW) : zero4;
+        }
+    const float *r = (a.out && a.resid) ? a.resid + base : nullptr;
+    const float *sh = (a.out && a.shift) ? a.shift + (size_t)b * a.shift_bs : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = cs + CS * i;
+        const bool ok = c < a.C && a.out;
+        rv[i] = (r && pv && ok) ? *reinterpret_cast<const float4 *>(r + (size_t)c * a.HW) : zero4;
+        gv[i] = ok ? a.g[c] : 0.f;
+        bv[i] = ok ? a.b[c] : 0.f;
+        sv[i] = (sh && ok) ? sh[c] : 0.f;
+    }
+    auto wg_sum = [&](float4 s, int slot) {
+#pragma unroll
+        for (int o = COLS; o < 64; o <<= 1) {
+            s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
+        }
+        if ((tid & 63) < COLS) red[slot][wave][col] = s;
+        __syncthreads();
+        float4 q = red[slot][0][col];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 u = red[slot][w][col]; q.x += u.x; q.y += u.y; q.z += u.z; q.w += u.w; }
+        return q;
+    };
+    float4 v[NV], s = zero4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = t[0][i];
+#pragma unroll
+        for (int k = 1; k < NP; ++k) { v[i].x += t[k][i].x; v[i].y += t[k][i].y; v[i].z += t[k][i].z; v[i].w += t[k][i].w; }   // slice 0, 1, 2, ...
+        s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w;
+    }
+    const float inv_c = 1.0f / (float)a.C;
+    float4 mean = wg_sum(s, 0);
+    mean.x *= inv_c; mean.y *= inv_c; mean.z *= inv_c; mean.w *= inv_c;
+    float4 q = zero4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (cs + CS * i < a.C) {
+            const float dx = v[i].x - mean.x, dy = v[i].y - mean.y, dz = v[i].z - mean.z, dw = v[i].w - mean.w;
+            q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+        }
+    float4 var = wg_sum(q, 1);
+    var.x *= inv_c; var.y *= inv_c; var.z *= inv_c; var.w *= inv_c;
+    if (a.fault && !(var.x < 3.0e38f && var.y < 3.0e38f && var.z < 3.0e38f && var.w < 3.0e38f)) *a.fault = 1;   // range guard (ConvArgs::fault)
+    if (!a.out) {
+        if (pv && cs == 0) {
+            *reinterpret_cast<float4 *>(a.stat_mean + (size_t)b * a.HW + p) = mean;
+            *reinterpret_cast<float4 *>(a.stat_rstd + (size_t)b * a.HW + p) =
+                make_float4(1.0f / sqrtf(var.x + a.eps), 1.0f / sqrtf(var.y + a.eps), 1.0f / sqrtf(var.z + a.eps), 1.0f / sqrtf(var.w + a.eps));
+        }
+        return;
+    }
+    const float4 den = make_float4(sqrtf(var.x + a.eps), sqrtf(var.y + a.eps), sqrtf(var.z + a.eps), sqrtf(var.w + a.eps));
+    float *y = a.out + base;
+    float4 s2 = zero4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = cs + CS * i;
+        if (c < a.C) {
+            float4 w;
+            w.x = (v[i].x - mean.x) / den.x * gv[i] + bv[i];
+            w.y = (v[i].y - mean.y) / den.y * gv[i] + bv[i];
+            w.z = (v[i].z - mean.z) / den.z * gv[i] + bv[i];
+            w.w = (v[i].w - mean.w) / den.w * gv[i] + bv[i];
+            if (a.relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+            if (sh) { w.x += sv[i]; w.y += sv[i]; w.z += sv[i]; w.w += sv[i]; }
+            if (r) { w.x += rv[i].x; w.y += rv[i].y; w.z += rv[i].z; w.w += rv[i].w; }
+            if (pv) *reinterpret_cast<float4 *>(y + (size_t)c * a.HW) = w;
+            v[i] = w;
+            s2.x += w.x; s2.y += w.y; s2.z += w.z; s2.w += w.w;
+        } else {
+            v[i] = zero4;
+        }
+    }
+    if (a.stat_mean) {
+        float4 m2 = wg_sum(s2, 0);
+        m2.x *= inv_c; m2.y *= inv_c; m2.z *= inv_c; m2.w *= inv_c;
+        float4 q2 = zero4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (cs + CS * i < a.C) {
+                const float dx = v[i].x - m2.x, dy = v[i].y - m2.y, dz = v[i].z - m2.z, dw = v[i].w - m2.w;
+                q2.x += dx * dx; q2.y += dy * dy; q2.z += dz * dz; q2.w += dw * dw;
+            }
+        const float4 v2 = wg_sum(q2, 1);
+        if (pv && cs == 0) {
+            *reinterpret_cast<float4 *>(a.stat_mean + (size_t)b * a.HW + p) = m2;
+            *reinterpret_cast<float4 *>(a.stat_rstd + (size_t)b * a.HW + p) =
+                make_float4(1.0f / sqrtf(v2.x * inv_c + a.eps), 1.0f / sqrtf(v2.y * inv_c + a.eps), 1.0f / sqrtf(v2.z * inv_c + a.eps),
+                            1.0f / sqrtf(v2.w * inv_c + a.eps));
+        }
+    }
+}
+
+template <int COLS> static void ln_vec_launch(const LnArgs &a, dim3 grid, hipStream_t st) {
+    switch (a.nparts) {
+        case 1: hipLaunchKernelGGL((ln_kernel_vec<COLS, 1>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((ln_kernel_vec<COLS, 2>), grid, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((ln_kernel_vec<COLS, 3>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((ln_kernel_vec<COLS, 4>), grid, dim3(256), 0, st, a); break;
+    }
+}
+
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
+    if (a.C <= 8 * kLnCache && a.nparts >= 1 && a.nparts <= 4 && (a.HW & 3) == 0 && (a.part_stride & 3) == 0 &&
+        ((((uintptr_t)a.in) | ((uintptr_t)a.out) | ((uintptr_t)a.resid) | ((uintptr_t)a.stat_mean) | ((uintptr_t)a.stat_rstd)) & 15) == 0 &&
+        !dev_env("CDC_NO_LN_VEC")) {
+        const long long min_wgs = dev_env("CDC_LN_MIN_WGS") ? atoll(dev_env("CDC_LN_MIN_WGS")) : 256;
+        int cols = (long long)ceil_div(a.HW, 32) * B >= min_wgs ? 8 : ((long long)ceil_div(a.HW, 16) * B >= min_wgs ? 4 : 2);
+        if (const char *e = dev_env("CDC_LN_VEC_COLS")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) cols = v; }
+        const dim3 grid((unsigned)ceil_div(a.HW, 4 * cols), (unsigned)B);
+        if (cols == 8) ln_vec_launch<8>(a, grid, st);
+        else if (cols == 4) ln_vec_launch<4>(a, grid, st);
+        else ln_vec_launch<2>(a, grid, st);
+        return hipGetLastError();
+    }
     if (a.C <= 8 * kLnCache) {
         static const int pl8_max = dev_env("CDC_LN_PL8_MAX") ? atoi(dev_env("CDC_LN_PL8_MAX")) : 64;
         // 8-pixel workgroups also wherever 32-pixel ones would leave most of the chip idle (small batches)

@@ -251,6 +251,21 @@ def test_layernorm_matches_oracle(O, G):
     assert relerr(G.chan_layernorm(x, g, b), O.chan_layernorm(x, g, b)) < 1e-6
 
 
+@pytest.mark.parametrize("env", [{}, {"CDC_LN_VEC_COLS": "8"}, {"CDC_LN_VEC_COLS": "4"}, {"CDC_NO_LN_VEC": "1"}])
+@pytest.mark.parametrize("shape", [(2, 48, 8, 8), (3, 320, 16, 16), (2, 384, 8, 8), (1, 256, 12, 20), (33, 40, 4, 4)])
+def test_layernorm_on_16_byte_accesses(O, shape, env, monkeypatch):
+    """ln_kernel_vec (pixel counts that are multiples of 4): every column count, whole and partial workgroups, against the
+    oracle and against the 4-byte kernel it replaces."""
+    monkeypatch.setenv("CDC_DEV", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B, C, H, W = shape
+    x = synth.normal("lvx", shape, 29, 2.0, 0.5)
+    g = synth.normal("lvg", (C,), 29, 0.2, 1.0)
+    b = synth.normal("lvb", (C,), 29, 0.2)
+    assert relerr(Ops(0).chan_layernorm(x, g, b), O.chan_layernorm(x, g, b)) < 1e-6
+
+
 @pytest.mark.parametrize("case", [(2, 16, 8, 8), (1, 64, 32, 32), (2, 64, 64, 64), (1, 128, 64, 64), (2, 128, 16, 16), (1, 384, 8, 8),
                                   (1, 24, 12, 20), (1, 64, 64, 64)])
 def test_linear_attention_matches_oracle(O, G, case):
