@@ -524,7 +524,18 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
         float m = -INFINITY;
         if (d0 + r < C) {
             const float4 *r4 = reinterpret_cast<const float4 *>(kb + (size_t)(d0 + r) * N);
-            for (int n = part; n < (N >> 2); n += 4) {
+            // eight independent 16-byte loads per round trip (hipcc keeps two in flight on its own: 32 dependent round trips of
+            // ~0.8 us per 1024-pixel row, a third of the launch)
+            const int n4 = N >> 2;
+            int n = part;
+            for (; n + 28 < n4; n += 32) {
+                float4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = r4[n + 4 * u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(q[u].x, q[u].y), fmaxf(q[u].z, q[u].w)));
+            }
+            for (; n < n4; n += 4) {
                 const float4 q = r4[n];
                 m = fmaxf(m, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
             }
@@ -991,50 +1002,100 @@ __global__ void __launch_bounds__(256) ctx_r3_kernel(const float *T1, const floa
 // Both operand blocks (K x 32 floats each) are fetched with 16-byte loads, all in flight at once, into LDS; the K loop then runs
 // from LDS.  (Fetching the operands per MFMA step straight from L2 was measured slower than the FMA kernels it replaced: 192 dependent
 // 4-byte loads per wave.)
-__device__ __forceinline__ void fold_stage(float *lds, const float *src, int ld, int K) {     // lds[k][32] <- src[k * ld + 0..31]
-    const int lane = threadIdx.x, r8 = lane >> 3, c4 = (lane & 7) * 4;
-    for (int k0 = 0; k0 < K; k0 += 8)
-        *reinterpret_cast<float4 *>(lds + (k0 + r8) * 32 + c4) = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + r8) * ld + c4);
+// Staging by 16-byte LDS-DMA (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l, which is exactly lds[k0 + l / 8][4 (l % 8)]):
+// no staging registers, so every load of BOTH operand blocks is in flight at once whatever hipcc schedules.  (As register loads +
+// ds_write the staging loop came out as groups of four loads with a full wait each -- six dependent round trips per operand at C = 192 --
+// and, fully unrolled, as one load / wait / ds_write at a time: 14 - 30 us per launch for 1 - 3 us of matrix work.)
+// M0 handling as in conv_kernel.h dma_b128 (explicit wait state after the M0 write; M0 saved and restored).
+__device__ __forceinline__ void fold_dma16(const float *g, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte)) : "memory");
 }
-
-__global__ void __launch_bounds__(64) fold_r1_mfma_kernel(const float *ctxnT, const float *WoT, float *T1, int C) {
+// CT > 0: the channel count as a compile-time constant (64 / 128 / 192, the folded levels of the full-width models): straight-line code.
+template <int CT>
+__device__ __forceinline__ void fold_stage2(float *As, const float *a_src, float *Bs, const float *b_src, int ld, int K) {
+    const int lane = threadIdx.x, r8 = lane >> 3, c4 = (lane & 7) * 4;
+    const unsigned a_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)As;
+    const unsigned b_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)Bs;
+    const float *ap = a_src + (size_t)r8 * ld + c4, *bp = b_src + (size_t)r8 * ld + c4;
+    if constexpr (CT > 0) {
+#pragma unroll
+        for (int k0 = 0; k0 < CT; k0 += 8) fold_dma16(ap + (size_t)k0 * CT, a_lds + (unsigned)k0 * 128u);
+#pragma unroll
+        for (int k0 = 0; k0 < CT; k0 += 8) fold_dma16(bp + (size_t)k0 * CT, b_lds + (unsigned)k0 * 128u);
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 8) fold_dma16(ap + (size_t)k0 * ld, a_lds + (unsigned)k0 * 128u);
+        for (int k0 = 0; k0 < K; k0 += 8) fold_dma16(bp + (size_t)k0 * ld, b_lds + (unsigned)k0 * 128u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hipcc does not count these loads
+}
+template <int CT>
+__global__ void __launch_bounds__(64) fold_r1_mfma_kernel(const float *ctxnT, const float *WoT, float *T1, int Crt) {
     extern __shared__ __attribute__((aligned(16))) float fold_lds[];       // A block [C][32], B block [C][32]
+    const int C = CT > 0 ? CT : Crt;
     float *As = fold_lds, *Bs = fold_lds + C * 32;
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
-    fold_stage(As, ctxnT + (size_t)b * C * C + m0, C, C);     // A[m = d][k = e] = ctxnT[e][d]
-    fold_stage(Bs, WoT + n0, C, C);                           // B[k = e][n = c]
+    // A[m = d][k = e] = ctxnT[e][d] ; B[k = e][n = c]
+    fold_stage2<CT>(As, ctxnT + (size_t)b * C * C + m0, Bs, WoT + n0, C, C);
     __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (CT > 0) {
+#pragma unroll
+        for (int k2 = 0; k2 < CT / 2; ++k2) {
+            const int k = 2 * k2 + half;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], Bs[k * 32 + j], acc, 0, 0, 0);
+        }
+    } else {
 #pragma unroll 8
-    for (int k = half; k < C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], Bs[k * 32 + j], acc, 0, 0, 0);
+        for (int k = half; k < C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], Bs[k * 32 + j], acc, 0, 0, 0);
+    }
     float *o = T1 + (size_t)b * C * C + (size_t)(m0 + 4 * half) * C + n0 + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * C] = acc[r];
 }
 
-__global__ void __launch_bounds__(64) fold_r2_mfma_kernel(const float *T1, const float *Wq, int C, float scale, const float *ln_g,
+template <int CT>
+__global__ void __launch_bounds__(64) fold_r2_mfma_kernel(const float *T1, const float *Wq, int Crt, float scale, const float *ln_g,
                                                           float *Mt, int Cin_pad, int COP, unsigned short *Ws, int ws_f16,
                                                           const float *u, const float *b_out, float *biasB) {
     extern __shared__ __attribute__((aligned(16))) float fold_lds[];
+    const int C = CT > 0 ? CT : Crt;
     float *As = fold_lds, *Bs = fold_lds + C * 32;
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
-    fold_stage(As, Wq + m0, C, C);                            // A[m = ci][k = d] = Wq[d][ci]
-    fold_stage(Bs, T1 + (size_t)b * C * C + n0, C, C);        // B[k = d][n = c]
+    // A[m = ci][k = d] = Wq[d][ci] ; B[k = d][n = c]
+    const bool with_bias = blockIdx.y == 0;
+    float *us = fold_lds + 2 * C * 32;                       // u [C] (block row 0 only)
+    if (with_bias)
+        for (int k = lane; k < C; k += 64) us[k] = u[k];     // (u[k] fetched inside the K loop was a dependent global load per step)
+    fold_stage2<CT>(As, Wq + m0, Bs, T1 + (size_t)b * C * C + n0, C, C);
     __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float bsum = 0.f;
-    const bool with_bias = blockIdx.y == 0;
+    if constexpr (CT > 0) {
+#pragma unroll
+        for (int k2 = 0; k2 < CT / 2; ++k2) {
+            const int k = 2 * k2 + half;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], Bs[k * 32 + j], acc, 0, 0, 0);
+        }
+    } else {
 #pragma unroll 8
-    for (int k = half; k < C; k += 2) {
-        const float bv = Bs[k * 32 + j];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], bv, acc, 0, 0, 0);
-        if (with_bias) bsum += u[k] * bv;
+        for (int k = half; k < C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * 32 + j], Bs[k * 32 + j], acc, 0, 0, 0);
+    }
+    if (with_bias) {                                         // same summation order as inside the K loop: k = half, half + 2, ...
+        if constexpr (CT > 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < CT / 2; ++k2) { const int k = 2 * k2 + half; bsum += us[k] * Bs[k * 32 + j]; }
+        } else {
+            for (int k = half; k < C; k += 2) bsum += us[k] * Bs[k * 32 + j];
+        }
     }
     if (with_bias) {
         bsum += __shfl_xor(bsum, 32);
@@ -1095,10 +1156,20 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
     hipLaunchKernelGGL(ctx_r0_kernel, dim3(C, B), dim3(C * spf), sizeof(float) * (2 * nsplit + spf * C), st, S, ksum, C, nsplit,
                        Mt, M, spf, mfma ? 1 : 0);
     if (mfma) {
-        const size_t lds = sizeof(float) * 2 * C * 32;
-        hipLaunchKernelGGL(fold_r1_mfma_kernel, dim3(C / 32, C / 32, B), dim3(64), lds, st, Mt, WoT, T1, C);
-        hipLaunchKernelGGL(fold_r2_mfma_kernel, dim3(C / 32, C / 32, B), dim3(64), lds, st, T1, Wq, C, scale, ln_g, Mt, Cin_pad, COP, Ws,
-                           ws_f16, u, b_out, biasB);
+        const size_t lds = sizeof(float) * (2 * C * 32 + C);
+        const dim3 grid(C / 32, C / 32, B);
+#define CDC_FOLD_LAUNCH(CTV)                                                                                                        \
+        do {                                                                                                                        \
+            hipLaunchKernelGGL(fold_r1_mfma_kernel<CTV>, grid, dim3(64), lds, st, Mt, WoT, T1, C);                                      \
+            hipLaunchKernelGGL(fold_r2_mfma_kernel<CTV>, grid, dim3(64), lds, st, T1, Wq, C, scale, ln_g, Mt, Cin_pad, COP, Ws, ws_f16, \
+                               u, b_out, biasB);                                                                                    \
+        } while (0)
+        const bool ct = !dev_env("CDC_FOLD_RT");      // (the run-time-count form: A/B and the other channel counts)
+        if (ct && C == 64) CDC_FOLD_LAUNCH(64);
+        else if (ct && C == 128) CDC_FOLD_LAUNCH(128);
+        else if (ct && C == 192) CDC_FOLD_LAUNCH(192);
+        else CDC_FOLD_LAUNCH(0);
+#undef CDC_FOLD_LAUNCH
         return hipGetLastError();
     }
     hipLaunchKernelGGL(ctx_r1_kernel, dim3(ceil_div(C, kFoldRows), B), dim3(blk),

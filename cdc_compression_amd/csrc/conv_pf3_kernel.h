@@ -215,19 +215,29 @@ __global__ void __launch_bounds__(512, 1) conv_pf3_kernel(const PfArgs P) {
     if (P.xcd_remap) rank = (blockIdx.x & 7) * ((int)gridDim.x >> 3) + (blockIdx.x >> 3);
     struct Tile { int b, oy0, ox0; };
     Tile Tc, Tx;
+    // walk order inside the range (PfArgs::lin != 0 here): column-major -- consecutive tiles (one per group, a barrier interval apart) are
+    // VERTICAL neighbours, so the two halo rows a tile shares with the next one are fetched twice within a tile's time and meet in L2
+    // (row-major: the row below comes tiles_x tiles later, after ~1 MB of other patches per workgroup)
+    const bool ymajor = P.lin != 0;
     {
         const int t = rank * 2 * n_iter + grp, tiles_xy = P.tiles_x * P.tiles_y;
         Tc.b = t / tiles_xy;
         const int r = t - Tc.b * tiles_xy;
-        const int ty = r / P.tiles_x;
-        Tc.oy0 = ty * TH; Tc.ox0 = (r - ty * P.tiles_x) * 32;
+        if (ymajor) { const int tx = r / P.tiles_y; Tc.ox0 = tx * 32; Tc.oy0 = (r - tx * P.tiles_y) * TH; }
+        else { const int ty = r / P.tiles_x; Tc.oy0 = ty * TH; Tc.ox0 = (r - ty * P.tiles_x) * 32; }
     }
     const int w_pix = P.tiles_x * 32, h_pix = P.tiles_y * TH;
     auto advance = [&](const Tile &T) {
         Tile N = T;
+        if (ymajor) {
+            N.oy0 += 2 * TH;
+            while (N.oy0 >= h_pix) { N.oy0 -= h_pix; N.ox0 += 32; }
+            if (N.ox0 >= w_pix) { N.ox0 -= w_pix; N.b += 1; }
+        } else {
         N.ox0 += 64;
         while (N.ox0 >= w_pix) { N.ox0 -= w_pix; N.oy0 += TH; }
         if (N.oy0 >= h_pix) { N.oy0 -= h_pix; N.b += 1; }
+        }
         if (N.b >= P.B) N.b = P.B - 1;                    // (past the last tile: only ever a dummy patch source)
         return N;
     };

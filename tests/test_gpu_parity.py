@@ -130,11 +130,15 @@ def _conv_check(O, G, case, tol_plain=1e-5, tol_fused=1e-5):
         assert relerr(g2, r2) < tol_fused, relerr(g2, r2)
 
 
+@pytest.mark.parametrize("walk", ["column-major", "row-major"])
 @pytest.mark.parametrize("case", PF3_CASES)
-def test_conv2d_persistent_ping_pong_kernel(O, case, monkeypatch):
-    """conv_pf3_kernel (CDC_PF=1, large 3x3 layers): plain, and with LayerNorm + ReLU + per-image shift + residual."""
+def test_conv2d_persistent_ping_pong_kernel(O, case, walk, monkeypatch):
+    """conv_pf3_kernel (CDC_PF=1, large 3x3 layers): plain, and with LayerNorm + ReLU + per-image shift + residual; both tile walk
+    orders of a workgroup's range (column-major is the default, CDC_PF3_XMAJOR=1 the row-major one)."""
     monkeypatch.setenv("CDC_PF", "1")
     monkeypatch.setenv("CDC_PF_MAXPIX", "0")
+    if walk == "row-major":
+        monkeypatch.setenv("CDC_PF3_XMAJOR", "1")
     _conv_check(O, Ops(0), case)
 
 
