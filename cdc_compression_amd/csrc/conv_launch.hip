@@ -214,6 +214,8 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     // tuning aid: CDC_PLAN="MB,NPW,KC" (0 = free) restricts the candidates
     int f_mb = 0, f_npw = 0, f_kc = 0;
     if (const char *e = dev_env("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
+    // the same for the few-pixel levels only: CDC_PLAN8 (8 x 8 outputs), CDC_PLAN16 (16 x 16)
+    if (const char *e = dev_env(s.Ho * s.Wo <= 64 ? "CDC_PLAN8" : (s.Ho * s.Wo <= 256 ? "CDC_PLAN16" : "CDC_PLAN_NONE"))) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
     // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
     // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
     const bool split_ok = s.allow_split && (s.lnmode == 0 || s.lnmode == 1 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
