@@ -319,18 +319,28 @@ template <int COLS> static void ln_vec_launch(const LnArgs &a, dim3 grid, hipStr
         case 1: hipLaunchKernelGGL((ln_kernel_vec<COLS, 1>), grid, dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL((ln_kernel_vec<COLS, 2>), grid, dim3(256), 0, st, a); break;
         case 3: hipLaunchKernelGGL((ln_kernel_vec<COLS, 3>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((ln_kernel_vec<COLS, 4>), grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((ln_kernel_vec<COLS, 4>), grid, dim3(256), 0, st, a); break;
+        default:
+            // five / six slices: the 8-pixel form only (three float4 per thread and slice; one image per call slices the 8 x 8 level
+            // six ways -- kLnVecMaxParts2)
+            if constexpr (COLS == 2) {
+                if (a.nparts == 5) hipLaunchKernelGGL((ln_kernel_vec<2, 5>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((ln_kernel_vec<2, 6>), grid, dim3(256), 0, st, a);
+            }
+            break;
     }
 }
+constexpr int kLnVecMaxParts2 = 6;      // most slices ln_kernel_vec<2, NP> is instantiated for (other widths: 4)
 
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
-    if (a.C <= 8 * kLnCache && a.nparts >= 1 && a.nparts <= 4 && (a.HW & 3) == 0 && (a.part_stride & 3) == 0 &&
+    if (a.C <= 8 * kLnCache && a.nparts >= 1 && a.nparts <= kLnVecMaxParts2 && (a.HW & 3) == 0 && (a.part_stride & 3) == 0 &&
         ((((uintptr_t)a.in) | ((uintptr_t)a.out) | ((uintptr_t)a.resid) | ((uintptr_t)a.stat_mean) | ((uintptr_t)a.stat_rstd)) & 15) == 0 &&
         !dev_env("CDC_NO_LN_VEC")) {
         const long long min_wgs = dev_env("CDC_LN_MIN_WGS") ? atoll(dev_env("CDC_LN_MIN_WGS")) : 256;
         int cols = (long long)ceil_div(a.HW, 32) * B >= min_wgs ? 8 : ((long long)ceil_div(a.HW, 16) * B >= min_wgs ? 4 : 2);
         if (const char *e = dev_env("CDC_LN_VEC_COLS")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) cols = v; }
+        if (a.nparts > 4) cols = 2;                   // (more than four slices exist for the 8-pixel form only)
         const dim3 grid((unsigned)ceil_div(a.HW, 4 * cols), (unsigned)B);
         if (cols == 8) ln_vec_launch<8>(a, grid, st);
         else if (cols == 4) ln_vec_launch<4>(a, grid, st);
