@@ -1334,10 +1334,10 @@ struct Builder {
         const size_t plane_f = (size_t)B * w.Cout * H * W;
         if (!pre_add && w.wsp && w.Cout <= 8 * 48 && plane_f * 4 * 4 <= (160u << 20)) {
             // low-resolution levels: split-K partial sums into scratch, summed by the LayerNorm kernel
-            // one image per call: up to six slices (the 8 x 8 level: 24 chunks -> 6 slices of 4; measured at batch 1: its 3 x 3 layers
-            // 0.53 -> 0.46 ms per iteration, LayerNorm passes unchanged with ln_kernel_vec<2, 6>); larger batches fill the chip with four
-            // (eight were measured slower at batch 32)
-            const int kmax = dev_env("CDC_KMAX") ? atoi(dev_env("CDC_KMAX")) : (pb() == 1 ? 6 : 4);
+            // small batches: up to six slices (the 8 x 8 level: 24 chunks -> 6 slices of 4; measured at batch 1: its 3 x 3 layers
+            // 0.53 -> 0.46 ms per iteration, LayerNorm passes unchanged with ln_kernel_vec<2, 6>; whole model -1.4 % at batch 1 - 4,
+            // -0.4 % at 8, +0.5 % at 16, +2.2 % at 32: larger batches fill the chip with four)
+            const int kmax = dev_env("CDC_KMAX") ? atoi(dev_env("CDC_KMAX")) : (pb() <= 8 ? 6 : 4);
             float *part = dalloc(plane_f * kmax);
             u.max_ksplit = kmax;
             conv(w, s0, C0, bs0, s1, bs1, H, W, part, out.bs(), u, false, prof);
