@@ -1227,6 +1227,28 @@ hipError_t fold_combine_launch(const float *P, const float *bias, float *out, in
 // DDIM update.  x-param: xparam/modules/denoising_diffusion.py:152-174 ; eps-param:
 // epsilonparam/modules/denoising_diffusion.py:137-152.  Same operation order as the reference.
 // ---------------------------------------------------------------------------------------------
+// One element of the update (denoising_diffusion.py ddim(), both trees); shared by the two kernels below.  No fused multiply-adds
+// (fp contract off): every product and sum is rounded on its own, as the reference's element-wise tensor operations round them -- and the
+// scalar and the four-pixel kernel then hold the same bits whatever hipcc packs (left to the contraction heuristics the two differed in
+// the last bit, which a 30-step eps-param chain amplifies to 7e-4).
+struct DdimConsts { float c_recip, c_recipm1, c_acp, c_eps, c_sac, c_s1mac, sig; int pred_mode; };
+__device__ __forceinline__ float ddim_update(const DdimConsts &k, float fx, float x, float noise, bool clip, bool has_noise) {
+#pragma clang fp contract(off)
+    float x0, eps;
+    if (k.pred_mode == 0 || k.pred_mode == 3) {
+        x0 = k.pred_mode == 0 ? fx : k.c_sac * x - k.c_s1mac * fx;
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        eps = (k.c_recip * x - x0) / k.c_recipm1;
+    } else {
+        eps = fx;
+        x0 = k.c_recip * x - k.c_recipm1 * eps;
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    }
+    float xn = k.c_acp * x0 + k.c_eps * eps;
+    if (has_noise) xn += k.sig * noise;
+    return xn;
+}
+
 __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
     const int si = a.step_ptr ? *a.step_ptr : a.i;
     const float c_recip = a.tab[0 * a.steps + si];
@@ -1242,6 +1264,7 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
     const float c_eps = sqrtf(var);
     // clip: 0 none, 1 every image, 2 the first B/2 images only (eps-tree clip_noise "half", eps :142-143)
     const long long clip_n = a.clip == 1 ? a.n : (a.clip == 2 ? a.clip_half_n : 0);
+    const DdimConsts kc{c_recip, c_recipm1, c_acp, c_eps, c_sac, c_s1mac, sig, a.pred_mode};
     bool bad = false;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -1261,21 +1284,57 @@ __global__ void __launch_bounds__(256) ddim_kernel(const DdimArgs a) {
         }
         const float x = a.x[idx];
         bad |= !(fabsf(fx) <= 3.0e38f);                    // inf / NaN from the U-Net (fp16-plane range overflow)
-        float x0, eps;
-        if (a.pred_mode == 0 || a.pred_mode == 3) {
-            x0 = a.pred_mode == 0 ? fx : c_sac * x - c_s1mac * fx;
-            if (idx < clip_n) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-            eps = (c_recip * x - x0) / c_recipm1;
-        } else {
-            eps = fx;
-            x0 = c_recip * x - c_recipm1 * eps;
-            if (idx < clip_n) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-        }
-        float xn = c_acp * x0 + c_eps * eps;
-        if (a.noise) xn += sig * a.noise[idx];
-        a.x_next[idx] = xn;
+        a.x_next[idx] = ddim_update(kc, fx, x, a.noise ? a.noise[idx] : 0.f, idx < clip_n, a.noise != nullptr);
     }
     if (bad && a.fault) *a.fault = 1;                      // sticky, read by the host after the decode
+}
+
+// The same update with the 7-row combine, four consecutive pixels of one (image, channel) plane per thread (pW % 4 == 0; round 4):
+// 16-byte loads / stores, the (image, channel) index is blockIdx.y.  ddim_kernel's element loop derives (plane, pixel) from a 64-bit
+// element index -- two 64-bit divisions per element made it VALU-bound (90 us per launch at batch 32 for 0.23 GB of traffic).
+// Same sums in the same order, same expressions per component: same bits.
+__global__ void __launch_bounds__(256) ddim_rows4_kernel(const DdimArgs a) {
+    const int si = a.step_ptr ? *a.step_ptr : a.i;
+    const float c_recip = a.tab[0 * a.steps + si];
+    const float c_recipm1 = a.tab[1 * a.steps + si];
+    const float c_acp = a.tab[2 * a.steps + si];
+    const float c_1macp = a.tab[3 * a.steps + si];
+    const float sig = a.eta * a.tab[4 * a.steps + si];
+    const float c_sac = a.tab_v ? a.tab_v[si] : 0.f, c_s1mac = a.tab_v ? a.tab_v[a.steps + si] : 0.f;
+    float var = c_1macp - sig * sig;
+    if (a.pred_mode != 1) var = fmaxf(var, 0.f);
+    const float c_eps = sqrtf(var);
+    const long long clip_n = a.clip == 1 ? a.n : (a.clip == 2 ? a.clip_half_n : 0);
+    const int plane = a.pH * a.pW;
+    const int pix = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (pix >= plane) return;
+    const int img_co = blockIdx.y, y = pix / a.pW;
+    const long long idx = (long long)img_co * plane + pix;
+    const float *p = a.P + (size_t)img_co * a.pKH * plane + pix;
+    const float b0 = a.P_bias ? a.P_bias[img_co % a.pC] : 0.f;
+    float fx[4] = {b0, b0, b0, b0};
+    for (int ky = 0; ky < a.pKH; ++ky) {
+        const int r = y + ky - a.pPad;
+        if (r >= 0 && r < a.pH) {
+            const float4 q = *reinterpret_cast<const float4 *>(p + (size_t)ky * plane + (long long)(ky - a.pPad) * a.pW);
+            fx[0] += q.x; fx[1] += q.y; fx[2] += q.z; fx[3] += q.w;
+        }
+    }
+    const float4 x4 = *reinterpret_cast<const float4 *>(a.x + idx);
+    const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.noise) { const float4 n4 = *reinterpret_cast<const float4 *>(a.noise + idx); nz[0] = n4.x; nz[1] = n4.y; nz[2] = n4.z; nz[3] = n4.w; }
+    const bool clip = idx < clip_n;                       // (clip_n is a whole number of images)
+    const DdimConsts kc{c_recip, c_recipm1, c_acp, c_eps, c_sac, c_s1mac, sig, a.pred_mode};
+    bool bad = false;
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bad |= !(fabsf(fx[c]) <= 3.0e38f);
+        out[c] = ddim_update(kc, fx[c], xs[c], nz[c], clip, a.noise != nullptr);
+    }
+    *reinterpret_cast<float4 *>(a.x_next + idx) = make_float4(out[0], out[1], out[2], out[3]);
+    if (bad && a.fault) *a.fault = 1;
 }
 
 // end of a graph-replayed DDIM iteration: the next replay works on step - 1
@@ -1287,6 +1346,12 @@ hipError_t step_dec_launch(int *step, hipStream_t st) {
 }
 
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
+    const long long plane = (long long)a.pH * a.pW;
+    if (a.P && plane > 0 && (a.pW & 3) == 0 && plane < (1ll << 30) && a.n % plane == 0 && a.n / plane <= 65535 &&
+        (((uintptr_t)a.P | (uintptr_t)a.x | (uintptr_t)a.x_next | (uintptr_t)a.noise) & 15) == 0 && !dev_env("CDC_NO_DDIM_ROWS4")) {
+        hipLaunchKernelGGL(ddim_rows4_kernel, dim3((unsigned)ceil_div(plane / 4, 256), (unsigned)(a.n / plane)), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     const int grid = (int)std::min<long long>((a.n + 255) / 256, 4096);
     hipLaunchKernelGGL(ddim_kernel, dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
