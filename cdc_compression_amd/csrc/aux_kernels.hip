@@ -857,7 +857,19 @@ __global__ void __launch_bounds__(512) ctx_r0_kernel(const float *S, const float
     float *fs = r0s, *zf = r0s + nsplit, *red = r0s + 2 * nsplit;
     const int b = blockIdx.y, d = blockIdx.x;
     const int tid = threadIdx.x, e = tid % C, q = tid / C;
-    for (int sp = tid; sp < nsplit; sp += blockDim.x) fs[sp] = M ? M[((size_t)b * nsplit + sp) * C + d] : 0.f;
+    // All three kinds of global loads are issued before the first barrier (round 4): the row maxima, the partial row sums Z and this
+    // thread's first kR0Pre partial-context values.  (M -> barrier -> Z -> barrier -> S were three dependent round trips: 25 us per
+    // launch, the longest of the fold's three.)
+    constexpr int kR0Pre = 8;
+    const float *sp0 = S + ((size_t)b * nsplit * C + d) * C + e;
+    const size_t ss = (size_t)C * C;
+    float sv[kR0Pre];
+#pragma unroll
+    for (int i = 0; i < kR0Pre; ++i) { const int sp = q + i * SPF; sv[i] = sp < nsplit ? sp0[(size_t)sp * ss] : 0.f; }
+    for (int sp = tid; sp < nsplit; sp += blockDim.x) {
+        fs[sp] = M ? M[((size_t)b * nsplit + sp) * C + d] : 0.f;
+        zf[sp] = Zp[((size_t)b * nsplit + sp) * C + d];
+    }
     __syncthreads();
     float mg = -INFINITY;
     if (M)          // every split carries its own row maximum (kvctx kernels): bring them to the common one
@@ -866,16 +878,16 @@ __global__ void __launch_bounds__(512) ctx_r0_kernel(const float *S, const float
     for (int sp = tid; sp < nsplit; sp += blockDim.x) {
         const float f = M ? expf(fs[sp] - mg) : 1.0f;
         fs[sp] = f;
-        zf[sp] = Zp[((size_t)b * nsplit + sp) * C + d] * f;
+        zf[sp] = zf[sp] * f;
     }
     __syncthreads();
     float z = 0.f;
     for (int sp = 0; sp < nsplit; ++sp) z += zf[sp];
-    const float *sp0 = S + ((size_t)b * nsplit * C + d) * C + e;
-    const size_t ss = (size_t)C * C;
     float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kR0Pre; ++i) { const int sp = q + i * SPF; if (sp < nsplit) acc += sv[i] * fs[sp]; }     // same order: sp = q, q + SPF, ...
 #pragma unroll 8
-    for (int sp = q; sp < nsplit; sp += SPF) acc += sp0[(size_t)sp * ss] * fs[sp];
+    for (int sp = q + kR0Pre * SPF; sp < nsplit; sp += SPF) acc += sp0[(size_t)sp * ss] * fs[sp];
     if (SPF > 1) {
         red[q * C + e] = acc;
         __syncthreads();
