@@ -1485,7 +1485,8 @@ struct Builder {
         nsplit = std::min(nsplit, std::max(1, N / 64));
         if (fused) {        // >= 2.6 rounds of 3 workgroups per CU (C = 64) / 4 rounds of one (C = 128)
             static const int kv64 = dev_env("CDC_KV64_WGS") ? atoi(dev_env("CDC_KV64_WGS")) : 1024;   // (round 4: 2048 -> 1024: half the partial sums for the fold to add, 13.92 -> 13.89 ms per iteration)
-            nsplit = std::min(128, C == 64 ? ceil_div(kv64, B) : ceil_div(1024, B));   // (the fold sums the splits serially)
+            static const int kv128 = dev_env("CDC_KV128_WGS") ? atoi(dev_env("CDC_KV128_WGS")) : 1024;
+            nsplit = std::min(128, C == 64 ? ceil_div(kv64, B) : ceil_div(kv128, B));   // (the fold sums the splits serially)
             while (nsplit > 1 && N % (32 * nsplit)) --nsplit;
         }
         float *kmaxs = fused ? dalloc((size_t)B * nsplit * C) : nullptr;   // per-split row maxima
