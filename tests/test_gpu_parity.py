@@ -20,7 +20,7 @@ from helpers import GOLDEN, digest_idx, load_case, oracle_cfg
 pytestmark = pytest.mark.gpu
 TOL = 1e-4         # north_star's statement.  The test bounds below are ~3x what is MEASURED on the MI355X:
 TOL_FWD = 1e-5     #   one U-Net / compressor forward (or a stage of it) against the reference golden: measured <= 3.0e-6
-TOL_DEC = 5e-5     #   a few-step / full-length decode chain against the reference golden: measured <= 1.8e-5
+TOL_DEC = 5e-5     #   a few-step / full-length decode chain against the reference golden: measured <= 2.1e-5
 # (CDC_TEST_OBS=<file>: every relerr() of a run is appended there with its test id -- how the bounds were measured;
 #  tools/gpu_parity_obs.sh, summary under profiles/parity_obs_r04.txt)
 
