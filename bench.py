@@ -228,6 +228,13 @@ def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cf
                       "frac_of_8tb_s": alg_bytes / (dom_ms * 1e-3) / 8e12} if alg_bytes and dom_ms > 0 else None),
         "peak_basis": f"2500 TFLOP/s dense 16-bit MFMA / {products} products per algorithmic fp32 product",
         "mfma_tflops_executed": ach * products,
+        # informational (profiles/mfma_shape_clock_r04.txt, tools/ubench/mfma_shape_clock.hip): what a register-only loop of
+        # v_mfma_f32_32x32x16_f16 sustains on this part when its operands change on every instruction; `peak` / `frac` stay on the
+        # guide's 2500 TFLOP/s
+        "mfma_sustained_register_loop": {"tflops_random_operands": 1540.0, "tflops_constant_operands": 2450.0,
+                                          "frac_of_random_operand_loop": ach * products / 1540.0,
+                                          "note": "power management: with toggling multiplier inputs the pipe sustains 0.62 of the nominal "
+                                                  "dense figure (1.47 - 1.49 GHz at full issue); measured once on one box, not re-measured by this run"},
         "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
         "flops_per_launch": dom["flops"] / max(dom["n"], 1), "algorithmic_bytes_per_launch": alg_bytes,
         "traffic": traffic, "traffic_source": traffic_src, "traffic_by_variant": traffic_variants,
