@@ -15,6 +15,36 @@ template <int SHAPE>   // 0: 32x32x16 f16, 1: 16x16x32 f16, 2: 32x32x16 bf16, 3:
 __global__ void __launch_bounds__(256) mfma_loop(float *out, int iters) {
     h8 a, b; b8 ab, bb;
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(1.0f + i * 0.01f); ab[i] = (__bf16)(float)a[i]; bb[i] = (__bf16)(float)b[i]; }
+    if constexpr (SHAPE == 5 || SHAPE == 6 || SHAPE == 7) {
+        // operand reuse between consecutive instructions, random values: 5 = A held for four instructions while B walks four registers
+        // (a register-blocked GEMM's natural order); 6 = snake over a 2 x 2 block (one operand changes per instruction);
+        // 7 = as 4 (both change every instruction) but out of only TWO registers per operand
+        h8 ra[4], rb[4];
+        unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+        for (int p = 0; p < 4; ++p)
+            for (int i = 0; i < 8; ++i) {
+                x = x * 1664525u + 1013904223u; ra[p][i] = (_Float16)(((int)(x >> 8) % 2001 - 1000) * 0.001f);
+                x = x * 1664525u + 1013904223u; rb[p][i] = (_Float16)(((int)(x >> 8) % 2001 - 1000) * 0.001f);
+            }
+        f16v acc[4];
+        for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (SHAPE == 5) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[u], rb[k], acc[k], 0, 0, 0);
+                    else if constexpr (SHAPE == 6) {
+                        constexpr int ai[4] = {0, 0, 1, 1}, bi[4] = {0, 1, 1, 0};
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[2 * (u & 1) + ai[k]], rb[2 * (u >> 1) + bi[k]], acc[k], 0, 0, 0);
+                    } else acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[k & 1], rb[(k + u) & 1], acc[k], 0, 0, 0);
+                }
+        }
+        float s = 0.f;
+        for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
+        if (s == 12345.f) out[threadIdx.x] = s;
+        return;
+    }
     if constexpr (SHAPE == 4) {
         h8 ra[8], rb[8];
         unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
@@ -97,6 +127,9 @@ int main() {
         run<2>("bf16 32x32x16", w, d, cus);
         run<3>("bf16 16x16x32", w, d, cus);
         run<4>("f16  32x32x16 random", w, d, cus);
+        run<5>("f16 random, A held x4", w, d, cus);
+        run<6>("f16 random, snake 2x2", w, d, cus);
+        run<7>("f16 random, 2 regs", w, d, cus);
     }
     return 0;
 }
