@@ -9,8 +9,9 @@ batch is sharded (weak scaling: `batch` images per GPU) through cdc_compression_
 the only collective is its final all_gather of the decoded images over RCCL.
 
     python bench.py                      # N=1, 1 timed decode + verification + CPU baseline sample
+    python bench.py --gpus 8             # starts its 8 ranks itself (one per GPU, RCCL; self_launch below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 1 --warmup 0
+        --master-port 29500 bench.py --gpus 8 --steps 1 --warmup 0      # the same under an external launcher
 """
 import argparse
 import ctypes
@@ -316,6 +317,41 @@ def other_config(param, B, S, sample_steps, local, dev, prof_every):
     return res
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (the form the driver uses at N = 1): start the N ranks here -- one child
+    process of this same command line per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, rendezvous on
+    127.0.0.1 at a free port -- and wait for them.  Rank 0's single JSON line goes to this process's stdout unchanged.  The first
+    rank to fail ends the others (by their PIDs); the exit code is that rank's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CDC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live = 0, list(procs)
+    try:
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,9 +371,29 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the timed decodes of BASELINE configs[2] and configs[4]")
     ap.add_argument("--dump-ops", default=None, help="write the launch program's op labels (program order) to this file (profiling tools)")
     ap.add_argument("--prof-every", type=int, default=50)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group, one all_reduce counts the ranks, rank 0 prints "
+                         "{launch_check, ranks_seen, launcher}; no GPU work (CPU test of the self-launch path, gloo)")
     a = ap.parse_args()
     if a.sample_steps is None:
         a.sample_steps = 500 if a.param == "x" else 1000
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # bare `python bench.py --gpus N`: this process is only the launcher of its N ranks (one per GPU)
+        raise SystemExit(self_launch(a.gpus))
+    launcher = ("self" if os.environ.get("CDC_BENCH_SELF_LAUNCHED") else "external") if "WORLD_SIZE" in os.environ else None
+    if a.launch_check:
+        import torch
+        import torch.distributed as dist
+        if int(os.environ.get("WORLD_SIZE", 1)) != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
+        dist.init_process_group("gloo")
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        if dist.get_rank() == 0:
+            print(json.dumps({"launch_check": True, "ranks_seen": int(one.item()), "n_gpus": a.gpus, "launcher": launcher}), flush=True)
+        dist.destroy_process_group()
+        return
 
     import torch
     import cdc_compression_amd as cdc
@@ -347,7 +403,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if a.backend == "gloo":
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -440,7 +496,7 @@ def main():
             "config": {"workload": workload_name(a.param, B, S, a.sample_steps, world),
                        "batch_per_gpu": B, "global_batch": B * world, "sample_steps": a.sample_steps, "size": S,
                        "parallelism": f"batch-shard x{world}", "finite": ok, "rccl_ranks_seen": ranks_seen,
-                       "backend": (a.backend if use_dist else None),
+                       "backend": (a.backend if use_dist else None), "launcher": launcher,
                        "arith": arith_name(arith)},
             "roofline": roofline_block(classes, ops, B, S, arith, value, a.sample_steps, a.steps, dt, cfgd, a.prof_every),
         }

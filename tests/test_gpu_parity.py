@@ -1192,6 +1192,30 @@ def test_bench_multi_rank_branch_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in d and "other_configs" not in d   # N = 1 legs only
 
 
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """the driver's form of a multi-GPU run is the BARE command `python bench.py --gpus N ...` -- no
+    torch.distributed.run on the command line, no WORLD_SIZE in the environment.  bench.py then starts its N ranks itself
+    (self_launch: one child per GPU, rendezvous on 127.0.0.1) and rank 0 prints the one JSON line.  Two ranks share cuda:0 over
+    gloo here; on an 8-GPU node the same command without --backend runs one rank per GPU over RCCL."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--batch", "3", "--sample-steps", "6", "--size", "64", "--no-cpu-baseline", "--prof-every", "2"]
+    assert "torch.distributed.run" not in " ".join(cmd)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["config"]["launcher"] == "self"
+    assert d["config"]["global_batch"] == 6 and d["config"]["batch_per_gpu"] == 3 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["verify"]["ok"] is True and d["config"]["finite"] is True
+    assert d["scaling"] == "weak" and abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
 def test_inference_script_counterpart_on_kodak_crops(tmp_path):
     """examples/test_xparam.py = the reference's test_xparam.py on this path: argument set, EMA checkpoint layout
     ("ema_model." prefix, wrapper entries ignored), uint8/255*2-1 scaling, printed bpp.  Driven on two of the Kodak

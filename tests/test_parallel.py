@@ -125,3 +125,35 @@ def test_real_decode_through_ragged_shards_world2_on_one_gpu():
     assert sorted(r[3] for r in res) == [2, 3]                       # ragged shards
     for rank, shape, err, n, faults, _ in res:
         assert shape == (5, 3, 32, 32) and err < 2e-5 and faults == 0, (rank, shape, err, faults)
+
+
+def _run_bench(args, timeout=300, env=None):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=e, cwd=ROOT)
+
+
+def test_bench_self_launches_its_ranks_world2_gloo():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment -- the form the driver uses -- starts
+    its N ranks itself (bench.py::self_launch).  --launch-check stops after the rendezvous, so this runs without a GPU: two
+    ranks, gloo, one all_reduce counting them, ONE JSON line from rank 0."""
+    import json
+    r = _run_bench(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "ranks_seen": 2, "n_gpus": 2, "launcher": "self"}
+
+
+def test_bench_self_launch_reports_a_failed_rank():
+    """A rank that dies ends the launch with its exit code (here: both ranks fail, no GPU in the CPU test container; on a GPU
+    box RCCL refuses two ranks on one device unless --backend gloo) instead of hanging the other ranks at the rendezvous."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--batch", "1", "--sample-steps", "2", "--size", "64"], timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
