@@ -423,9 +423,13 @@ class _ContextDecoder:
         `like`'s device); all streams must have the same latent size.  max_image_hw=(H, W): refuse streams whose header
         describes a larger image before anything is allocated (untrusted input; default: the library's 2^22-position bound)."""
         L, h = _lib.lib(), self._hyper_handle()
+        # the limit is handle state in the library: set it on EVERY call (None -> the library's default bound), so that one
+        # restricted call does not restrict the next; the product is clamped before it is handed over as a C int
+        limit = 1 << 22
         if max_image_hw is not None:
             down = 2 ** (len(self.reversed_dims) - 1 + len(self.reversed_hyper_dims) - 2) if hasattr(self, "reversed_dims") else 64
-            _lib.check(h, L.cdc_entropy_set_limit(h, max(1, -(-int(max_image_hw[0]) // down)) * max(1, -(-int(max_image_hw[1]) // down))))
+            limit = min(limit, max(1, -(-int(max_image_hw[0]) // down)) * max(1, -(-int(max_image_hw[1]) // down)))
+        _lib.check(h, L.cdc_entropy_set_limit(h, int(limit)))
         if not (self._hyper_finalized and self._prior_loaded):
             raise _lib.CdcError("the prior.* tensors have not been loaded (load_state_dict with the full state_dict)")
         streams = [bytes(s) for s in streams]

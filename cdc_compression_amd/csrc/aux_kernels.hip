@@ -332,6 +332,10 @@ template <int COLS> static void ln_vec_launch(const LnArgs &a, dim3 grid, hipStr
 }
 constexpr int kLnVecMaxParts2 = 6;      // most slices ln_kernel_vec<2, NP> is instantiated for (other widths: 4)
 
+// The workgroup shape (pixel columns per workgroup, hence the order of the cross-slice channel reduction) is chosen from the RUN-TIME
+// batch B, so the last bits of a LayerNorm output may differ between batch sizes (the parity tests bound rows of a batch against
+// batch-1 calls at 5e-6).  Nothing with a bit-exactness contract across batch sizes contains a LayerNorm: hyper_dec -- the entropy
+// coder's model, include/cdc_hip.h -- is convolutions + LeakyReLU only.
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.nparts > 1 && a.C > 8 * kLnCache) return hipErrorInvalidValue;
     if (a.C <= 8 * kLnCache && a.nparts >= 1 && a.nparts <= kLnVecMaxParts2 && (a.HW & 3) == 0 && (a.part_stride & 3) == 0 &&

@@ -657,6 +657,7 @@ struct Builder {
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
         const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack"};
+        if (op.kind == Op::PFPACK && op.pk.c4 == 2) kinds[Op::PFPACK] = "pfunpack";
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d tg%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
@@ -744,6 +745,7 @@ struct Builder {
     bool pf_on() const { return pf_mode() != 0; }
     static long long pf_maxpix() { const char *e = dev_env("CDC_PF_MAXPIX"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : (1LL << 40); }
     PfTwin *twin(const float *p) { auto it = pfmap.find(p); return it == pfmap.end() ? nullptr : &it->second; }
+    bool still_planes_only(const float *p) { PfTwin *t = twin(p); return t && t->only; }    // (false once ensure_f32 unpacked it)
     void add_twin(const float *p, int C, int H, int W) {
         if (rc || !p || !pf_on() || (C % 16) || W < 32 || H < 2 || (long long)H * W > pf_maxpix()) return;
         PfTwin t; t.C = C; t.H = H; t.W = W;
@@ -767,6 +769,26 @@ struct Builder {
         emit(op);
         t->valid = true;
     }
+    // PF -> fp32 for a planes-only tensor that reaches a reader of fp32 after all (the planes-only decision is taken by shape
+    // predicates BEFORE the readers are planned -- join_would_read_planes, pf_s2_would_plan, ... -- and a predicate can miss: an odd
+    // channel split of a join, a reader that needs split-K, a shape below the plane kernels' minimum grid).  The fp32 buffer of
+    // every activation is allocated anyway, so the program unpacks h + l * 2^-11 into it once, ahead of that reader (the values the
+    // plane readers see), instead of failing the build.  Returns true when `q` is readable as fp32 afterwards.
+    bool ensure_f32(const float *q, long long bs) {
+        PfTwin *t = q ? twin(q) : nullptr;
+        if (!t || !t->only) return true;
+        if (rc || !t->valid || bs != (long long)t->C * t->H * t->W) return false;
+        Op op; op.kind = Op::PFPACK; op.prof = PC_SMALL;
+        op.pk = {q, bs, t->p, t->bs(), t->C, t->H, t->W, 2};      // c4 == 2: unpack (dst = the planes, src = the fp32 buffer to fill)
+        op.bytes = 8.0 * B * t->C * t->H * t->W;
+        emit(op);
+        t->only = false;
+        ++n_unpacked;
+        if (getenv("CDC_DEBUG_PLAN")) fprintf(stderr, "[plan] planes-only tensor %dx%dx%d unpacked for an fp32 reader\n", t->C, t->H, t->W);
+        return true;
+    }
+    int n_unpacked = 0;
+
     // A hoisted (step-invariant) partial-sum tensor in accumulator order for conv_pf_kernel's epilogue (PfArgs::pre_c4): packed once per
     // decode, in the context-only part of the program.
     std::map<const float *, float *> c4map;
@@ -892,6 +914,7 @@ struct Builder {
         if (!pf_on() || !w.wsh || (w.stride != 1 && w.stride != 2) || o.pre_mean || o.w_bs || o.wsp_bs || o.max_ksplit > 1) return false;
         // stride 2: the 3x3 / pad 1 Downsample form on even extents, single source (conv_pf_kernel, STR = 2)
         if (w.stride == 2 && (w.transposed || w.KH != 3 || w.KW != 3 || s1 || (H & 1) || (W & 1) || o.pre_add || o.res3_w)) return false;
+        if (s1 && dev_env("CDC_TEST_JOIN_MISS")) return false;   // test hook: the joins miss the plane kernels AFTER their halves were made planes-only (ensure_f32)
         PfTwin *t0 = twin(s0), *t1 = s1 ? twin(s1) : nullptr;
         if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
         if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
@@ -961,11 +984,14 @@ struct Builder {
             if (tr->only) {     // the residual exists as planes only (a ResnetBlock-chain output): read it from there
                 if (!tr->valid || tr->C != w.Cout || tr->H != s.Ho || tr->W != s.Wo || w.transposed || w.stride != 1 ||
                     o.resid_bs != (long long)w.Cout * s.Ho * s.Wo || o.resid_cs != (long long)s.Ho * s.Wo) {
-                    rc = fail(h, CDC_ERR_UNSUPPORTED, "planes-only residual of a shape the plane-operand kernels do not read");
-                    return true;
+                    if (!ensure_f32(o.resid, o.resid_bs)) {
+                        if (!rc) rc = fail(h, CDC_ERR_UNSUPPORTED, "planes-only residual of a shape the plane-operand kernels do not read");
+                        return true;
+                    }
+                } else {
+                    a.resid = nullptr;
+                    a.resid_pf = tr->p; a.rpf_bs = tr->bs(); a.rpf_ps = tr->ps(); a.rpf_ys = s.Wo + 2; a.rpf_zoff = (s.Wo + 2) + 1;
                 }
-                a.resid = nullptr;
-                a.resid_pf = tr->p; a.rpf_bs = tr->bs(); a.rpf_ps = tr->ps(); a.rpf_ys = s.Wo + 2; a.rpf_zoff = (s.Wo + 2) + 1;
             }
         a.stat_mean = o.stat_mean; a.stat_rstd = o.stat_rstd;
         a.res3_w = o.res3_w; a.res3_x = o.res3_x; a.res3_bs = o.res3_bs;
@@ -1128,9 +1154,14 @@ struct Builder {
         if (o.uf_c && !s1 && try_pf_uf(w, s0, bs0, H, W, out, out_bs, o, need_all, prof, s)) return true;
         if (o.pf_only) return false;
         if (o.resid1 && !rc) { rc = fail(h, CDC_ERR_UNSUPPORTED, "a two-source residual reached a kernel without it"); return true; }
-        for (const float *q : {s0, s1, o.resid})
-            if (PfTwin *tq = q ? twin(q) : nullptr)
-                if (tq->only && !rc) { rc = fail(h, CDC_ERR_UNSUPPORTED, "a planes-only tensor reached a kernel that reads fp32"); return true; }
+        {   // a planes-only source / residual and a reader of fp32: unpack it once (ensure_f32)
+            const std::pair<const float *, long long> rd[3] = {{s0, bs0}, {s1, bs1}, {o.resid, o.resid_bs}};
+            for (const auto &q : rd)
+                if (!ensure_f32(q.first, q.second) && !rc) {
+                    rc = fail(h, CDC_ERR_UNSUPPORTED, "a planes-only tensor reached a kernel that reads fp32 and cannot be unpacked");
+                    return true;
+                }
+        }
         if (!o.uf_c && try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
@@ -1663,7 +1694,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
             Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2, true, Builder::SITE_DOWN);
             Builder::ConvOpts od; od.emit_pf = true;
             bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), od, false, PC_DOWN);
-            if (x.pf && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
+            if (x.pf && bd.still_planes_only(x.p) && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
                 return fail(h, CDC_ERR_UNSUPPORTED, "planes-only Downsample input without a plane-operand kernel");
             x = y;
             h->taps[dn + ".3"] = x;
@@ -1733,18 +1764,19 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         if (!done) {
             bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ou, false, PC_UP);
             up_pf_only = bd.last_pf_only;
+            if (up_pf_only) { Builder::PfTwin *ty = bd.twin(y.p); ty->only = true; y.pf = ty->p; y.pf_bs = ty->bs(); }
             if (i == n - 2) {
                 if (!fsm) { fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl); }
                 bd.ln(y.p, nullptr, y.C, y.H * y.W, nullptr, nullptr, 0, nullptr, nullptr, fsm, fsr);
             }
         }
-        if (x_planes_only) {
+        if (x_planes_only && bd.still_planes_only(x.p)) {
             bool on_pf = false;
             for (size_t q = ops_before; q < h->ops.size(); ++q) on_pf = on_pf || (h->ops[q].kind == Op::CONVPF && !h->ops[q].pw);
             if (!on_pf) return fail(h, CDC_ERR_UNSUPPORTED, "planes-only Upsample input without a plane-operand kernel");
         }
         x = y;
-        if (!final_ln_done && !up_pf_only) h->taps["ups." + std::to_string(i)] = x;   // (the last one may hold LN(up(x)) instead; a planes-only tensor has no fp32 tap)
+        if (!final_ln_done) h->taps["ups." + std::to_string(i)] = x;   // (the last one may hold LN(up(x)) instead; a planes-only tensor is unpacked on demand: Act::pf)
         if (bd.rc) return bd.rc;
     }
     if (n == 1) {       // no Upsample stage: statistics of the last attention output
@@ -1762,7 +1794,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
     of.no_bias = true;
     bd.conv(h->fin_conv, x.p, x.C, x.bs(), nullptr, 0, H, W, h->fin_P, (long long)h->out_dim * KHf * H * W,
             of, false, PC_CONV7);
-    if (x.pf && !bd.rc && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
+    if (x.pf && !bd.rc && bd.still_planes_only(x.p) && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
         return fail(h, CDC_ERR_UNSUPPORTED, "planes-only final-convolution input without a plane-operand kernel");
     Op cb; cb.kind = Op::COMBINE; cb.prof = PC_SMALL;
     cb.cb = {h->fin_P, h->fin_bias, h->out_fx, h->out_dim, KHf, 3, H, W};
@@ -1901,6 +1933,10 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             else HIP_TRY(h, pf_launch(op.pf, op.pfplan, B, op.nz, st));
             break;
         case Op::PFPACK:
+            if (op.pk.c4 == 2) {       // unpack: planes (pk.dst) -> the tensor's fp32 buffer (pk.src)
+                HIP_TRY(h, pf_unpack_launch(op.pk.dst, op.pk.dst_bs, const_cast<float *>(op.pk.src), op.pk.src_bs, op.pk.C, op.pk.H, op.pk.W, B, st));
+                break;
+            }
             if (op.pk.c4) { HIP_TRY(h, c4_pack_launch(op.pk.src, op.pk.src_bs, (float *)op.pk.dst, op.pk.C, (long long)op.pk.H * op.pk.W, B, st)); break; }
             HIP_TRY(h, pf_pack_launch(op.pk.src, op.pk.src_bs, op.pk.dst, op.pk.dst_bs, op.pk.C, op.pk.H, op.pk.W, B, st));
             break;
@@ -3091,15 +3127,16 @@ int cdc_ddim_step(cdc_handle *h, const float *x_in, int i, const float *const *c
     hipStream_t st = pick_stream(h, stream, mem);
     const size_t n = (size_t)B * h->cfg.channels * H * W;
     if ((rc = copy_in(h, h->in_x, x_in, n, mem, st))) return rc;
+    // the flag is cleared BEFORE the hoisted context convolutions run: they report range faults into it too (as in cdc_decode)
+    if ((rc = ensure_fault_flag(h))) return rc;              // (the sampler kernel writes the flag)
+    const bool guard = guard_enabled(h);
+    HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st));
     if (ctx) {
         if ((rc = stage_ctx(h, ctx, n_ctx, B, mem, st))) return rc;
         h->prof_now = true;
         if ((rc = run_pre(h, st))) return rc;
     }
     if (eta != 0.f && (rc = copy_in(h, h->noise_buf, noise, n, mem, st))) return rc;
-    if ((rc = ensure_fault_flag(h))) return rc;              // (the sampler kernel writes the flag)
-    const bool guard = guard_enabled(h);
-    HIP_TRY(h, hipMemsetAsync(h->d_fault, 0, sizeof(int), st));
     if ((rc = ddim_on_device(h, h->in_x, i, h->noise_buf, eta, h->xa, B, H, W, pred_mode, clip, st)))
         return rc;
     if (guard) {

@@ -1,6 +1,7 @@
 // cdc_internal.h -- host-side declarations shared by the translation units of libcdc_hip.so.
 #pragma once
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,6 +10,8 @@
 #include <vector>
 
 #include "conv_args.h"
+
+extern "C" char **environ;
 
 namespace cdc {
 
@@ -79,13 +82,26 @@ hipError_t pf_unpack_launch(const void *src, long long src_bs, float *dst, long 
 // entropy coder's "the decoder reproduces the encoder's hyper-decoder output" contract needs (include/cdc_hip.h).
 // User-level variables stay plain getenv: CDC_ARITH, CDC_NO_RANGE_GUARD, CDC_GRAPH, CDC_DEBUG_PLAN, CDC_PROF_OPS.
 inline const char *dev_env(const char *name) {
-    static const bool on = [] { const char *e = ::getenv("CDC_DEV"); return e && atoi(e) != 0; }();
-    if (on) return ::getenv(name);
-    if (::getenv(name)) {       // a tuning tool that forgot CDC_DEV=1 would silently time the default plan under every label
-        static bool warned = false;
-        if (!warned) { warned = true; fprintf(stderr, "cdc_hip: %s is set but ignored: development switches need CDC_DEV=1\n", name); }
-    }
-    return nullptr;
+    // Without CDC_DEV the answer is always "not set", at no cost per call (this runs on per-launch paths: ADVICE r4).  A tuning tool
+    // that forgot CDC_DEV=1 would silently time the default plan under every label, so the first call scans the environment ONCE
+    // for CDC_* variables that are not user-level and says so.
+    static const bool on = [] {
+        const char *e = ::getenv("CDC_DEV");
+        if (e && atoi(e) != 0) return true;
+        static const char *const user_level[] = {"CDC_DEV=", "CDC_ARITH=", "CDC_NO_RANGE_GUARD=", "CDC_GRAPH=", "CDC_DEBUG_PLAN=", "CDC_PROF_OPS=",
+                                                 "CDC_BENCH_", "CDC_TEST_", "CDC_SYNC_EACH_OP=", "CDC_HIP_LIB=", "CDC_NO_COMBINE_FUSE="};
+        for (char **v = environ; v && *v; ++v) {
+            if (strncmp(*v, "CDC_", 4)) continue;
+            bool user = false;
+            for (const char *u : user_level) user = user || !strncmp(*v, u, strlen(u));
+            if (!user) {
+                fprintf(stderr, "cdc_hip: %.*s is set but ignored: development switches need CDC_DEV=1\n", (int)strcspn(*v, "="), *v);
+                break;
+            }
+        }
+        return false;
+    }();
+    return on ? ::getenv(name) : nullptr;
 }
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -316,7 +316,12 @@ def test_corrupt_stream_is_rejected():
     with pytest.raises(_lib.CdcError, match="exceeds the decoder's limit"):
         comp.decompress_from_bytes([s128], max_image_hw=(64, 64))
     assert comp.decompress_from_bytes([s128], max_image_hw=(128, 128)).shape == (1, 256, 8, 8)
-    comp.decompress_from_bytes([s], max_image_hw=(1 << 17, 1 << 17))           # (back to the library's own bound)
+    # the limit is not sticky -- a call without max_image_hw decodes the larger stream right after a restricted call --
+    # and an absurd bound is clamped (its product would not fit a C int), not wrapped
+    with pytest.raises(_lib.CdcError, match="exceeds the decoder's limit"):
+        comp.decompress_from_bytes([s128], max_image_hw=(64, 64))
+    assert comp.decompress_from_bytes([s128]).shape == (1, 256, 8, 8)
+    assert comp.decompress_from_bytes([s128], max_image_hw=(1 << 40, 1 << 40)).shape == (1, 256, 8, 8)
     # version-1 containers (no fingerprints) are not accepted
     with pytest.raises(_lib.CdcError):
         comp.decompress_from_bytes([s[:3] + b"\x01" + s[4:]])

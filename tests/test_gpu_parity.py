@@ -865,6 +865,36 @@ def test_configs1_full_length_batch32_rows_match_batch1_decodes():
 TAPS = ["downs.0.0", "downs.0.2", "downs.1.3", "mid_block1", "ups.0"]
 
 
+def _op_labels(un):
+    L, h = _lib.lib(), un._handle()
+    labels = []
+    for i in range(L.cdc_prof_num_ops(h)):
+        lab, ms, n, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+        labels.append(lab.value.decode())
+    return labels
+
+
+@pytest.mark.parametrize("name", ["full_x", "full_eps"])
+def test_planes_only_tensor_reaching_an_fp32_reader_is_unpacked_not_a_build_error(name, monkeypatch):
+    """a skip / Upsample output is made planes-only on SHAPE predictions of its readers' launch plans, taken
+    before those readers are planned.  When a prediction misses -- here every decoder join is forced off the plane-operand kernels
+    AFTER its two halves were made planes-only -- the program used to fail to build (CDC_ERR_UNSUPPORTED); it now unpacks
+    h + l 2^-11 into the tensor's fp32 buffer once, ahead of that reader, and the forward matches the reference golden."""
+    for k, v in {"CDC_PF_MIN_WAVES": "1", "CDC_PF_S2_MIN_WGS": "1", "CDC_PF_TZ_MIN_WGS": "1"}.items():
+        monkeypatch.setenv(k, v)
+    un, kw, sd, x, time, ctx, g = make_unet(name)
+    un(x, time, ctx)
+    assert not [l for l in _op_labels(un) if l == "pfunpack"]          # the predictions hold on the default plans: nothing to unpack
+    monkeypatch.setenv("CDC_TEST_JOIN_MISS", "1")
+    un2, kw, sd, x, time, ctx, g = make_unet(name)
+    y = un2(x, time, ctx)
+    assert len([l for l in _op_labels(un2) if l == "pfunpack"]) >= 2   # skip halves and Upsample halves of the joins
+    assert relerr(y, g["y"]) < TOL_FWD, relerr(y, g["y"])
+    got = un2.tap("ups.1")                                             # a planes-only Upsample output keeps its tap (unpacked on demand)
+    assert got.ndim == 4 and np.isfinite(got).all()
+
+
 @pytest.mark.parametrize("name", ["small_x", "small_eps", "odd_x", "full_x", "full_eps"])
 def test_unet_stage_taps_match_reference(name):
     """Per-stage activations (forward hooks on the reference modules, stored by gen_unet as arrays for the small
