@@ -94,6 +94,21 @@ def cpu_baseline(param, size, sample_steps, n_iter=4):
             "reference_probe": REFERENCE_PROBE}
 
 
+def measure_ceilings(L, local):
+    """The part's own ceilings, measured on the spot: csrc/probe.hip through the C-ABI, ~50 ms in all."""
+    tf_r, tf_c, gbs = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    rc = [L.cdc_probe_mfma_f16(local, 1, 4000, ctypes.byref(tf_r)), L.cdc_probe_mfma_f16(local, 0, 4000, ctypes.byref(tf_c)),
+          L.cdc_probe_hbm_copy(local, 1 << 30, 5, ctypes.byref(gbs))]
+    if any(rc):
+        return None
+    return {"mfma": {"tflops_random_operands": tf_r.value, "tflops_constant_operands": tf_c.value,
+                     "frac_of_nominal_random": tf_r.value / PEAK_16BIT_MFMA_TFLOPS, "nominal_tflops": PEAK_16BIT_MFMA_TFLOPS,
+                     "note": "register-only v_mfma_f32_32x32x16_f16 loop, two waves per SIMD, best of 2 timed launches of 4000 x 16 instructions "
+                             "per wave; random = eight pseudo-random operand pairs cycled (inputs toggle as on real data)"},
+            "hbm": {"gb_per_s": gbs.value, "frac_of_nominal": gbs.value / 8000.0, "nominal_gb_per_s": 8000.0,
+                    "note": "float4 copy of 1 GiB, bytes read + bytes written, best of 5 launches"}}
+
+
 def arith_name(arith):
     return "f16x2" if arith == 1 else "bf16x3"
 
@@ -159,7 +174,7 @@ def op_bytes(label, B):
     return 4.0 * B * (cin * ho * wo * st * st + cout * ho * wo * (2 if ("+res" in t or "+resP" in t) else 1))     # (+resP: the residual read from a PF tensor, same bytes)
 
 
-def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cfgd, prof_every, full=True):
+def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cfgd, prof_every, full=True, ceilings=None):
     """The `roofline` object of the JSON line.  Dominant kernel = the (layer shape, kernel) pair with the largest total time among
     the 3x3 stride-1 Block convolutions (the rule of rounds 1-3; epilogue variants of one kernel on one layer shape together);
     `by_shape` lists the other pairs, `families` the totals per kernel function (what rocprofv3 --stats rows add up to)."""
@@ -199,18 +214,26 @@ def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cf
     # (tools/gpu_profiles_r04.sh -> profiles/pmc_r04_traffic.json: {op label: {...}}, per-dispatch FETCH_SIZE / WRITE_SIZE of the
     # whole-path passes matched to the launch program's op labels).  `traffic` is the mean over the SAME launches that
     # `algorithmic_bytes_per_launch` averages (every epilogue variant of the pair), so the two figures compare like with like.
-    traffic, traffic_src, traffic_variants = None, None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_r04_traffic.json")
-    if os.path.exists(tpath) and dom["raw"]:
+    traffic, traffic_src, traffic_variants, traffic_hash = None, None, None, None
+    import glob
+    from cdc_compression_amd._lib import kernel_source_hash
+    build_hash = kernel_source_hash()
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*_traffic.json")), reverse=True):      # newest round first
+        if not dom["raw"]:
+            break
         try:
             tj = json.load(open(tpath))
+            if tj.get("kernel_source_hash") != build_hash:      # counters of other kernels say nothing about this build
+                continue
             per = tj.get("ops", {}) if tj.get("batch") == B and tj.get("arith") == arith_name(arith) else {}
             rows = [per.get(lab) for lab in dom["raw"]]
             if rows and all(rows):
                 traffic = sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
-                traffic_src = tj.get("source")
+                traffic_src = "from_file: " + os.path.relpath(tpath, ROOT) + " -- " + str(tj.get("source"))
+                traffic_hash = tj.get("kernel_source_hash")
                 traffic_variants = [{"launch": lab, "hbm_bytes_corrected": r["hbm_bytes_corrected"], "hbm_bytes_raw": r["hbm_bytes_raw"],
                                      "algorithmic_bytes": op_bytes(lab, B)} for lab, r in zip(dom["raw"], rows)]
+                break
         except Exception:
             pass
     by_shape = sorted(({"launch_key": k, "family": g["family"], "launches_per_iteration": g["n"], "avg_launch_ms": g["ms"] / g["n"],
@@ -229,18 +252,20 @@ def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cf
                       "frac_of_8tb_s": alg_bytes / (dom_ms * 1e-3) / 8e12} if alg_bytes and dom_ms > 0 else None),
         "peak_basis": f"2500 TFLOP/s dense 16-bit MFMA / {products} products per algorithmic fp32 product",
         "mfma_tflops_executed": ach * products,
-        # informational (profiles/mfma_shape_clock_r04.txt, tools/ubench/mfma_shape_clock.hip): what a register-only loop of
-        # v_mfma_f32_32x32x16_f16 sustains on this part when its operands change on every instruction; `peak` / `frac` stay on the
-        # guide's 2500 TFLOP/s
-        "mfma_sustained_register_loop": {"tflops_random_operands": 1540.0, "tflops_constant_operands": 2450.0,
-                                          "frac_of_random_operand_loop": ach * products / 1540.0,
-                                          "note": "power management: with toggling multiplier inputs the pipe sustains 0.62 of the nominal "
-                                                  "dense figure (1.47 - 1.49 GHz at full issue); measured once on one box, not re-measured by this run"},
+        # what THIS box sustains, measured by this run right after the timed region (csrc/probe.hip through the C-ABI): a register-only
+        # loop of v_mfma_f32_32x32x16_f16 on constant / on pseudo-random operands, and a 1 GiB float4 copy.  `peak` / `frac` stay on the
+        # guide's nominal 2500 TFLOP/s; these say how far the part itself is from it under load.
+        "mfma_sustained_measured": ({**ceilings["mfma"], "frac_of_random_operand_loop": (ach * products / ceilings["mfma"]["tflops_random_operands"]
+                                                                                     if ceilings["mfma"].get("tflops_random_operands") else None)}
+                                    if ceilings else None),
+        "hbm_copy_measured": ceilings["hbm"] if ceilings else None,
         "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
         "flops_per_launch": dom["flops"] / max(dom["n"], 1), "algorithmic_bytes_per_launch": alg_bytes,
         "traffic": traffic, "traffic_source": traffic_src, "traffic_by_variant": traffic_variants,
-        "traffic_note": "mean corrected counter bytes (FETCH_SIZE x2 + WRITE_SIZE) over the same launches that algorithmic_bytes_per_launch "
-                        "averages; null when no PMC pass of this build / batch / arithmetic is committed",
+        "traffic_kernel_source_hash": traffic_hash, "kernel_source_hash": build_hash,
+        "traffic_note": "from a committed counter file, not re-measured by this run: mean corrected counter bytes (FETCH_SIZE x2 + WRITE_SIZE) "
+                        "over the same launches that algorithmic_bytes_per_launch averages; null unless a PMC pass of exactly these kernel "
+                        "sources (kernel_source_hash), batch and arithmetic is committed under profiles/",
         "class_conv3x3": {"achieved": cls_ach, "frac": cls_ach / peak if peak else 0,
                           "avg_launch_ms": cls3["ms"] / max(cls3["launches"], 1),
                           "flops_per_launch": cls3["flops"] / max(cls3["launches"], 1)},
@@ -498,7 +523,8 @@ def main():
                        "parallelism": f"batch-shard x{world}", "finite": ok, "rccl_ranks_seen": ranks_seen,
                        "backend": (a.backend if use_dist else None), "launcher": launcher,
                        "arith": arith_name(arith)},
-            "roofline": roofline_block(classes, ops, B, S, arith, value, a.sample_steps, a.steps, dt, cfgd, a.prof_every),
+            "roofline": roofline_block(classes, ops, B, S, arith, value, a.sample_steps, a.steps, dt, cfgd, a.prof_every,
+                                       ceilings=measure_ceilings(L, local) if world == 1 else None),
         }
         if world > 1 and not a.no_verify:
             out["verify"] = {"every_rank_checked_rows_0_and_last_of_its_shard_against_batch1_decodes": True,

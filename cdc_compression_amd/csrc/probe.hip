@@ -1,0 +1,121 @@
+// probe.hip -- what THIS part sustains, measured on the spot (include/cdc_hip.h: cdc_probe_*).  bench.py prints the two figures
+// beside the guide's nominal peaks (2.5 PFLOP/s dense 16-bit MFMA, 8 TB/s HBM3E) so that a driver run re-measures its own ceilings
+// instead of quoting a committed number.  No handle, no model: a register-only MFMA loop and a float4 copy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cdc_hip.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x16_f16 out of registers: four independent accumulators, no LDS, no memory.  RANDOM = true cycles eight
+// pseudo-random operand pairs, so the multiplier inputs toggle on every instruction as they do on real data (the power management
+// then gives back clock); RANDOM = false multiplies the same registers every time (the nominal-peak conditions).
+template <bool RANDOM>
+__global__ void __launch_bounds__(256) probe_mfma_kernel(float *out, int iters) {
+    h8 ra[8], rb[8];
+    unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+    for (int p = 0; p < 8; ++p)
+        for (int i = 0; i < 8; ++i) {
+            x = x * 1664525u + 1013904223u; ra[p][i] = (_Float16)(((int)(x >> 8) % 2001 - 1000) * 0.001f);
+            x = x * 1664525u + 1013904223u; rb[p][i] = (_Float16)(((int)(x >> 8) % 2001 - 1000) * 0.001f);
+        }
+    f16v acc[4];
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (RANDOM) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[(4 * u + k) & 7], rb[(4 * u + k + 3) & 7], acc[k], 0, 0, 0);
+                else acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[0], rb[0], acc[k], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
+    if (s == 12345.f) out[threadIdx.x] = s;          // (keeps the loop alive; never true)
+}
+
+__global__ void __launch_bounds__(256) probe_copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+struct Ev {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int cdc_probe_mfma_f16(int device, int random_operands, int iters, double *tflops) {
+    if (!tflops || iters < 1) return CDC_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return CDC_ERR_HIP;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return CDC_ERR_HIP;
+    float *d = nullptr;
+    if (hipMalloc(&d, 4096) != hipSuccess) return CDC_ERR_NOMEM;
+    Ev ev;
+    int rc = CDC_OK;
+    const int grid = pr.multiProcessorCount * 2;         // two waves per SIMD, as the ping-ponged kernels run
+    auto launch = [&](int n) {
+        if (random_operands) hipLaunchKernelGGL(probe_mfma_kernel<true>, dim3(grid), dim3(256), 0, 0, d, n);
+        else hipLaunchKernelGGL(probe_mfma_kernel<false>, dim3(grid), dim3(256), 0, 0, d, n);
+    };
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) rc = CDC_ERR_HIP;
+    double best = 0.0;
+    if (!rc) {
+        launch(200);                                      // pages the code in, wakes the clocks
+        for (int rep = 0; rep < 3 && !rc; ++rep) {
+            (void)hipEventRecord(ev.a, 0);
+            launch(iters);
+            (void)hipEventRecord(ev.b, 0);
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.b) != hipSuccess || hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess || !(ms > 0.f)) { rc = CDC_ERR_HIP; break; }
+            const double tf = 16.0 * 32768.0 * iters * 4.0 * grid / (ms * 1e-3) / 1e12;    // 16 instructions of 32x32x16 per wave and iteration
+            if (rep > 0 && tf > best) best = tf;          // (the first timed launch still ramps)
+        }
+    }
+    (void)hipFree(d);
+    *tflops = best;
+    return rc;
+}
+
+int cdc_probe_hbm_copy(int device, size_t bytes, int reps, double *gbytes_per_s) {
+    if (!gbytes_per_s || bytes < (1u << 20) || reps < 1) return CDC_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return CDC_ERR_HIP;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return CDC_ERR_HIP;
+    const long long n = (long long)(bytes / 16);
+    float4 *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, (size_t)n * 16) != hipSuccess) return CDC_ERR_NOMEM;
+    if (hipMalloc(&dst, (size_t)n * 16) != hipSuccess) { (void)hipFree(src); return CDC_ERR_NOMEM; }
+    Ev ev;
+    int rc = CDC_OK;
+    if (hipMemset(src, 1, (size_t)n * 16) != hipSuccess || hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) rc = CDC_ERR_HIP;
+    double best = 0.0;
+    const int grid = pr.multiProcessorCount * 8;
+    if (!rc) {
+        hipLaunchKernelGGL(probe_copy_kernel, dim3(grid), dim3(256), 0, 0, src, dst, n);
+        for (int rep = 0; rep < reps; ++rep) {
+            (void)hipEventRecord(ev.a, 0);
+            hipLaunchKernelGGL(probe_copy_kernel, dim3(grid), dim3(256), 0, 0, src, dst, n);
+            (void)hipEventRecord(ev.b, 0);
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.b) != hipSuccess || hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess || !(ms > 0.f)) { rc = CDC_ERR_HIP; break; }
+            const double gbs = 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9;     // bytes read + bytes written
+            if (gbs > best) best = gbs;
+        }
+    }
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    *gbytes_per_s = best;
+    return rc;
+}
+
+}  // extern "C"

@@ -285,6 +285,16 @@ int cdc_entropy_decode(cdc_handle *h, const unsigned char *in, const size_t *off
 int cdc_dequantize(cdc_handle *h, const float *x, const float *offset, float *out, long long n, int mem_kind,
                    void *stream);
 
+/* Measurement aids of bench.py (csrc/probe.hip; no handle, no model): what THIS part sustains, measured on the spot, to print
+ * beside the nominal peaks a roofline is quoted against.
+ * cdc_probe_mfma_f16: a register-only loop of v_mfma_f32_32x32x16_f16 (two waves per SIMD, four independent accumulators, `iters`
+ *   x 16 instructions per wave) -> TFLOP/s.  random_operands = 1 cycles eight pseudo-random operand pairs (the multiplier inputs
+ *   toggle as on real data; the power management gives back clock), 0 multiplies the same registers every time.
+ * cdc_probe_hbm_copy: a float4 copy of `bytes` (>= 1 MiB) from one device buffer to another, best of `reps` -> GB/s counting
+ *   bytes read + bytes written.  Both run on the null stream of `device` and synchronise. */
+int cdc_probe_mfma_f16(int device, int random_operands, int iters, double *tflops);
+int cdc_probe_hbm_copy(int device, size_t bytes, int reps, double *gbytes_per_s);
+
 /* Kernel-class timing: hipEvent pairs recorded (without host synchronisation) on the launch stream
  * around every kernel of a forward / DDIM iteration and resolved at cdc_prof_get.
  * on = 0: off (default); on = 1: every launch; on = n > 1: inside cdc_decode only the DDIM

@@ -1222,6 +1222,21 @@ def test_bench_multi_rank_branch_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in d and "other_configs" not in d   # N = 1 legs only
 
 
+def test_probes_measure_the_parts_own_ceilings():
+    """bench.py re-measures what the box sustains (csrc/probe.hip) instead of quoting committed literals.  The
+    figures must be physical: the register-only MFMA loop between a fifth of and just above the nominal 2.5 PFLOP/s, constant
+    operands no slower than toggling ones, the float4 copy between 1 and 8 TB/s."""
+    L = _lib.lib()
+    tf_r, tf_c, gbs = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    assert L.cdc_probe_mfma_f16(0, 1, 2000, ctypes.byref(tf_r)) == 0
+    assert L.cdc_probe_mfma_f16(0, 0, 2000, ctypes.byref(tf_c)) == 0
+    assert L.cdc_probe_hbm_copy(0, 1 << 28, 3, ctypes.byref(gbs)) == 0
+    assert 500.0 < tf_r.value < 2700.0 and 500.0 < tf_c.value < 2700.0, (tf_r.value, tf_c.value)
+    assert tf_c.value > 0.95 * tf_r.value
+    assert 1000.0 < gbs.value < 8200.0, gbs.value
+    assert L.cdc_probe_mfma_f16(0, 1, 0, ctypes.byref(tf_r)) != 0 and L.cdc_probe_hbm_copy(0, 16, 1, ctypes.byref(gbs)) != 0   # bad arguments
+
+
 def test_bench_self_launch_two_ranks_on_one_gpu():
     """the driver's form of a multi-GPU run is the BARE command `python bench.py --gpus N ...` -- no
     torch.distributed.run on the command line, no WORLD_SIZE in the environment.  bench.py then starts its N ranks itself

@@ -97,6 +97,15 @@ def test_compute_fails_loudly_without_gpu():
         Ops().chan_layernorm(np.zeros((1, 4, 2, 2), np.float32), np.ones(4), np.zeros(4))
 
 
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a host without a GPU")
+def test_probes_fail_loudly_without_gpu():
+    import ctypes
+    L = _lib.lib()
+    v = ctypes.c_double(-1.0)
+    assert L.cdc_probe_mfma_f16(0, 1, 100, ctypes.byref(v)) < 0
+    assert L.cdc_probe_hbm_copy(0, 1 << 20, 1, ctypes.byref(v)) < 0
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "cdc_compression_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -128,7 +128,9 @@ if ops_file and os.path.exists(ops_file):
                      "hbm_bytes_corrected": (2 * e["fetch"] + e["write"]) / e["n"], "hbm_bytes_raw": (e["fetch"] + e["write"]) / e["n"]}
                for lab, e in ops.items()}
         arith = "bf16x3" if os.environ.get("CDC_ARITH") == "0" else "f16x2"
-        json.dump({"batch": B, "arith": arith, "ops": res,
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from cdc_compression_amd._lib import kernel_source_hash
+        json.dump({"batch": B, "arith": arith, "ops": res, "kernel_source_hash": kernel_source_hash(),
                    "source": f"profiles/pmc_{tag}_path.* passes (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes, "
                              "FETCH_SIZE x2 gfx950 correction): the convolution dispatches of the last DDIM iteration matched in program order to the op labels"},
                   open(os.path.join(out, f"pmc_{tag}_traffic.json"), "w"), indent=1)
