@@ -97,13 +97,13 @@ def cpu_baseline(param, size, sample_steps, n_iter=4):
 def measure_ceilings(L, local):
     """The part's own ceilings, measured on the spot: csrc/probe.hip through the C-ABI, ~50 ms in all."""
     tf_r, tf_c, gbs = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-    rc = [L.cdc_probe_mfma_f16(local, 1, 4000, ctypes.byref(tf_r)), L.cdc_probe_mfma_f16(local, 0, 4000, ctypes.byref(tf_c)),
+    rc = [L.cdc_probe_mfma_f16(local, 1, 20000, ctypes.byref(tf_r)), L.cdc_probe_mfma_f16(local, 0, 20000, ctypes.byref(tf_c)),
           L.cdc_probe_hbm_copy(local, 1 << 30, 5, ctypes.byref(gbs))]
     if any(rc):
         return None
     return {"mfma": {"tflops_random_operands": tf_r.value, "tflops_constant_operands": tf_c.value,
                      "frac_of_nominal_random": tf_r.value / PEAK_16BIT_MFMA_TFLOPS, "nominal_tflops": PEAK_16BIT_MFMA_TFLOPS,
-                     "note": "register-only v_mfma_f32_32x32x16_f16 loop, two waves per SIMD, best of 2 timed launches of 4000 x 16 instructions "
+                     "note": "register-only v_mfma_f32_32x32x16_f16 loop, two waves per SIMD, best of 4 timed launches of 20000 x 16 instructions "
                              "per wave; random = eight pseudo-random operand pairs cycled (inputs toggle as on real data)"},
             "hbm": {"gb_per_s": gbs.value, "frac_of_nominal": gbs.value / 8000.0, "nominal_gb_per_s": 8000.0,
                     "note": "float4 copy of 1 GiB, bytes read + bytes written, best of 5 launches"}}

@@ -15,6 +15,7 @@
 
 #include "../../include/cdc_hip.h"
 #include "cdc_internal.h"
+#include "conv_ws_kernel.h"
 #include "entropy.h"
 
 using namespace cdc;
@@ -66,13 +67,14 @@ struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                unsigned short *kvWh = nullptr; float kv_scale_inv = 1.f; };   // fp16 planes {WH, WL, WH2} of W' 2^s   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV, CONVPF, PFPACK } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV, CONVPF, PFPACK, CONVWS } kind;
     int prof = PC_SMALL;
     int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
     char label[96] = {0};
     double flops = 0, bytes = 0;
     ConvArgs conv; ConvPlan plan; int nz = 1;
     PfArgs pf; PfPlan pfplan;     // CONVPF: pre-split fp16 operands by LDS-DMA (conv_pf_kernel.h)
+    WsArgs ws; WsPlan wsplan;     // CONVWS: weight-stationary 3x3 convolution of the few-pixel levels (conv_ws_kernel.h)
     bool pw = false;              // CONVPF on conv_pw_kernel (pointwise, activations from the fp32 tensor)
     LnArgs ln;
     TembArgs temb;
@@ -656,7 +658,7 @@ struct Builder {
         op.id = (int)h->op_ms.size();
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
-        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack"};
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack", "convws"};
         if (op.kind == Op::PFPACK && op.pk.c4 == 2) kinds[Op::PFPACK] = "pfunpack";
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d tg%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
@@ -669,6 +671,9 @@ struct Builder {
                      op.pf.stride == 2 ? 2 : 1, op.pf.Cin, op.pf.Cout, op.pf.Ho, op.pf.Wo, op.pfplan.MB, op.pfplan.NPW, op.pfplan.WM, op.pfplan.WP,
                      op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
                      op.pf.resid ? " +res" : (op.pf.resid_pf ? " +resP" : ""), cur == &h->pre_ops ? " HOIST" : "", op.pf.tz == 4 ? " TZ4" : "");
+        else if (op.kind == Op::CONVWS)
+            snprintf(buf, sizeof buf, "conv 3x3 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS%s", op.ws.Cin, op.ws.Cout, op.ws.H, op.wsplan.W,
+                     op.wsplan.NPB, op.wsplan.waves, op.wsplan.tiles, op.wsplan.groups, op.ws.ln_part ? " LNload" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -1121,6 +1126,46 @@ struct Builder {
         return true;
     }
 
+    // 3x3 / stride-1 / pad-1 layer of a few-pixel level on conv_ws_kernel (conv_ws_kernel.h): the RAW result (bias added, no LayerNorm)
+    // goes to `raw`, the (mean, M2) of every pixel's 32-channel groups to `part` (may be null).  `lnl` (optional): the single source
+    // s0 is itself such a raw result and LayerNorm, ReLU and the time shift are applied while it is loaded.
+    struct LnLoad { const float *part; int G; const float *g, *b, *shift; };
+    bool ws_would_plan(const ConvW &w, int C0, bool two_src, int H, int W) {
+        if (h->arith != 1 || !w.wsh || planB > 0 || w.KH != 3 || w.KW != 3 || w.stride != 1 || w.transposed || w.nz != 1) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 1 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 1) return false;
+        if (w.COP != w.Cout || w.Cin_pad != w.Cin) return false;
+        WsPlan plan;
+        return ws_make_plan(w.Cin, two_src ? C0 : w.Cin, w.Cout, H, W, pb(), &plan);
+    }
+    bool try_ws(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W, float *raw,
+                long long raw_bs, float *part, const LnLoad *lnl, int prof) {
+        if (rc || !ws_would_plan(w, C0, s1 != nullptr, H, W) || (lnl && s1)) return false;
+        if (!ensure_f32(s0, bs0) || (s1 && !ensure_f32(s1, bs1))) return false;
+        Op op;
+        op.kind = Op::CONVWS; op.prof = prof;
+        if (!ws_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H, W, pb(), &op.wsplan)) return false;
+        WsArgs &a = op.ws;
+        memset(&a, 0, sizeof a);
+        a.x0 = s0; a.x0_bs = bs0; a.x1 = s1; a.x1_bs = bs1;
+        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.B = B;
+        if (lnl) { a.ln_part = lnl->part; a.ln_G = lnl->G; a.ln_g = lnl->g; a.ln_b = lnl->b; a.ln_shift = lnl->shift; a.shift_bs = h->shift_bs; }
+        a.eps = 1e-5f;
+        a.w = w.wsh; a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout; a.acc_scale = w.wscale_inv;
+        a.bias = w.bias;
+        a.out = raw; a.out_bs = raw_bs; a.stat_part = part;
+        a.fault = fault_flag();
+        const double px = (double)B * H * W;
+        op.flops = 2.0 * px * w.Cout * w.Cin * 9;
+        op.bytes = 4.0 * px * (w.Cin + w.Cout);
+        if (getenv("CDC_DEBUG_PLAN"))
+            fprintf(stderr, "[plan] conv 3x3 %d->%d out %dx%d on conv_ws_kernel: %d tiles x %d groups, %d waves, %zu bytes of LDS%s\n", w.Cin, w.Cout, H, W,
+                    op.wsplan.tiles, op.wsplan.groups, op.wsplan.waves, op.wsplan.lds_bytes, lnl ? ", LayerNorm on load" : "");
+        last_ksplit = 1;
+        last_pf_only = false;
+        emit(op);
+        return true;
+    }
+
     // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
     bool conv(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1,
@@ -1356,6 +1401,12 @@ struct Builder {
             op.pf_only = true;
             if (conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), op, true, prof)) return true;
         }
+        // few-pixel levels: the weight-stationary kernel (all of K in one workgroup, no partial-sum tensors) + an in-place LayerNorm pass
+        if (!pre_add && !want_res3 && !uf_c && !resid1 && out.bs() == (long long)w.Cout * H * W &&
+            try_ws(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), nullptr, nullptr, prof)) {
+            ln(out.p, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr);
+            return true;
+        }
         if (prefer_fused(w, H, W) && conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), o, true, prof))
             return true;
         if (uf_c) return false;
@@ -1469,6 +1520,14 @@ struct Builder {
             copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
             s0 = cat.p; s1 = nullptr; C0 = cat.C; bs0 = cat.bs(); bs1 = 0;
         }
+        // Few-pixel levels (round 5): both convolutions on conv_ws_kernel; block1's LayerNorm + ReLU + time shift are applied by block2
+        // WHILE IT LOADS h1 (from the per-group statistics block1's epilogue wrote): h1 is stored raw, once, and never normalised in
+        // HBM; one in-place LayerNorm pass (with the residual) finishes the block.
+        const bool ws_pair = !twin(h1.p) && !twin(out.p) && ws_would_plan(rb.c1, C0, s1 != nullptr, H, W) && ws_would_plan(rb.c2, rb.cout, false, H, W) &&
+                             !dev_env("CDC_NO_WS_LNLOAD");
+        float *part1 = ws_pair ? dalloc((size_t)B * (rb.cout / 32) * 2 * HW) : nullptr;
+        const bool ws1 = ws_pair && try_ws(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), part1, nullptr, prof1);
+        if (!ws1)
         block(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1, rb.g1, rb.b1, shift, nullptr, nullptr, 0, nullptr,
               nullptr, prof1, h1_pf_only);
         const float *res = s0;
@@ -1478,6 +1537,15 @@ struct Builder {
             conv(rb.cres, s0, C0, bs0, s1, bs1, H, W, r.p, r.bs(), ConvOpts(), false, PC_CONV1);
             res = r.p; res_bs = r.bs();
         }
+        if (ws1) {
+            const LnLoad lnl{part1, rb.cout / 32, rb.g1, rb.b1, shift};
+            if (!try_ws(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), nullptr, &lnl, PC_CONV3)) {
+                if (!rc) rc = fail(h, CDC_ERR_UNSUPPORTED, "conv_ws_kernel planned block1 of a ResnetBlock but not block2");
+                return out;
+            }
+            ln(out.p, out.p, rb.cout, HW, rb.g2, rb.b2, 1, nullptr, res, sm, sr);
+            last_pf_only = false;
+        } else
         block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
               res_bs, sm, sr, PC_CONV3, out_planes_only && twin(out.p));
         mark_planes_only(out);
@@ -1932,6 +2000,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             if (op.pw) HIP_TRY(h, pw_launch(op.pf, op.pfplan, B, st));
             else HIP_TRY(h, pf_launch(op.pf, op.pfplan, B, op.nz, st));
             break;
+        case Op::CONVWS: HIP_TRY(h, ws_launch(op.ws, op.wsplan, st)); break;
         case Op::PFPACK:
             if (op.pk.c4 == 2) {       // unpack: planes (pk.dst) -> the tensor's fp32 buffer (pk.src)
                 HIP_TRY(h, pf_unpack_launch(op.pk.dst, op.pk.dst_bs, const_cast<float *>(op.pk.src), op.pk.src_bs, op.pk.C, op.pk.H, op.pk.W, B, st));
@@ -3382,7 +3451,11 @@ static int op_conv2d_impl(cdc_handle *h, const float *x, const float *w, const f
     o.resid = dr; o.resid_bs = (long long)Cout * Ho * Wo; o.resid_cs = (long long)Ho * Wo;
     const long long obs = (long long)Cout * Ho * Wo;
     const int prof = KH == 7 ? PC_CONV7 : (KH == 1 ? PC_CONV1 : PC_CONV3);
-    if (dg) {
+    // few-pixel maps: the weight-stationary kernel (its raw result + the in-place LayerNorm pass; a bias-only call is the raw result)
+    if (dg && relu && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, nullptr, nullptr, prof)) {
+        bd.ln(dy, dy, Cout, Ho * Wo, dg, db, relu, ds, dr, nullptr, nullptr);
+    } else if (!dg && !relu && !ds && !dr && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, nullptr, nullptr, prof)) {
+    } else if (dg) {
         if (!bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, o, true, prof)) {
             bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, Builder::ConvOpts(),
                     false, prof);
@@ -3397,6 +3470,11 @@ static int op_conv2d_impl(cdc_handle *h, const float *x, const float *w, const f
         bool on_pf = false;
         for (const Op &q : h->ops) on_pf = on_pf || (q.kind == Op::CONVPF && !q.pw);
         if (!on_pf) return fail(h, CDC_ERR_UNSUPPORTED, "CDC_OP_REQUIRE_PF: the convolution was not planned on conv_pf_kernel");
+    }
+    if (dev_env("CDC_OP_REQUIRE_WS")) {       // ... or on the weight-stationary kernel of the few-pixel levels
+        bool on_ws = false;
+        for (const Op &q : h->ops) on_ws = on_ws || q.kind == Op::CONVWS;
+        if (!on_ws) return fail(h, CDC_ERR_UNSUPPORTED, "CDC_OP_REQUIRE_WS: the convolution was not planned on conv_ws_kernel");
     }
     return sc.run(B, y, dy, (size_t)B * Cout * Ho * Wo);
 }

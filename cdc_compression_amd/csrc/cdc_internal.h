@@ -66,6 +66,12 @@ hipError_t pf_launch(PfArgs a, const PfPlan &plan, int B, int nz, hipStream_t st
 // persistent ping-ponged kernel for the large 3x3 layers (conv_pf3_kernel.h, conv_inst_q.hip): decided on the complete argument block
 bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *plan);
 hipError_t pf3_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
+int device_cus();                 // CUs of the current device (256 when unknown)
+// weight-stationary 3x3 convolution of the few-pixel levels (conv_ws_kernel.h, conv_inst_t.hip)
+struct WsPlan { int W, NPB, waves, tiles, groups; size_t lds_bytes; };
+struct WsArgs;
+bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *plan);
+hipError_t ws_launch(WsArgs a, const WsPlan &plan, hipStream_t st);
 // pointwise (1x1) convolution with per-wave activation staging from the fp32 tensor (conv_pw_kernel.h, conv_inst_w.hip)
 bool pw_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);

@@ -14,7 +14,7 @@ static pf_kernel_fn pf3_lookup(int COPT, int epv) {
     return nullptr;
 }
 
-static int device_cus() {
+int device_cus() {
     static int n = 0;
     if (!n) {
         int dev = 0;

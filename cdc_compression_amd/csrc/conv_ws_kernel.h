@@ -1,0 +1,361 @@
+// conv_ws_kernel.h -- 3x3 / stride-1 / pad-1 convolutions of the FEW-PIXEL levels (maps 8, 16 or 32 pixels wide: the <= 16^2 trunk of
+// the U-Net, 256 - 768 input channels), weight-stationary in registers (round 5).
+//
+// What bounded these layers on conv_split2_kernel: 2 048 - 8 192 pixels per batch leave a launch < 3 workgroups per CU,
+// so K was sliced over workgroups (4 partial-sum tensors + a LayerNorm pass that adds them), and a 32 x 32 wave tile fetches one
+// A and one B operand from LDS per MFMA: 5 ds_read_b128 per 3 MFMAs -- LDS-bandwidth-bound at 12 waves per CU.
+//
+// Here K is sliced over the WAVES of one workgroup instead, and the weights never touch LDS:
+//   * workgroup = (32 output channels) x (NPB 32-pixel blocks = 128 pixels: two 8x8 images or half a 16x16 one) x ALL of K;
+//     wave w owns the 16-channel chunks w, w + NW, ... of the input;
+//   * for its chunk a wave loads the weight operands (planes WH, WL, WH2; a kernel row at a time, two register sets: the next row's
+//     loads fly while this one multiplies) straight from global memory in A-operand order and keeps a row for all NPB pixel blocks: per pixel block and tap only the two activation planes (h, l') come from LDS --
+//     2 ds_read_b128 per 3 MFMAs instead of 5: the loop is matrix-bound, not LDS-bound;
+//   * the wave converts its own chunk of the input (fp32 NCHW -> two fp16 planes, conv_split_kernel.h AR = 1) into its own LDS
+//     patch: no cross-wave synchronisation inside the K loop at all.  LayerNorm-on-load (LN = true): the input is the RAW result of
+//     the previous convolution of this kernel and (x - mean) * rstd * g + b, ReLU, + shift is applied while converting -- the
+//     statistics are combined (Chan) from the per-(pixel, 32-channel group) (mean, M2) partials that kernel's epilogue wrote; the
+//     LayerNorm pass between block1 and block2 of a ResnetBlock and its tensor disappear;
+//   * the NW partial accumulators meet in LDS once, after the K loop (no partial-sum tensors in HBM, no sum pass); the epilogue
+//     stores the raw result (bias added) and the (mean, M2) of its 32 channels per pixel.
+// fp32 accumulation; the chunk order of the sum is fixed by (nchunk, NW): deterministic.
+#pragma once
+#include "conv_pf_kernel.h"
+
+namespace cdc {
+
+struct WsArgs {
+    const float *x0, *x1;           // fp32 NCHW sources (channel concatenation; x1 may be null)
+    long long x0_bs, x1_bs;         // batch strides in floats
+    int C0, Cin;                    // channels taken from x0; total (both multiples of 16)
+    int H, B;                       // rows of the map (its width is the template parameter), batch
+    // LayerNorm on load (LN = true): x0 holds raw convolution results, ln_part the partial statistics of its producer
+    const float *ln_part;           // [B][ln_G][2][H*W]: mean and M2 (sum of squared deviations) of each 32-channel group
+    int ln_G;
+    const float *ln_g, *ln_b;       // [Cin]
+    float eps;
+    const float *ln_shift;          // + shift[b * shift_bs + c] after the ReLU (time embedding), or null
+    int shift_bs;
+    const void *w;                  // fp16 planes {WH, WL, WH2} of w 2^s: [tap][Cin/16][3][2][COP] 16-byte units
+    int nchunk, cpw;                // 16-channel chunks; chunks per wave (nchunk = cpw * waves)
+    int COP, Cout;
+    float acc_scale;                // 2^-s
+    const float *bias;              // [Cout] or null
+    float *out;                     // raw result, fp32 NCHW
+    long long out_bs;
+    float *stat_part;               // [B][groups][2][H*W] partial statistics of `out`, or null
+    int tiles, groups;              // pixel tiles; 32-channel groups of Cout (gridDim.x = tiles * groups)
+    int xcd_remap;
+    int *fault;                     // range guard (ConvArgs::fault)
+};
+
+// LDS bytes of a launch: the waves' patches during the K loop (the partial accumulators after it) + the LayerNorm-on-load tables
+// (g, b [Cin], shift [images of a tile][Cin], per-pixel mean / rstd of the tile's loaded rows)
+__host__ __device__ inline int ws_ppix(int W, int H, int NPB) {
+    const int tpx = NPB * 32, hw = H * W;
+    return (tpx >= hw ? tpx / hw : 1) * ((tpx >= hw ? H : tpx / W) + 2) * (W + 2);
+}
+__host__ __device__ inline int ws_nload(int W, int H, int NPB) {
+    const int tpx = NPB * 32, hw = H * W;
+    return tpx >= hw ? tpx : (tpx / W + 2) * W;
+}
+__host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves, int Cin, bool ln) {
+    const int tpx = NPB * 32, hw = H * W, n_img = tpx >= hw ? tpx / hw : 1;
+    const size_t patches = (size_t)waves * 4 * ws_ppix(W, H, NPB) * 16, red = (size_t)waves * NPB * 4096;
+    const size_t tab = ln ? ((size_t)(2 + n_img) * Cin + 2 * ws_nload(W, H, NPB)) * 4 : 0;
+    return (patches > red ? patches : red) + ((tab + 15) & ~(size_t)15);
+}
+
+template <int W_, int NPB, bool LN>
+__global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
+    static_assert(W_ == 8 || W_ == 16 || W_ == 32, "map width");
+    // (the fields the kernel uses, as locals: the lambdas below capture THESE -- capturing the argument block itself made hipcc copy it to scratch)
+    const auto a_x0 = PA.x0;
+    const auto a_x1 = PA.x1;
+    const auto a_x0_bs = PA.x0_bs;
+    const auto a_x1_bs = PA.x1_bs;
+    const auto a_C0 = PA.C0;
+    const auto a_Cin = PA.Cin;
+    const auto a_H = PA.H;
+    const auto a_ln_part = PA.ln_part;
+    const auto a_ln_G = PA.ln_G;
+    const auto a_ln_g = PA.ln_g;
+    const auto a_ln_b = PA.ln_b;
+    const auto a_eps = PA.eps;
+    const auto a_ln_shift = PA.ln_shift;
+    const auto a_shift_bs = PA.shift_bs;
+    const auto a_w = PA.w;
+    const auto a_nchunk = PA.nchunk;
+    const auto a_cpw = PA.cpw;
+    const auto a_COP = PA.COP;
+    const auto a_acc_scale = PA.acc_scale;
+    const auto a_bias = PA.bias;
+    const auto a_out = PA.out;
+    const auto a_out_bs = PA.out_bs;
+    const auto a_stat_part = PA.stat_part;
+    const auto a_tiles = PA.tiles;
+    const auto a_groups = PA.groups;
+    const auto a_xcd_remap = PA.xcd_remap;
+    const auto a_fault = PA.fault;
+    constexpr int PW = W_ + 2, TPX = NPB * 32;
+    constexpr int MAXLOAD = TPX + 2 * W_;                       // most pixels a tile loads (a band of rows + its two neighbour rows)
+    constexpr int NIT = (2 * MAXLOAD + 63) / 64;                // loader passes: an item = 8 channels (one k-half) of one pixel
+    extern __shared__ __attribute__((aligned(16))) uint4 ws_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const int n = lane & 31, kg = lane >> 5;
+    const int H = a_H, HW = H * W_;
+    // ---- this workgroup: channel group g, pixel tile (whole images, or R rows of one image) ------------------------------------
+    int slot = blockIdx.x;
+    if (a_xcd_remap) slot = (blockIdx.x & 7) * ((int)gridDim.x >> 3) + (blockIdx.x >> 3);     // one contiguous (group-major) band per XCD: its L2 holds ~groups / 8 weight slices
+    const int g = slot / a_tiles, tile = slot - g * a_tiles;
+    const bool whole = TPX >= HW;
+    const int n_img = whole ? TPX / HW : 1, R = whole ? H : TPX / W_, PR = R + 2, PPIX = n_img * PR * PW;
+    const int parts = whole ? 1 : HW / TPX;
+    const int b0 = whole ? tile * n_img : tile / parts, y0 = whole ? 0 : (tile - b0 * parts) * R;
+    // loaded rows of an image part: whole images rows 0 .. H-1 (patch rows 1 .. H); a part also its neighbour rows (patch rows 0 .. R+1)
+    const int row0 = whole ? 1 : 0, nrow = whole ? H : PR, nload = n_img * nrow * W_;
+    uint4 *patch = ws_smem + (size_t)wave * 4 * PPIX;
+    // LayerNorm-on-load tables behind the patches / the reduction scratch
+    const size_t main_units = (size_t)nw * 4 * PPIX > (size_t)nw * NPB * 256 ? (size_t)nw * 4 * PPIX : (size_t)nw * NPB * 256;
+    float *t_g = reinterpret_cast<float *>(ws_smem + main_units), *t_b = t_g + a_Cin, *t_sh = t_b + a_Cin;       // [Cin], [Cin], [n_img][Cin]
+    float *t_mu = t_sh + (size_t)n_img * a_Cin, *t_rs = t_mu + nload;                                             // [nload] each
+
+    if constexpr (LN) {
+        for (int c = tid; c < a_Cin; c += (int)blockDim.x) {
+            t_g[c] = a_ln_g[c]; t_b[c] = a_ln_b[c];
+            for (int i = 0; i < n_img; ++i) t_sh[i * a_Cin + c] = a_ln_shift ? a_ln_shift[(size_t)(b0 + i) * a_shift_bs + c] : 0.f;
+        }
+        // per-pixel statistics: Chan's combination of the per-group (mean, M2) partials, 32 channels each (network_components.py:56-66:
+        // biased variance).  All loads of a pixel are issued before the first use (groups in batches of 12).
+        for (int idx = tid; idx < nload; idx += (int)blockDim.x) {
+            const int img = idx / (nrow * W_), rem = idx - img * (nrow * W_), r = rem / W_, x = rem - r * W_;
+            const int y = y0 - 1 + row0 + r;
+            float mean = 0.f, rstd = 0.f;
+            if (y >= 0 && y < H) {
+                const float *sp = a_ln_part + (size_t)(b0 + img) * a_ln_G * 2 * HW + y * W_ + x;
+                float s = 0.f, q2 = 0.f, qm = 0.f;             // sum of group means; sum of M2; sum of squared deviations of the group means
+                for (int q0 = 0; q0 < a_ln_G; q0 += 12) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {             // unconditional (clamped) loads: all 24 in flight together
+                        const int qq = min(q0 + q, a_ln_G - 1);
+                        const float m = sp[(size_t)qq * 2 * HW], v = sp[(size_t)qq * 2 * HW + HW];
+                        s += q0 + q < a_ln_G ? m : 0.f;
+                        q2 += q0 + q < a_ln_G ? v : 0.f;
+                    }
+                }
+                mean = s / (float)a_ln_G;
+                for (int q0 = 0; q0 < a_ln_G; q0 += 12) {      // second pass over the (cached) means
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {
+                        const int qq = min(q0 + q, a_ln_G - 1);
+                        const float d = sp[(size_t)qq * 2 * HW] - mean;
+                        qm += q0 + q < a_ln_G ? d * d : 0.f;
+                    }
+                }
+                rstd = 1.0f / sqrtf((q2 + 32.f * qm) / (32.f * (float)a_ln_G) + a_eps);
+            }
+            t_mu[idx] = mean; t_rs[idx] = rstd;
+        }
+    }
+    // zero halo (and the rows outside the image): written once, the loader only ever writes image pixels
+    for (int i = lane; i < 4 * PPIX; i += 64) patch[i] = make_uint4(0, 0, 0, 0);
+    if constexpr (LN) __syncthreads();
+
+    // ---- loader items of this lane (the same for every chunk): item e = pass * 64 + lane -> (k-half, loaded pixel) ---------------
+    int l_off[NIT];                            // float offset inside a channel plane (+ image stride), -1: nothing to load
+    int l_tab[NIT];                            // patch unit incl. the k-half (12 bits) | index of the pixel's statistics << 12 | image << 20 | k-half << 24
+    static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
+        constexpr int it = decltype(itc)::value;
+        const int e = it * 64 + lane;
+        l_off[it] = -1; l_tab[it] = 0;
+        if (e < 2 * nload) {
+            const int k2 = e / nload, idx = e - k2 * nload;
+            const int img = idx / (nrow * W_), rem = idx - img * (nrow * W_), r = rem / W_, x = rem - r * W_;
+            const int y = y0 - 1 + row0 + r;
+            if (y >= 0 && y < H) {
+                l_off[it] = k2 * 8 * HW + y * W_ + x;            // (+ img * batch stride: added per source below)
+                l_tab[it] = ((k2 * 2) * PPIX + (img * PR + row0 + r) * PW + x + 1) | (idx << 12) | (img << 20) | (k2 << 24);
+            }
+        }
+    });
+
+    // ---- B-operand base of every pixel block: lane = pixel n of the block, k-half kg ---------------------------------------------
+    int bbase[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int p = pb * 32 + n;
+        const int img = whole ? p / HW : 0, rem = p - img * HW, y = rem / W_, x = rem - y * W_;     // (part of an image: y counts from y0)
+        bbase[pb] = (kg * 2) * PPIX + (img * PR + y) * PW + x;
+    }
+    const size_t tap_stride = (size_t)a_nchunk * 6 * a_COP;
+
+    f32x16 acc[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
+
+    const int c0_chunks = a_C0 >> 4;
+    float xv[NIT][8];
+    // x loads of a chunk: 8 channels of one pixel per item (4-byte accesses, 256-byte runs per instruction)
+    // (every global access of the K loop is "uniform 64-bit base + 32-bit lane offset": the saddr form, no 64-bit vector address arithmetic)
+    auto load_x = [&](int chunk) __attribute__((always_inline)) {
+        const bool from0 = chunk < c0_chunks;
+        const int cc = from0 ? chunk * 16 : (chunk - c0_chunks) * 16;
+        const long long sbs = from0 ? a_x0_bs : a_x1_bs;
+        const char *src = reinterpret_cast<const char *>((from0 ? a_x0 : a_x1) + (size_t)b0 * sbs + (size_t)cc * HW);
+        static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
+            constexpr int it = decltype(itc)::value;
+            const unsigned vo = l_off[it] >= 0 ? (unsigned)(((l_tab[it] >> 20) & 0xf) * (int)sbs + l_off[it]) * 4u : 0u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const char *sc = src + (size_t)c * HW * 4;             // (uniform: scalar arithmetic)
+                const float v = *reinterpret_cast<const float *>(sc + vo);
+                xv[it][c] = l_off[it] >= 0 ? v : 0.f;
+            }
+        });
+    };
+    // fp32 -> (LayerNorm, ReLU, shift) -> planes h, l' in this wave's patch
+    auto convert_x = [&](int chunk) __attribute__((always_inline)) {
+        static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
+            constexpr int it = decltype(itc)::value;
+            if (l_off[it] < 0) return;
+            float gg[8], bb[8], ss[8], mu = 0.f, rs = 0.f;
+            if constexpr (LN) {
+                const int c8 = chunk * 16 + ((l_tab[it] >> 24) & 1) * 8, img = (l_tab[it] >> 20) & 0xf;
+                const float4 g0 = *reinterpret_cast<const float4 *>(t_g + c8), g1 = *reinterpret_cast<const float4 *>(t_g + c8 + 4);
+                const float4 b0v = *reinterpret_cast<const float4 *>(t_b + c8), b1v = *reinterpret_cast<const float4 *>(t_b + c8 + 4);
+                const float4 s0 = *reinterpret_cast<const float4 *>(t_sh + img * a_Cin + c8), s1 = *reinterpret_cast<const float4 *>(t_sh + img * a_Cin + c8 + 4);
+                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+                bb[0] = b0v.x; bb[1] = b0v.y; bb[2] = b0v.z; bb[3] = b0v.w; bb[4] = b1v.x; bb[5] = b1v.y; bb[6] = b1v.z; bb[7] = b1v.w;
+                ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+                mu = t_mu[(l_tab[it] >> 12) & 0xff]; rs = t_rs[(l_tab[it] >> 12) & 0xff];
+            }
+            f16x8 vh, vl;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = xv[it][c];
+                if constexpr (LN) {
+                    v = (v - mu) * rs * gg[c] + bb[c];
+                    v = fmaxf(v, 0.f * v) + ss[c];                  // ReLU that keeps a NaN alive (range guard), then the time shift
+                }
+                _Float16 hq, lq;
+                split2h(v, hq, lq);
+                vh[c] = hq; vl[c] = lq;
+            }
+            patch[l_tab[it] & 0xfff] = __builtin_bit_cast(uint4, vh);
+            patch[(l_tab[it] & 0xfff) + PPIX] = __builtin_bit_cast(uint4, vl);
+        });
+    };
+    // weights of one kernel row of a chunk: 3 taps x planes {WH, WL, WH2 = WH 2^-11}, one 16-byte unit per lane each (A-operand order in
+    // memory).  Three planes and ONE accumulator set (the plane-operand kernels hold two sets and two planes): the registers go to the
+    // loads in flight instead.
+    f16x8 A[2][3][3];
+    const unsigned wlane = (unsigned)(kg * a_COP + g * 32 + n) * 16u;
+    auto load_a = [&](auto bufc, int chunk, int row) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const char *wc = reinterpret_cast<const char *>(a_w) + ((size_t)chunk * 6 * a_COP + (size_t)(row * 3) * tap_stride) * 16;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                A[buf][t][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(wc + ((size_t)t * tap_stride + (size_t)pl * 2 * a_COP) * 16 + wlane));
+    };
+    // a = h + l' 2^-11, w 2^s = WH + WL:  acc += WL.h + WH2.l' + WH.h
+    auto mma_row = [&](auto bufc, auto rowc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value, row = decltype(rowc)::value;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int koff = row * PW + t;
+                const f16x8 bh = __builtin_bit_cast(f16x8, patch[bbase[pb] + koff]);
+                const f16x8 bl = __builtin_bit_cast(f16x8, patch[bbase[pb] + PPIX + koff]);
+                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][1], bh, acc[pb], 0, 0, 0);
+                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][2], bl, acc[pb], 0, 0, 0);
+                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][0], bh, acc[pb], 0, 0, 0);
+            }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    // One chunk.  In flight while it multiplies: the next kernel row's weights (two register sets) and, from its second row on, the
+    // NEXT chunk's input values -- the chunk boundary costs the conversion, no exposed load latency.
+    auto chunk_body = [&](auto parc, int ci) __attribute__((always_inline)) {
+        constexpr int p0 = decltype(parc)::value;
+        typedef std::integral_constant<int, p0> PA;
+        typedef std::integral_constant<int, p0 ^ 1> PB;
+        const int chunk = __builtin_amdgcn_readfirstlane(wave + ci * nw);
+        const int nxt = __builtin_amdgcn_readfirstlane(wave + (ci + 1 < a_cpw ? ci + 1 : ci) * nw);      // (past the last chunk: a harmless re-read)
+        convert_x(chunk);
+        load_a(PB{}, chunk, 1);
+        mma_row(PA{}, I0{});
+        load_a(PA{}, chunk, 2);
+        load_x(nxt);
+        mma_row(PB{}, I1{});
+        load_a(PB{}, nxt, 0);
+        mma_row(PA{}, I2{});
+    };
+    load_x(wave);
+    load_a(I0{}, wave, 0);
+    for (int ci = 0; ci < a_cpw; ci += 2) {
+        chunk_body(I0{}, ci);
+        if (ci + 1 < a_cpw) chunk_body(I1{}, ci + 1);
+    }
+
+    // ---- the K slices of the waves meet in LDS: red[wave][pb][4 regs x 4][lane] --------------------------------------------------
+    __syncthreads();                                            // every wave is done with its patch
+    float4 *red = reinterpret_cast<float4 *>(ws_smem);
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = make_float4(acc[pb][4 * q + 0], acc[pb][4 * q + 1], acc[pb][4 * q + 2], acc[pb][4 * q + 3]);
+            red[((wave * NPB + pb) * 4 + q) * 64 + lane] = v;
+        }
+    __syncthreads();
+    // wave pb finishes pixel block pb (waves beyond NPB are done; fewer waves than blocks: a wave takes several)
+    for (int pb = wave; pb < NPB; pb += nw) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 s = red[((0 * NPB + pb) * 4 + q) * 64 + lane];
+            for (int w = 1; w < nw; ++w) {                      // fixed order: deterministic
+                const float4 t = red[((w * NPB + pb) * 4 + q) * 64 + lane];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            v[4 * q + 0] = s.x; v[4 * q + 1] = s.y; v[4 * q + 2] = s.z; v[4 * q + 3] = s.w;
+        }
+        // accumulator layout: lane = pixel n, register r -> channel (r & 3) + 8 (r >> 2) + 4 kg of the group
+        const int p = pb * 32 + n;
+        const int img = whole ? p / HW : 0, pix = whole ? p - img * HW : y0 * W_ + p;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            v[r] = v[r] * a_acc_scale + (a_bias ? a_bias[co] : 0.f);
+            sum += v[r];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 32.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 32);
+        if (a_fault && !(m2 < 3.0e38f)) *a_fault = 1;           // non-finite accumulators: reported before any LayerNorm can hide them
+        float *o = a_out + (size_t)(b0 + img) * a_out_bs + (size_t)(g * 32 + 4 * kg) * HW + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];
+        if (a_stat_part && kg == 0) {
+            float *sp = a_stat_part + ((size_t)(b0 + img) * a_groups + g) * 2 * HW + pix;
+            sp[0] = mean;
+            sp[HW] = m2;
+        }
+    }
+}
+
+typedef void (*ws_kernel_fn)(const WsArgs);
+
+}  // namespace cdc
