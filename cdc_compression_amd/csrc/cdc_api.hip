@@ -1524,8 +1524,8 @@ struct Builder {
         // WHILE IT LOADS h1 (from the per-group statistics block1's epilogue wrote): h1 is stored raw, once, and never normalised in
         // HBM; one in-place LayerNorm pass (with the residual) finishes the block.
         const bool ws_pair = !twin(h1.p) && !twin(out.p) && ws_would_plan(rb.c1, C0, s1 != nullptr, H, W) && ws_would_plan(rb.c2, rb.cout, false, H, W) &&
-                             !dev_env("CDC_NO_WS_LNLOAD");
-        float *part1 = ws_pair ? dalloc((size_t)B * (rb.cout / 32) * 2 * HW) : nullptr;
+                             rb.cout / 16 <= kWsMaxG && !dev_env("CDC_NO_WS_LNLOAD");
+        float *part1 = ws_pair ? dalloc((size_t)B * (rb.cout / 16) * 2 * HW) : nullptr;
         const bool ws1 = ws_pair && try_ws(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), part1, nullptr, prof1);
         if (!ws1)
         block(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1, rb.g1, rb.b1, shift, nullptr, nullptr, 0, nullptr,
@@ -1538,7 +1538,7 @@ struct Builder {
             res = r.p; res_bs = r.bs();
         }
         if (ws1) {
-            const LnLoad lnl{part1, rb.cout / 32, rb.g1, rb.b1, shift};
+            const LnLoad lnl{part1, rb.cout / 16, rb.g1, rb.b1, shift};
             if (!try_ws(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), nullptr, &lnl, PC_CONV3)) {
                 if (!rc) rc = fail(h, CDC_ERR_UNSUPPORTED, "conv_ws_kernel planned block1 of a ResnetBlock but not block2");
                 return out;

@@ -60,10 +60,40 @@ hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
         if (dev >= 0 && dev < 16) attr_done[dev][wi][ln] = true;
     }
     a.tiles = p.tiles; a.groups = p.groups;
+    a.dbg = 0;
+#ifdef CDC_WS_LAB
+    a.dbg = dev_env("CDC_WS_DBG") ? atoi(dev_env("CDC_WS_DBG")) : 0;
+#endif
     a.cpw = a.nchunk / p.waves;
     const unsigned grid = (unsigned)(p.tiles * p.groups);
     a.xcd_remap = (grid % 8 == 0 && grid >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+#ifdef CDC_WS_LAB
+    static unsigned long long *tl = nullptr;
+    static int tl_n = 0;
+    if (dev_env("CDC_WS_TL")) {
+        if (!tl) (void)hipMalloc((void **)&tl, (size_t)8192 * 16 * 8);
+        (void)hipMemsetAsync(tl, 0, (size_t)8192 * 16 * 8, st);
+        a.tl = grid <= 8192 ? tl : nullptr;
+    } else a.tl = nullptr;
+#endif
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * p.waves), ws_lds_bytes(p.W, a.H, p.NPB, p.waves, a.Cin, ln), st, a);
+#ifdef CDC_WS_LAB
+    if (a.tl && tl_n++ >= 40 && tl_n < 63) {                 // the launches of the third DDIM iteration: mean stamps over the grid
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        (void)hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost);
+        double d[16] = {0}; unsigned long long first = ~0ull, last = 0;
+        for (unsigned g = 0; g < grid; ++g) {
+            const unsigned long long *t = &h[(size_t)g * 16];
+            for (int i = 1; i < 16; ++i) if (t[i]) d[i] += (double)(t[i] - t[0]);
+            if (t[0] < first) first = t[0];
+            if (t[15] > last) last = t[15];
+        }
+        fprintf(stderr, "[ws-tl] Cin=%d Cout=%d H=%d W=%d waves=%d ln=%d grid=%u | span %llu | mean since start:", a.Cin, a.Cout, a.H, p.W, p.waves, (int)ln, grid, last - first);
+        for (int i = 1; i < 16; ++i) fprintf(stderr, " %d:%.0f", i, d[i] / grid);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 

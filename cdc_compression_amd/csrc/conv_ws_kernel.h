@@ -17,7 +17,7 @@
 //     statistics are combined (Chan) from the per-(pixel, 32-channel group) (mean, M2) partials that kernel's epilogue wrote; the
 //     LayerNorm pass between block1 and block2 of a ResnetBlock and its tensor disappear;
 //   * the NW partial accumulators meet in LDS once, after the K loop (no partial-sum tensors in HBM, no sum pass); the epilogue
-//     stores the raw result (bias added) and the (mean, M2) of its 32 channels per pixel.
+//     (all waves) stores the raw result (bias added) and, per pixel, the (mean, M2) of each 16-channel half of its 32 channels.
 // fp32 accumulation; the chunk order of the sum is fixed by (nchunk, NW): deterministic.
 #pragma once
 #include "conv_pf_kernel.h"
@@ -30,7 +30,7 @@ struct WsArgs {
     int C0, Cin;                    // channels taken from x0; total (both multiples of 16)
     int H, B;                       // rows of the map (its width is the template parameter), batch
     // LayerNorm on load (LN = true): x0 holds raw convolution results, ln_part the partial statistics of its producer
-    const float *ln_part;           // [B][ln_G][2][H*W]: mean and M2 (sum of squared deviations) of each 32-channel group
+    const float *ln_part;           // [B][ln_G][2][H*W]: mean and M2 (sum of squared deviations) of each 16-channel group (ln_G = Cin / 16 <= kWsMaxG)
     int ln_G;
     const float *ln_g, *ln_b;       // [Cin]
     float eps;
@@ -43,11 +43,17 @@ struct WsArgs {
     const float *bias;              // [Cout] or null
     float *out;                     // raw result, fp32 NCHW
     long long out_bs;
-    float *stat_part;               // [B][groups][2][H*W] partial statistics of `out`, or null
+    float *stat_part;               // [B][2 * groups][2][H*W] partial statistics of `out` (mean, M2 of each 16-channel half of a group), or null
     int tiles, groups;              // pixel tiles; 32-channel groups of Cout (gridDim.x = tiles * groups)
     int xcd_remap;
     int *fault;                     // range guard (ConvArgs::fault)
+#ifdef CDC_WS_LAB
+    unsigned long long *tl;         // 16 cycle stamps per workgroup (wave 0)
+#endif
+    int dbg;                        // -DCDC_WS_LAB builds only (CDC_WS_DBG, timing experiments, wrong results): 1 no MFMAs, 8 no reduction / epilogue
 };
+
+constexpr int kWsMaxG = 24;          // most 16-channel statistic groups of a LayerNorm-on-load input (384 channels)
 
 // LDS bytes of a launch: the waves' patches during the K loop (the partial accumulators after it) + the LayerNorm-on-load tables
 // (g, b [Cin], shift [images of a tile][Cin], per-pixel mean / rstd of the tile's loaded rows)
@@ -66,9 +72,17 @@ __host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves,
     return (patches > red ? patches : red) + ((tab + 15) & ~(size_t)15);
 }
 
+#ifdef CDC_WS_LAB
+#define WS_STAMP(i) do { if (PA.tl && threadIdx.x == 0) PA.tl[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WS_STAMP(i) do { } while (0)
+#endif
+
 template <int W_, int NPB, bool LN>
 __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     static_assert(W_ == 8 || W_ == 16 || W_ == 32, "map width");
+    static_assert(NPB % 2 == 0, "pixel blocks are multiplied in pairs");
+    WS_STAMP(0);
     // (the fields the kernel uses, as locals: the lambdas below capture THESE -- capturing the argument block itself made hipcc copy it to scratch)
     const auto a_x0 = PA.x0;
     const auto a_x1 = PA.x1;
@@ -97,6 +111,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     const auto a_groups = PA.groups;
     const auto a_xcd_remap = PA.xcd_remap;
     const auto a_fault = PA.fault;
+    const int a_dbg = PA.dbg;
     constexpr int PW = W_ + 2, TPX = NPB * 32;
     constexpr int MAXLOAD = TPX + 2 * W_;                       // most pixels a tile loads (a band of rows + its two neighbour rows)
     constexpr int NIT = (2 * MAXLOAD + 63) / 64;                // loader passes: an item = 8 channels (one k-half) of one pixel
@@ -122,48 +137,10 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     float *t_g = reinterpret_cast<float *>(ws_smem + main_units), *t_b = t_g + a_Cin, *t_sh = t_b + a_Cin;       // [Cin], [Cin], [n_img][Cin]
     float *t_mu = t_sh + (size_t)n_img * a_Cin, *t_rs = t_mu + nload;                                             // [nload] each
 
-    if constexpr (LN) {
-        for (int c = tid; c < a_Cin; c += (int)blockDim.x) {
-            t_g[c] = a_ln_g[c]; t_b[c] = a_ln_b[c];
-            for (int i = 0; i < n_img; ++i) t_sh[i * a_Cin + c] = a_ln_shift ? a_ln_shift[(size_t)(b0 + i) * a_shift_bs + c] : 0.f;
-        }
-        // per-pixel statistics: Chan's combination of the per-group (mean, M2) partials, 32 channels each (network_components.py:56-66:
-        // biased variance).  All loads of a pixel are issued before the first use (groups in batches of 12).
-        for (int idx = tid; idx < nload; idx += (int)blockDim.x) {
-            const int img = idx / (nrow * W_), rem = idx - img * (nrow * W_), r = rem / W_, x = rem - r * W_;
-            const int y = y0 - 1 + row0 + r;
-            float mean = 0.f, rstd = 0.f;
-            if (y >= 0 && y < H) {
-                const float *sp = a_ln_part + (size_t)(b0 + img) * a_ln_G * 2 * HW + y * W_ + x;
-                float s = 0.f, q2 = 0.f, qm = 0.f;             // sum of group means; sum of M2; sum of squared deviations of the group means
-                for (int q0 = 0; q0 < a_ln_G; q0 += 12) {
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) {             // unconditional (clamped) loads: all 24 in flight together
-                        const int qq = min(q0 + q, a_ln_G - 1);
-                        const float m = sp[(size_t)qq * 2 * HW], v = sp[(size_t)qq * 2 * HW + HW];
-                        s += q0 + q < a_ln_G ? m : 0.f;
-                        q2 += q0 + q < a_ln_G ? v : 0.f;
-                    }
-                }
-                mean = s / (float)a_ln_G;
-                for (int q0 = 0; q0 < a_ln_G; q0 += 12) {      // second pass over the (cached) means
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) {
-                        const int qq = min(q0 + q, a_ln_G - 1);
-                        const float d = sp[(size_t)qq * 2 * HW] - mean;
-                        qm += q0 + q < a_ln_G ? d * d : 0.f;
-                    }
-                }
-                rstd = 1.0f / sqrtf((q2 + 32.f * qm) / (32.f * (float)a_ln_G) + a_eps);
-            }
-            t_mu[idx] = mean; t_rs[idx] = rstd;
-        }
-    }
-    // zero halo (and the rows outside the image): written once, the loader only ever writes image pixels
-    for (int i = lane; i < 4 * PPIX; i += 64) patch[i] = make_uint4(0, 0, 0, 0);
-    if constexpr (LN) __syncthreads();
-
     // ---- loader items of this lane (the same for every chunk): item e = pass * 64 + lane -> (k-half, loaded pixel) ---------------
+    // (no runtime divisions in the set-up: a tile holds at most four images -- compare chains -- and W_ is a power of two)
+    const int per_img = nrow * W_;
+    auto img_of = [](int i, int per) __attribute__((always_inline)) { return (i >= per ? 1 : 0) + (i >= 2 * per ? 1 : 0) + (i >= 3 * per ? 1 : 0); };
     int l_off[NIT];                            // float offset inside a channel plane (+ image stride), -1: nothing to load
     int l_tab[NIT];                            // patch unit incl. the k-half (12 bits) | index of the pixel's statistics << 12 | image << 20 | k-half << 24
     static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
@@ -171,8 +148,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
         const int e = it * 64 + lane;
         l_off[it] = -1; l_tab[it] = 0;
         if (e < 2 * nload) {
-            const int k2 = e / nload, idx = e - k2 * nload;
-            const int img = idx / (nrow * W_), rem = idx - img * (nrow * W_), r = rem / W_, x = rem - r * W_;
+            const int k2 = e >= nload ? 1 : 0, idx = e - k2 * nload;
+            const int img = img_of(idx, per_img), rem = idx - img * per_img, r = rem / W_, x = rem - r * W_;
             const int y = y0 - 1 + row0 + r;
             if (y >= 0 && y < H) {
                 l_off[it] = k2 * 8 * HW + y * W_ + x;            // (+ img * batch stride: added per source below)
@@ -180,22 +157,6 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
             }
         }
     });
-
-    // ---- B-operand base of every pixel block: lane = pixel n of the block, k-half kg ---------------------------------------------
-    int bbase[NPB];
-#pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-        const int p = pb * 32 + n;
-        const int img = whole ? p / HW : 0, rem = p - img * HW, y = rem / W_, x = rem - y * W_;     // (part of an image: y counts from y0)
-        bbase[pb] = (kg * 2) * PPIX + (img * PR + y) * PW + x;
-    }
-    const size_t tap_stride = (size_t)a_nchunk * 6 * a_COP;
-
-    f32x16 acc[NPB];
-#pragma unroll
-    for (int pb = 0; pb < NPB; ++pb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
 
     const int c0_chunks = a_C0 >> 4;
     float xv[NIT][8];
@@ -217,6 +178,84 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
             }
         });
     };
+    const size_t tap_stride = (size_t)a_nchunk * 6 * a_COP;
+    // weights of one kernel row of a chunk: 3 taps x planes {WH, WL, WH2 = WH 2^-11}, one 16-byte unit per lane each (A-operand order in
+    // memory).  Three planes and ONE accumulator set (the plane-operand kernels hold two sets and two planes): the registers go to the
+    // loads in flight instead.
+    f16x8 A[2][3][3];
+    const unsigned wlane = (unsigned)(kg * a_COP + g * 32 + n) * 16u;
+    auto load_a = [&](auto bufc, int chunk, int row) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const char *wc = reinterpret_cast<const char *>(a_w) + ((size_t)chunk * 6 * a_COP + (size_t)(row * 3) * tap_stride) * 16;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                A[buf][t][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(wc + ((size_t)t * tap_stride + (size_t)pl * 2 * a_COP) * 16 + wlane));
+    };
+    typedef std::integral_constant<int, 0> I0;
+    // the first chunk's input values and first kernel row are requested before anything else is set up
+    load_x(wave);
+    load_a(I0{}, wave, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_STAMP(1);
+    if constexpr (LN) {
+        for (int c = tid; c < a_Cin; c += (int)blockDim.x) {
+            t_g[c] = a_ln_g[c]; t_b[c] = a_ln_b[c];
+            for (int i = 0; i < n_img; ++i) t_sh[i * a_Cin + c] = a_ln_shift ? a_ln_shift[(size_t)(b0 + i) * a_shift_bs + c] : 0.f;
+        }
+        WS_STAMP(2);
+        // per-pixel statistics: Chan's combination of the per-group (mean, M2) partials, 16 channels each (network_components.py:56-66:
+        // biased variance).  All loads of a pixel are issued before the first use (groups in batches of 12).
+        for (int idx = tid; idx < nload; idx += (int)blockDim.x) {
+            const int img = img_of(idx, per_img), rem = idx - img * per_img, r = rem / W_, x = rem - r * W_;
+            const int y = y0 - 1 + row0 + r;
+            float mean = 0.f, rstd = 0.f;
+            if (y >= 0 && y < H) {
+                const float *sp = a_ln_part + (size_t)(b0 + img) * a_ln_G * 2 * HW + y * W_ + x;
+                // two passes over the groups' means (the second one hits the cache); every load of a pass is independent of the others
+                float s = 0.f, q2 = 0.f, qm = 0.f;
+                static_for<kWsMaxG>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    const int qq = q < a_ln_G ? q : a_ln_G - 1;
+                    const float m = sp[(size_t)qq * 2 * HW], v = sp[(size_t)qq * 2 * HW + HW];
+                    s += q < a_ln_G ? m : 0.f;
+                    q2 += q < a_ln_G ? v : 0.f;
+                });
+                mean = s / (float)a_ln_G;
+                static_for<kWsMaxG>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    const int qq = q < a_ln_G ? q : a_ln_G - 1;
+                    const float d = sp[(size_t)qq * 2 * HW] - mean;
+                    qm += q < a_ln_G ? d * d : 0.f;
+                });
+                rstd = 1.0f / sqrtf((q2 + 16.f * qm) / (16.f * (float)a_ln_G) + a_eps);
+            }
+            t_mu[idx] = mean; t_rs[idx] = rstd;
+        }
+    }
+    WS_STAMP(3);
+    // zero halo (and the rows outside the image): written once, the loader only ever writes image pixels
+    for (int i = lane; i < 4 * PPIX; i += 64) patch[i] = make_uint4(0, 0, 0, 0);
+    if constexpr (LN) __syncthreads();
+    WS_STAMP(4);
+
+    // ---- B-operand base of every pixel block: lane = pixel n of the block, k-half kg ---------------------------------------------
+    int bbase[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int p = pb * 32 + n;
+        const int img = whole ? img_of(p, HW) : 0, rem = p - img * HW, y = rem / W_, x = rem - y * W_;     // (part of an image: y counts from y0)
+        bbase[pb] = (kg * 2) * PPIX + (img * PR + y) * PW + x;
+    }
+    WS_STAMP(5);
+
+    f32x16 acc[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
+
     // fp32 -> (LayerNorm, ReLU, shift) -> planes h, l' in this wave's patch
     auto convert_x = [&](int chunk) __attribute__((always_inline)) {
         static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
@@ -249,64 +288,75 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
             patch[(l_tab[it] & 0xfff) + PPIX] = __builtin_bit_cast(uint4, vl);
         });
     };
-    // weights of one kernel row of a chunk: 3 taps x planes {WH, WL, WH2 = WH 2^-11}, one 16-byte unit per lane each (A-operand order in
-    // memory).  Three planes and ONE accumulator set (the plane-operand kernels hold two sets and two planes): the registers go to the
-    // loads in flight instead.
-    f16x8 A[2][3][3];
-    const unsigned wlane = (unsigned)(kg * a_COP + g * 32 + n) * 16u;
-    auto load_a = [&](auto bufc, int chunk, int row) __attribute__((always_inline)) {
-        constexpr int buf = decltype(bufc)::value;
-        const char *wc = reinterpret_cast<const char *>(a_w) + ((size_t)chunk * 6 * a_COP + (size_t)(row * 3) * tap_stride) * 16;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                A[buf][t][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(wc + ((size_t)t * tap_stride + (size_t)pl * 2 * a_COP) * 16 + wlane));
-    };
     // a = h + l' 2^-11, w 2^s = WH + WL:  acc += WL.h + WH2.l' + WH.h
     auto mma_row = [&](auto bufc, auto rowc) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value, row = decltype(rowc)::value;
+#ifdef CDC_WS_LAB
+        if (a_dbg & 1) return;
+#endif
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int koff = row * PW + t;
-                const f16x8 bh = __builtin_bit_cast(f16x8, patch[bbase[pb] + koff]);
-                const f16x8 bl = __builtin_bit_cast(f16x8, patch[bbase[pb] + PPIX + koff]);
-                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][1], bh, acc[pb], 0, 0, 0);
-                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][2], bl, acc[pb], 0, 0, 0);
-                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][0], bh, acc[pb], 0, 0, 0);
+            for (int p2 = 0; p2 < NPB; p2 += 2) {              // two pixel blocks at a time: 16 operand registers, not 32
+                f16x8 bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    bh[i] = __builtin_bit_cast(f16x8, patch[bbase[p2 + i] + row * PW + t]);
+                    bl[i] = __builtin_bit_cast(f16x8, patch[bbase[p2 + i] + PPIX + row * PW + t]);
+                }
+                // plane-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[p2 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][1], bh[i], acc[p2 + i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[p2 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][2], bl[i], acc[p2 + i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[p2 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[buf][t][0], bh[i], acc[p2 + i], 0, 0, 0);
             }
     };
-    typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
     // One chunk.  In flight while it multiplies: the next kernel row's weights (two register sets) and, from its second row on, the
     // NEXT chunk's input values -- the chunk boundary costs the conversion, no exposed load latency.
     auto chunk_body = [&](auto parc, int ci) __attribute__((always_inline)) {
         constexpr int p0 = decltype(parc)::value;
-        typedef std::integral_constant<int, p0> PA;
-        typedef std::integral_constant<int, p0 ^ 1> PB;
+        typedef std::integral_constant<int, p0> BufA;
+        typedef std::integral_constant<int, p0 ^ 1> BufB;
         const int chunk = __builtin_amdgcn_readfirstlane(wave + ci * nw);
         const int nxt = __builtin_amdgcn_readfirstlane(wave + (ci + 1 < a_cpw ? ci + 1 : ci) * nw);      // (past the last chunk: a harmless re-read)
+        // Program order is PINNED (sched_barrier): hipcc otherwise sinks every load to its first use -- nothing in flight beside the MFMAs
+        // (measured: the phases of the first version added up).  In flight while row r multiplies: the weights of row r + 1 and, from
+        // the first row of a chunk on, the input values of the NEXT chunk.
         convert_x(chunk);
-        load_a(PB{}, chunk, 1);
-        mma_row(PA{}, I0{});
-        load_a(PA{}, chunk, 2);
+        if (ci == 0) WS_STAMP(7);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(BufB{}, chunk, 1);
         load_x(nxt);
-        mma_row(PB{}, I1{});
-        load_a(PB{}, nxt, 0);
-        mma_row(PA{}, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma_row(BufA{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(BufA{}, chunk, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_row(BufB{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(BufB{}, nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_row(BufA{}, I2{});
+        __builtin_amdgcn_sched_barrier(0);
     };
-    load_x(wave);
-    load_a(I0{}, wave, 0);
+    WS_STAMP(6);
     for (int ci = 0; ci < a_cpw; ci += 2) {
         chunk_body(I0{}, ci);
-        if (ci + 1 < a_cpw) chunk_body(I1{}, ci + 1);
+        WS_STAMP(8 + (ci < 3 ? ci : 3));
+        if (ci + 1 < a_cpw) { chunk_body(I1{}, ci + 1); WS_STAMP(8 + (ci + 1 < 3 ? ci + 1 : 3)); }
     }
 
+#ifdef CDC_WS_LAB
+    if (a_dbg & 8) { if (acc[0][0] == 12345.678f) a_out[0] = acc[1][1] + acc[2][2] + acc[3][3]; return; }
+#endif
     // ---- the K slices of the waves meet in LDS: red[wave][pb][4 regs x 4][lane] --------------------------------------------------
+    WS_STAMP(12);
     __syncthreads();                                            // every wave is done with its patch
+    WS_STAMP(13);
     float4 *red = reinterpret_cast<float4 *>(ws_smem);
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb)
@@ -316,44 +366,47 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
             red[((wave * NPB + pb) * 4 + q) * 64 + lane] = v;
         }
     __syncthreads();
-    // wave pb finishes pixel block pb (waves beyond NPB are done; fewer waves than blocks: a wave takes several)
-    for (int pb = wave; pb < NPB; pb += nw) {
-        float v[16];
+    WS_STAMP(14);
+    // unit u = (pixel block, 16-channel half of the group): wave u, u + waves, ... finishes it -- all waves take part
+    for (int u = wave; u < 2 * NPB; u += nw) {
+        const int pb = u >> 1, qh = u & 1;
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 s = red[((0 * NPB + pb) * 4 + q) * 64 + lane];
+        for (int q = 0; q < 2; ++q) {
+            float4 s4 = red[((0 * NPB + pb) * 4 + 2 * qh + q) * 64 + lane];
             for (int w = 1; w < nw; ++w) {                      // fixed order: deterministic
-                const float4 t = red[((w * NPB + pb) * 4 + q) * 64 + lane];
-                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                const float4 t = red[((w * NPB + pb) * 4 + 2 * qh + q) * 64 + lane];
+                s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
             }
-            v[4 * q + 0] = s.x; v[4 * q + 1] = s.y; v[4 * q + 2] = s.z; v[4 * q + 3] = s.w;
+            v[4 * q + 0] = s4.x; v[4 * q + 1] = s4.y; v[4 * q + 2] = s4.z; v[4 * q + 3] = s4.w;
         }
-        // accumulator layout: lane = pixel n, register r -> channel (r & 3) + 8 (r >> 2) + 4 kg of the group
+        // accumulator layout: lane = pixel n, register r = 4 q' + i -> channel i + 8 q' + 4 kg of the group (q' = 2 qh + q)
         const int p = pb * 32 + n;
         const int img = whole ? p / HW : 0, pix = whole ? p - img * HW : y0 * W_ + p;
+        const int cbase = g * 32 + 16 * qh + 4 * kg;
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            v[r] = v[r] * a_acc_scale + (a_bias ? a_bias[co] : 0.f);
+        for (int r = 0; r < 8; ++r) {
+            v[r] = v[r] * a_acc_scale + (a_bias ? a_bias[cbase + (r & 3) + 8 * (r >> 2)] : 0.f);
             sum += v[r];
         }
         sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / 32.0f);
+        const float mean = sum * (1.0f / 16.0f);
         float m2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; m2 += d * d; }
+        for (int r = 0; r < 8; ++r) { const float d = v[r] - mean; m2 += d * d; }
         m2 += __shfl_xor(m2, 32);
         if (a_fault && !(m2 < 3.0e38f)) *a_fault = 1;           // non-finite accumulators: reported before any LayerNorm can hide them
-        float *o = a_out + (size_t)(b0 + img) * a_out_bs + (size_t)(g * 32 + 4 * kg) * HW + pix;
+        float *o = a_out + (size_t)(b0 + img) * a_out_bs + (size_t)cbase * HW + pix;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];
+        for (int r = 0; r < 8; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];
         if (a_stat_part && kg == 0) {
-            float *sp = a_stat_part + ((size_t)(b0 + img) * a_groups + g) * 2 * HW + pix;
+            float *sp = a_stat_part + ((size_t)(b0 + img) * 2 * a_groups + 2 * g + qh) * 2 * HW + pix;
             sp[0] = mean;
             sp[HW] = m2;
         }
     }
+    WS_STAMP(15);
 }
 
 typedef void (*ws_kernel_fn)(const WsArgs);
