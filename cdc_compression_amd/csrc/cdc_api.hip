@@ -673,7 +673,7 @@ struct Builder {
                      op.pf.resid ? " +res" : (op.pf.resid_pf ? " +resP" : ""), cur == &h->pre_ops ? " HOIST" : "", op.pf.tz == 4 ? " TZ4" : "");
         else if (op.kind == Op::CONVWS)
             snprintf(buf, sizeof buf, "conv 3x3 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS%s", op.ws.Cin, op.ws.Cout, op.ws.H, op.wsplan.W,
-                     op.wsplan.NPB, op.wsplan.waves, op.wsplan.tiles, op.wsplan.groups, op.ws.ln_part ? " LNload" : "");
+                     op.wsplan.NPB, op.wsplan.waves, op.wsplan.tiles, op.wsplan.groups, "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -1127,9 +1127,7 @@ struct Builder {
     }
 
     // 3x3 / stride-1 / pad-1 layer of a few-pixel level on conv_ws_kernel (conv_ws_kernel.h): the RAW result (bias added, no LayerNorm)
-    // goes to `raw`, the (mean, M2) of every pixel's 32-channel groups to `part` (may be null).  `lnl` (optional): the single source
-    // s0 is itself such a raw result and LayerNorm, ReLU and the time shift are applied while it is loaded.
-    struct LnLoad { const float *part; int G; const float *g, *b, *shift; };
+    // goes to `raw`; a Block's LayerNorm / ReLU / shift / residual is the in-place pass its caller emits behind it.
     bool ws_would_plan(const ConvW &w, int C0, bool two_src, int H, int W) {
         if (h->arith != 1 || !w.wsh || planB > 0 || w.KH != 3 || w.KW != 3 || w.stride != 1 || w.transposed || w.nz != 1) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 1 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 1) return false;
@@ -1138,8 +1136,8 @@ struct Builder {
         return ws_make_plan(w.Cin, two_src ? C0 : w.Cin, w.Cout, H, W, pb(), &plan);
     }
     bool try_ws(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W, float *raw,
-                long long raw_bs, float *part, const LnLoad *lnl, int prof) {
-        if (rc || !ws_would_plan(w, C0, s1 != nullptr, H, W) || (lnl && s1)) return false;
+                long long raw_bs, int prof) {
+        if (rc || !ws_would_plan(w, C0, s1 != nullptr, H, W)) return false;
         if (!ensure_f32(s0, bs0) || (s1 && !ensure_f32(s1, bs1))) return false;
         Op op;
         op.kind = Op::CONVWS; op.prof = prof;
@@ -1148,18 +1146,16 @@ struct Builder {
         memset(&a, 0, sizeof a);
         a.x0 = s0; a.x0_bs = bs0; a.x1 = s1; a.x1_bs = bs1;
         a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.B = B;
-        if (lnl) { a.ln_part = lnl->part; a.ln_G = lnl->G; a.ln_g = lnl->g; a.ln_b = lnl->b; a.ln_shift = lnl->shift; a.shift_bs = h->shift_bs; }
-        a.eps = 1e-5f;
         a.w = w.wsh; a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout; a.acc_scale = w.wscale_inv;
         a.bias = w.bias;
-        a.out = raw; a.out_bs = raw_bs; a.stat_part = part;
+        a.out = raw; a.out_bs = raw_bs;
         a.fault = fault_flag();
         const double px = (double)B * H * W;
         op.flops = 2.0 * px * w.Cout * w.Cin * 9;
         op.bytes = 4.0 * px * (w.Cin + w.Cout);
         if (getenv("CDC_DEBUG_PLAN"))
-            fprintf(stderr, "[plan] conv 3x3 %d->%d out %dx%d on conv_ws_kernel: %d tiles x %d groups, %d waves, %zu bytes of LDS%s\n", w.Cin, w.Cout, H, W,
-                    op.wsplan.tiles, op.wsplan.groups, op.wsplan.waves, op.wsplan.lds_bytes, lnl ? ", LayerNorm on load" : "");
+            fprintf(stderr, "[plan] conv 3x3 %d->%d out %dx%d on conv_ws_kernel: %d tiles of %d pixels x %d groups, %d waves, %zu bytes of LDS\n", w.Cin, w.Cout, H, W,
+                    op.wsplan.tiles, op.wsplan.NPB * 32, op.wsplan.groups, op.wsplan.waves, op.wsplan.lds_bytes);
         last_ksplit = 1;
         last_pf_only = false;
         emit(op);
@@ -1403,7 +1399,7 @@ struct Builder {
         }
         // few-pixel levels: the weight-stationary kernel (all of K in one workgroup, no partial-sum tensors) + an in-place LayerNorm pass
         if (!pre_add && !want_res3 && !uf_c && !resid1 && out.bs() == (long long)w.Cout * H * W &&
-            try_ws(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), nullptr, nullptr, prof)) {
+            try_ws(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), prof)) {
             ln(out.p, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr);
             return true;
         }
@@ -1520,14 +1516,6 @@ struct Builder {
             copy(a1->p, a1->bs(), cat.p + a0.bs(), cat.bs(), a1->bs());
             s0 = cat.p; s1 = nullptr; C0 = cat.C; bs0 = cat.bs(); bs1 = 0;
         }
-        // Few-pixel levels (round 5): both convolutions on conv_ws_kernel; block1's LayerNorm + ReLU + time shift are applied by block2
-        // WHILE IT LOADS h1 (from the per-group statistics block1's epilogue wrote): h1 is stored raw, once, and never normalised in
-        // HBM; one in-place LayerNorm pass (with the residual) finishes the block.
-        const bool ws_pair = !twin(h1.p) && !twin(out.p) && ws_would_plan(rb.c1, C0, s1 != nullptr, H, W) && ws_would_plan(rb.c2, rb.cout, false, H, W) &&
-                             rb.cout / 16 <= kWsMaxG && !dev_env("CDC_NO_WS_LNLOAD");
-        float *part1 = ws_pair ? dalloc((size_t)B * (rb.cout / 16) * 2 * HW) : nullptr;
-        const bool ws1 = ws_pair && try_ws(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1.p, h1.bs(), part1, nullptr, prof1);
-        if (!ws1)
         block(rb.c1, s0, C0, bs0, s1, bs1, H, W, h1, rb.g1, rb.b1, shift, nullptr, nullptr, 0, nullptr,
               nullptr, prof1, h1_pf_only);
         const float *res = s0;
@@ -1537,15 +1525,6 @@ struct Builder {
             conv(rb.cres, s0, C0, bs0, s1, bs1, H, W, r.p, r.bs(), ConvOpts(), false, PC_CONV1);
             res = r.p; res_bs = r.bs();
         }
-        if (ws1) {
-            const LnLoad lnl{part1, rb.cout / 16, rb.g1, rb.b1, shift};
-            if (!try_ws(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out.p, out.bs(), nullptr, &lnl, PC_CONV3)) {
-                if (!rc) rc = fail(h, CDC_ERR_UNSUPPORTED, "conv_ws_kernel planned block1 of a ResnetBlock but not block2");
-                return out;
-            }
-            ln(out.p, out.p, rb.cout, HW, rb.g2, rb.b2, 1, nullptr, res, sm, sr);
-            last_pf_only = false;
-        } else
         block(rb.c2, h1.p, rb.cout, h1.bs(), nullptr, 0, H, W, out, rb.g2, rb.b2, nullptr, nullptr, res,
               res_bs, sm, sr, PC_CONV3, out_planes_only && twin(out.p));
         mark_planes_only(out);
@@ -3452,9 +3431,9 @@ static int op_conv2d_impl(cdc_handle *h, const float *x, const float *w, const f
     const long long obs = (long long)Cout * Ho * Wo;
     const int prof = KH == 7 ? PC_CONV7 : (KH == 1 ? PC_CONV1 : PC_CONV3);
     // few-pixel maps: the weight-stationary kernel (its raw result + the in-place LayerNorm pass; a bias-only call is the raw result)
-    if (dg && relu && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, nullptr, nullptr, prof)) {
+    if (dg && relu && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, prof)) {
         bd.ln(dy, dy, Cout, Ho * Wo, dg, db, relu, ds, dr, nullptr, nullptr);
-    } else if (!dg && !relu && !ds && !dr && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, nullptr, nullptr, prof)) {
+    } else if (!dg && !relu && !ds && !dr && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, prof)) {
     } else if (dg) {
         if (!bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, o, true, prof)) {
             bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, Builder::ConvOpts(),

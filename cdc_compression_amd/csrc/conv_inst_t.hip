@@ -6,13 +6,13 @@
 namespace cdc {
 
 namespace {
-constexpr int kWsNPB = 4;                 // pixel blocks per workgroup: 128 pixels (72 weight registers feed 4 x 27 MFMAs per chunk)
-
-ws_kernel_fn ws_lookup(int W, bool ln) {
+// pixel blocks per workgroup: 4 (128 pixels: a kernel row's weight registers feed 4 x 9 MFMAs) wherever that fills the chip,
+// 2 (64 pixels) for the small batches
+ws_kernel_fn ws_lookup(int W, int NPB) {
     switch (W) {
-        case 8: return ln ? conv_ws_kernel<8, kWsNPB, true> : conv_ws_kernel<8, kWsNPB, false>;
-        case 16: return ln ? conv_ws_kernel<16, kWsNPB, true> : conv_ws_kernel<16, kWsNPB, false>;
-        case 32: return ln ? conv_ws_kernel<32, kWsNPB, true> : conv_ws_kernel<32, kWsNPB, false>;
+        case 8: return NPB == 4 ? conv_ws_kernel<8, 4> : conv_ws_kernel<8, 2>;
+        case 16: return NPB == 4 ? conv_ws_kernel<16, 4> : conv_ws_kernel<16, 2>;
+        case 32: return NPB == 4 ? conv_ws_kernel<32, 4> : conv_ws_kernel<32, 2>;
     }
     return nullptr;
 }
@@ -22,42 +22,47 @@ ws_kernel_fn ws_lookup(int W, bool ln) {
 bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *p) {
     static const bool off = dev_env("CDC_NO_WS") != nullptr;
     if (off || (W != 8 && W != 16 && W != 32) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
-    const int hw = H * W, tpx = kWsNPB * 32;
+    const int hw = H * W, groups = Cout / 32, nchunk = Cin / 16;
     if (hw % 32) return false;
-    if (tpx >= hw ? ((tpx % hw) || (hw % 64)) : ((hw % tpx) || ((tpx / W) < 1))) return false;     // whole images (each a multiple of a loader pass), or an image in equal row bands
-    const long long tot_px = (long long)B * hw;
-    if (tot_px % tpx) return false;
-    const int tiles = (int)(tot_px / tpx), groups = Cout / 32, nchunk = Cin / 16;
-    // K slices over the waves of the workgroup: up to 8 waves (two per SIMD: the kernel holds 200+ registers), equal shares
-    int waves = 0;
-    for (int w = 8; w >= 2; --w)
-        if (nchunk % w == 0) { waves = w; break; }
-    if (!waves) return false;
-    // two workgroups per CU when both fit (LDS, 8 waves): fewer waves per workgroup then
-    const long long wgs = (long long)tiles * groups;
-    if (wgs > 2 * device_cus() && waves > 4)
-        for (int w = 4; w >= 2; --w)
+    const long long min_wgs = dev_env("CDC_WS_MIN_WGS") ? atoll(dev_env("CDC_WS_MIN_WGS")) : 12;
+    const int force_npb = dev_env("CDC_WS_NPB") ? atoi(dev_env("CDC_WS_NPB")) : 0;
+    for (int npb : {4, 2}) {
+        if (force_npb && npb != force_npb) continue;
+        const int tpx = npb * 32;
+        // a tile = whole images (each a multiple of a loader pass of 64 pixels), or an image in equal bands of rows
+        if (tpx >= hw ? ((tpx % hw) || (hw % 64)) : ((hw % tpx) || (tpx % W))) continue;
+        const long long tot_px = (long long)B * hw;
+        if (tot_px % tpx) continue;
+        const int tiles = (int)(tot_px / tpx);
+        const long long wgs = (long long)tiles * groups;
+        // 128-pixel tiles only where they leave at most a quarter of the chip idle; 64-pixel tiles below that
+        if (npb == 4 && !force_npb && wgs < (3 * device_cus()) / 4) continue;
+        if (wgs < min_wgs) return false;
+        // K slices over the waves of the workgroup: up to 8 waves (two per SIMD: the kernel holds ~250 registers), equal shares;
+        // two workgroups per CU when the launch has more than two per CU (LDS and registers then want <= 4 waves each)
+        int waves = 0;
+        for (int w = (wgs > 2 * device_cus() ? 4 : 8); w >= 2; --w)
             if (nchunk % w == 0) { waves = w; break; }
-    const long long min_wgs = dev_env("CDC_WS_MIN_WGS") ? atoll(dev_env("CDC_WS_MIN_WGS")) : 96;
-    if (wgs < min_wgs) return false;
-    const size_t lds = ws_lds_bytes(W, H, kWsNPB, waves, Cin, true);      // (with the LayerNorm-on-load tables: the larger of the two forms)
-    if (lds > 160 * 1024) return false;
-    p->W = W; p->NPB = kWsNPB; p->waves = waves; p->tiles = tiles; p->groups = groups; p->lds_bytes = lds;
-    return true;
+        if (!waves) continue;
+        const size_t lds = ws_lds_bytes(W, H, npb, waves);
+        if (lds > 160 * 1024) continue;
+        p->W = W; p->NPB = npb; p->waves = waves; p->tiles = tiles; p->groups = groups; p->lds_bytes = lds;
+        return true;
+    }
+    return false;
 }
 
 hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
-    const bool ln = a.ln_part != nullptr;
-    ws_kernel_fn fn = ws_lookup(p.W, ln);
+    ws_kernel_fn fn = ws_lookup(p.W, p.NPB);
     if (!fn) return hipErrorInvalidValue;
-    static bool attr_done[16][3][2] = {};
+    static bool attr_done[16][3][2] = {};                  // [device][width][NPB == 4]
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int wi = p.W == 8 ? 0 : (p.W == 16 ? 1 : 2);
-    if (dev < 0 || dev >= 16 || !attr_done[dev][wi][ln]) {
+    if (dev < 0 || dev >= 16 || !attr_done[dev][wi][p.NPB == 4]) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 16) attr_done[dev][wi][ln] = true;
+        if (dev >= 0 && dev < 16) attr_done[dev][wi][p.NPB == 4] = true;
     }
     a.tiles = p.tiles; a.groups = p.groups;
     a.dbg = 0;
@@ -76,7 +81,7 @@ hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
         a.tl = grid <= 8192 ? tl : nullptr;
     } else a.tl = nullptr;
 #endif
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * p.waves), ws_lds_bytes(p.W, a.H, p.NPB, p.waves, a.Cin, ln), st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * p.waves), p.lds_bytes, st, a);
 #ifdef CDC_WS_LAB
     if (a.tl && tl_n++ >= 40 && tl_n < 63) {                 // the launches of the third DDIM iteration: mean stamps over the grid
         (void)hipStreamSynchronize(st);
@@ -89,7 +94,7 @@ hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
             if (t[0] < first) first = t[0];
             if (t[15] > last) last = t[15];
         }
-        fprintf(stderr, "[ws-tl] Cin=%d Cout=%d H=%d W=%d waves=%d ln=%d grid=%u | span %llu | mean since start:", a.Cin, a.Cout, a.H, p.W, p.waves, (int)ln, grid, last - first);
+        fprintf(stderr, "[ws-tl] Cin=%d Cout=%d H=%d W=%d waves=%d npb=%d grid=%u | span %llu | mean since start:", a.Cin, a.Cout, a.H, p.W, p.waves, p.NPB, grid, last - first);
         for (int i = 1; i < 16; ++i) fprintf(stderr, " %d:%.0f", i, d[i] / grid);
         fprintf(stderr, "\n");
     }

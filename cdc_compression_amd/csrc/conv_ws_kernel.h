@@ -12,12 +12,12 @@
 //     loads fly while this one multiplies) straight from global memory in A-operand order and keeps a row for all NPB pixel blocks: per pixel block and tap only the two activation planes (h, l') come from LDS --
 //     2 ds_read_b128 per 3 MFMAs instead of 5: the loop is matrix-bound, not LDS-bound;
 //   * the wave converts its own chunk of the input (fp32 NCHW -> two fp16 planes, conv_split_kernel.h AR = 1) into its own LDS
-//     patch: no cross-wave synchronisation inside the K loop at all.  LayerNorm-on-load (LN = true): the input is the RAW result of
-//     the previous convolution of this kernel and (x - mean) * rstd * g + b, ReLU, + shift is applied while converting -- the
-//     statistics are combined (Chan) from the per-(pixel, 32-channel group) (mean, M2) partials that kernel's epilogue wrote; the
-//     LayerNorm pass between block1 and block2 of a ResnetBlock and its tensor disappear;
+//     patch: no cross-wave synchronisation inside the K loop at all;
 //   * the NW partial accumulators meet in LDS once, after the K loop (no partial-sum tensors in HBM, no sum pass); the epilogue
-//     (all waves) stores the raw result (bias added) and, per pixel, the (mean, M2) of each 16-channel half of its 32 channels.
+//     (all waves) stores the raw result (bias added).  The channel LayerNorm of a Block (the workgroup owns 32 of the channels) is
+//     the in-place pass that follows (ln_kernel_vec over ONE tensor).  "LayerNorm on load" -- the next convolution of this kernel
+//     normalising the raw result while it converts it, from per-group (mean, M2) partials of this epilogue -- was built and measured
+//     slower than that pass (profiles/ws_lnload_ab_r05.txt) and removed.
 // fp32 accumulation; the chunk order of the sum is fixed by (nchunk, NW): deterministic.
 #pragma once
 #include "conv_pf_kernel.h"
@@ -29,13 +29,6 @@ struct WsArgs {
     long long x0_bs, x1_bs;         // batch strides in floats
     int C0, Cin;                    // channels taken from x0; total (both multiples of 16)
     int H, B;                       // rows of the map (its width is the template parameter), batch
-    // LayerNorm on load (LN = true): x0 holds raw convolution results, ln_part the partial statistics of its producer
-    const float *ln_part;           // [B][ln_G][2][H*W]: mean and M2 (sum of squared deviations) of each 16-channel group (ln_G = Cin / 16 <= kWsMaxG)
-    int ln_G;
-    const float *ln_g, *ln_b;       // [Cin]
-    float eps;
-    const float *ln_shift;          // + shift[b * shift_bs + c] after the ReLU (time embedding), or null
-    int shift_bs;
     const void *w;                  // fp16 planes {WH, WL, WH2} of w 2^s: [tap][Cin/16][3][2][COP] 16-byte units
     int nchunk, cpw;                // 16-channel chunks; chunks per wave (nchunk = cpw * waves)
     int COP, Cout;
@@ -43,7 +36,6 @@ struct WsArgs {
     const float *bias;              // [Cout] or null
     float *out;                     // raw result, fp32 NCHW
     long long out_bs;
-    float *stat_part;               // [B][2 * groups][2][H*W] partial statistics of `out` (mean, M2 of each 16-channel half of a group), or null
     int tiles, groups;              // pixel tiles; 32-channel groups of Cout (gridDim.x = tiles * groups)
     int xcd_remap;
     int *fault;                     // range guard (ConvArgs::fault)
@@ -53,23 +45,14 @@ struct WsArgs {
     int dbg;                        // -DCDC_WS_LAB builds only (CDC_WS_DBG, timing experiments, wrong results): 1 no MFMAs, 8 no reduction / epilogue
 };
 
-constexpr int kWsMaxG = 24;          // most 16-channel statistic groups of a LayerNorm-on-load input (384 channels)
-
-// LDS bytes of a launch: the waves' patches during the K loop (the partial accumulators after it) + the LayerNorm-on-load tables
-// (g, b [Cin], shift [images of a tile][Cin], per-pixel mean / rstd of the tile's loaded rows)
+// LDS bytes of a launch: the waves' patches during the K loop, the partial accumulators after it
 __host__ __device__ inline int ws_ppix(int W, int H, int NPB) {
     const int tpx = NPB * 32, hw = H * W;
     return (tpx >= hw ? tpx / hw : 1) * ((tpx >= hw ? H : tpx / W) + 2) * (W + 2);
 }
-__host__ __device__ inline int ws_nload(int W, int H, int NPB) {
-    const int tpx = NPB * 32, hw = H * W;
-    return tpx >= hw ? tpx : (tpx / W + 2) * W;
-}
-__host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves, int Cin, bool ln) {
-    const int tpx = NPB * 32, hw = H * W, n_img = tpx >= hw ? tpx / hw : 1;
+__host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves) {
     const size_t patches = (size_t)waves * 4 * ws_ppix(W, H, NPB) * 16, red = (size_t)waves * NPB * 4096;
-    const size_t tab = ln ? ((size_t)(2 + n_img) * Cin + 2 * ws_nload(W, H, NPB)) * 4 : 0;
-    return (patches > red ? patches : red) + ((tab + 15) & ~(size_t)15);
+    return patches > red ? patches : red;
 }
 
 #ifdef CDC_WS_LAB
@@ -78,7 +61,7 @@ __host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves,
 #define WS_STAMP(i) do { } while (0)
 #endif
 
-template <int W_, int NPB, bool LN>
+template <int W_, int NPB>
 __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     static_assert(W_ == 8 || W_ == 16 || W_ == 32, "map width");
     static_assert(NPB % 2 == 0, "pixel blocks are multiplied in pairs");
@@ -89,15 +72,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     const auto a_x0_bs = PA.x0_bs;
     const auto a_x1_bs = PA.x1_bs;
     const auto a_C0 = PA.C0;
-    const auto a_Cin = PA.Cin;
     const auto a_H = PA.H;
-    const auto a_ln_part = PA.ln_part;
-    const auto a_ln_G = PA.ln_G;
-    const auto a_ln_g = PA.ln_g;
-    const auto a_ln_b = PA.ln_b;
-    const auto a_eps = PA.eps;
-    const auto a_ln_shift = PA.ln_shift;
-    const auto a_shift_bs = PA.shift_bs;
     const auto a_w = PA.w;
     const auto a_nchunk = PA.nchunk;
     const auto a_cpw = PA.cpw;
@@ -106,9 +81,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     const auto a_bias = PA.bias;
     const auto a_out = PA.out;
     const auto a_out_bs = PA.out_bs;
-    const auto a_stat_part = PA.stat_part;
     const auto a_tiles = PA.tiles;
-    const auto a_groups = PA.groups;
     const auto a_xcd_remap = PA.xcd_remap;
     const auto a_fault = PA.fault;
     const int a_dbg = PA.dbg;
@@ -132,17 +105,12 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     // loaded rows of an image part: whole images rows 0 .. H-1 (patch rows 1 .. H); a part also its neighbour rows (patch rows 0 .. R+1)
     const int row0 = whole ? 1 : 0, nrow = whole ? H : PR, nload = n_img * nrow * W_;
     uint4 *patch = ws_smem + (size_t)wave * 4 * PPIX;
-    // LayerNorm-on-load tables behind the patches / the reduction scratch
-    const size_t main_units = (size_t)nw * 4 * PPIX > (size_t)nw * NPB * 256 ? (size_t)nw * 4 * PPIX : (size_t)nw * NPB * 256;
-    float *t_g = reinterpret_cast<float *>(ws_smem + main_units), *t_b = t_g + a_Cin, *t_sh = t_b + a_Cin;       // [Cin], [Cin], [n_img][Cin]
-    float *t_mu = t_sh + (size_t)n_img * a_Cin, *t_rs = t_mu + nload;                                             // [nload] each
-
     // ---- loader items of this lane (the same for every chunk): item e = pass * 64 + lane -> (k-half, loaded pixel) ---------------
     // (no runtime divisions in the set-up: a tile holds at most four images -- compare chains -- and W_ is a power of two)
     const int per_img = nrow * W_;
     auto img_of = [](int i, int per) __attribute__((always_inline)) { return (i >= per ? 1 : 0) + (i >= 2 * per ? 1 : 0) + (i >= 3 * per ? 1 : 0); };
     int l_off[NIT];                            // float offset inside a channel plane (+ image stride), -1: nothing to load
-    int l_tab[NIT];                            // patch unit incl. the k-half (12 bits) | index of the pixel's statistics << 12 | image << 20 | k-half << 24
+    int l_tab[NIT];                            // patch unit incl. the k-half (12 bits) | image << 20
     static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
         constexpr int it = decltype(itc)::value;
         const int e = it * 64 + lane;
@@ -153,7 +121,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
             const int y = y0 - 1 + row0 + r;
             if (y >= 0 && y < H) {
                 l_off[it] = k2 * 8 * HW + y * W_ + x;            // (+ img * batch stride: added per source below)
-                l_tab[it] = ((k2 * 2) * PPIX + (img * PR + row0 + r) * PW + x + 1) | (idx << 12) | (img << 20) | (k2 << 24);
+                l_tab[it] = ((k2 * 2) * PPIX + (img * PR + row0 + r) * PW + x + 1) | (img << 20);
             }
         }
     });
@@ -199,45 +167,9 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     load_a(I0{}, wave, 0);
     __builtin_amdgcn_sched_barrier(0);
     WS_STAMP(1);
-    if constexpr (LN) {
-        for (int c = tid; c < a_Cin; c += (int)blockDim.x) {
-            t_g[c] = a_ln_g[c]; t_b[c] = a_ln_b[c];
-            for (int i = 0; i < n_img; ++i) t_sh[i * a_Cin + c] = a_ln_shift ? a_ln_shift[(size_t)(b0 + i) * a_shift_bs + c] : 0.f;
-        }
-        WS_STAMP(2);
-        // per-pixel statistics: Chan's combination of the per-group (mean, M2) partials, 16 channels each (network_components.py:56-66:
-        // biased variance).  All loads of a pixel are issued before the first use (groups in batches of 12).
-        for (int idx = tid; idx < nload; idx += (int)blockDim.x) {
-            const int img = img_of(idx, per_img), rem = idx - img * per_img, r = rem / W_, x = rem - r * W_;
-            const int y = y0 - 1 + row0 + r;
-            float mean = 0.f, rstd = 0.f;
-            if (y >= 0 && y < H) {
-                const float *sp = a_ln_part + (size_t)(b0 + img) * a_ln_G * 2 * HW + y * W_ + x;
-                // two passes over the groups' means (the second one hits the cache); every load of a pass is independent of the others
-                float s = 0.f, q2 = 0.f, qm = 0.f;
-                static_for<kWsMaxG>([&](auto qc) __attribute__((always_inline)) {
-                    constexpr int q = decltype(qc)::value;
-                    const int qq = q < a_ln_G ? q : a_ln_G - 1;
-                    const float m = sp[(size_t)qq * 2 * HW], v = sp[(size_t)qq * 2 * HW + HW];
-                    s += q < a_ln_G ? m : 0.f;
-                    q2 += q < a_ln_G ? v : 0.f;
-                });
-                mean = s / (float)a_ln_G;
-                static_for<kWsMaxG>([&](auto qc) __attribute__((always_inline)) {
-                    constexpr int q = decltype(qc)::value;
-                    const int qq = q < a_ln_G ? q : a_ln_G - 1;
-                    const float d = sp[(size_t)qq * 2 * HW] - mean;
-                    qm += q < a_ln_G ? d * d : 0.f;
-                });
-                rstd = 1.0f / sqrtf((q2 + 16.f * qm) / (16.f * (float)a_ln_G) + a_eps);
-            }
-            t_mu[idx] = mean; t_rs[idx] = rstd;
-        }
-    }
     WS_STAMP(3);
     // zero halo (and the rows outside the image): written once, the loader only ever writes image pixels
     for (int i = lane; i < 4 * PPIX; i += 64) patch[i] = make_uint4(0, 0, 0, 0);
-    if constexpr (LN) __syncthreads();
     WS_STAMP(4);
 
     // ---- B-operand base of every pixel block: lane = pixel n of the block, k-half kg ---------------------------------------------
@@ -256,30 +188,15 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
 
-    // fp32 -> (LayerNorm, ReLU, shift) -> planes h, l' in this wave's patch
+    // fp32 -> planes h, l' in this wave's patch
     auto convert_x = [&](int chunk) __attribute__((always_inline)) {
         static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
             constexpr int it = decltype(itc)::value;
             if (l_off[it] < 0) return;
-            float gg[8], bb[8], ss[8], mu = 0.f, rs = 0.f;
-            if constexpr (LN) {
-                const int c8 = chunk * 16 + ((l_tab[it] >> 24) & 1) * 8, img = (l_tab[it] >> 20) & 0xf;
-                const float4 g0 = *reinterpret_cast<const float4 *>(t_g + c8), g1 = *reinterpret_cast<const float4 *>(t_g + c8 + 4);
-                const float4 b0v = *reinterpret_cast<const float4 *>(t_b + c8), b1v = *reinterpret_cast<const float4 *>(t_b + c8 + 4);
-                const float4 s0 = *reinterpret_cast<const float4 *>(t_sh + img * a_Cin + c8), s1 = *reinterpret_cast<const float4 *>(t_sh + img * a_Cin + c8 + 4);
-                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                bb[0] = b0v.x; bb[1] = b0v.y; bb[2] = b0v.z; bb[3] = b0v.w; bb[4] = b1v.x; bb[5] = b1v.y; bb[6] = b1v.z; bb[7] = b1v.w;
-                ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
-                mu = t_mu[(l_tab[it] >> 12) & 0xff]; rs = t_rs[(l_tab[it] >> 12) & 0xff];
-            }
             f16x8 vh, vl;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 float v = xv[it][c];
-                if constexpr (LN) {
-                    v = (v - mu) * rs * gg[c] + bb[c];
-                    v = fmaxf(v, 0.f * v) + ss[c];                  // ReLU that keeps a NaN alive (range guard), then the time shift
-                }
                 _Float16 hq, lq;
                 split2h(v, hq, lq);
                 vh[c] = hq; vl[c] = lq;
@@ -367,7 +284,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
         }
     __syncthreads();
     WS_STAMP(14);
-    // unit u = (pixel block, 16-channel half of the group): wave u, u + waves, ... finishes it -- all waves take part
+    // unit u = (pixel block, 16-channel half of the group's 32): wave u, u + waves, ... finishes it -- all waves take part
     for (int u = wave; u < 2 * NPB; u += nw) {
         const int pb = u >> 1, qh = u & 1;
         float v[8];
@@ -384,27 +301,16 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
         const int p = pb * 32 + n;
         const int img = whole ? p / HW : 0, pix = whole ? p - img * HW : y0 * W_ + p;
         const int cbase = g * 32 + 16 * qh + 4 * kg;
-        float sum = 0.f;
+        float mag = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             v[r] = v[r] * a_acc_scale + (a_bias ? a_bias[cbase + (r & 3) + 8 * (r >> 2)] : 0.f);
-            sum += v[r];
+            mag += fabsf(v[r]);
         }
-        sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / 16.0f);
-        float m2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { const float d = v[r] - mean; m2 += d * d; }
-        m2 += __shfl_xor(m2, 32);
-        if (a_fault && !(m2 < 3.0e38f)) *a_fault = 1;           // non-finite accumulators: reported before any LayerNorm can hide them
+        if (a_fault && !(mag < 3.0e38f)) *a_fault = 1;          // non-finite accumulators: reported before the LayerNorm pass can hide them
         float *o = a_out + (size_t)(b0 + img) * a_out_bs + (size_t)cbase * HW + pix;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];
-        if (a_stat_part && kg == 0) {
-            float *sp = a_stat_part + ((size_t)(b0 + img) * 2 * a_groups + 2 * g + qh) * 2 * HW + pix;
-            sp[0] = mean;
-            sp[HW] = m2;
-        }
     }
     WS_STAMP(15);
 }

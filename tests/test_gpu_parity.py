@@ -168,14 +168,17 @@ WS_CASES = [
     (3, 256, 16, 16, 320, 3, 1, 1, True),
     (1, 64, 32, 32, 96, 3, 1, 1, True),     # 32 wide: 4-row bands; 4 chunks over 4 waves; 3 channel groups
     (2, 48, 8, 8, 32, 3, 1, 1, True),       # 3 chunks over 3 waves, fewer waves than pixel blocks
+    (4, 64, 16, 8, 64, 3, 1, 1, True),      # non-square map, 8 wide: 128 pixels per image
 ]
 
 
+@pytest.mark.parametrize("npb", ["2", "4"])
 @pytest.mark.parametrize("case", WS_CASES)
-def test_conv2d_weight_stationary_kernel(O, case, monkeypatch):
+def test_conv2d_weight_stationary_kernel(O, case, npb, monkeypatch):
     """conv + LayerNorm + ReLU + shift + residual of a few-pixel level: conv_ws_kernel (raw result, all of K inside one workgroup) + the
-    in-place LayerNorm pass, against the oracle; and the launch really is that kernel."""
+    in-place LayerNorm pass, and the bias-only convolution (the raw result itself), against the oracle; the launch really is that kernel."""
     monkeypatch.setenv("CDC_WS_MIN_WGS", "1")
+    monkeypatch.setenv("CDC_WS_NPB", npb)             # 64- / 128-pixel tiles
     monkeypatch.setenv("CDC_OP_REQUIRE_WS", "1")      # fails instead of falling back to the register-staged kernel
     from cdc_compression_amd.ops import Ops
     B, Ci, H, W, Co, k, s, p, fused = case
@@ -191,13 +194,14 @@ def test_conv2d_weight_stationary_kernel(O, case, monkeypatch):
     G2 = Ops(0)
     g2 = G2.conv2d(x, w, b, s, p, ln_g=g, ln_b=bb, relu=True, shift=shift, resid=resid)
     assert relerr(g2, r2) < 1e-5, relerr(g2, r2)
+    assert relerr(G2.conv2d(x, w, b, s, p), ref) < 1e-5
 
 
-def test_weight_stationary_trunk_with_layernorm_on_load_matches_the_default_program(monkeypatch):
-    """The few-pixel trunk of the full-width model on conv_ws_kernel with block1's LayerNorm + ReLU + time shift applied while block2
-    LOADS h1 (statistics combined from the per-group partials of block1's epilogue): one 256 x 256 image with the kernel forced
-    (16 x 16 level: 2 tiles per layer; the 8 x 8 level has 64 pixels per image -- below a tile -- and stays where it was) and a batch of
-    4 (both levels), against the program without the kernel (CDC_WS_MIN_WGS huge), which the reference digests pin."""
+@pytest.mark.parametrize("npb", ["2", "4"])
+def test_weight_stationary_trunk_matches_the_round4_program(npb, monkeypatch):
+    """The few-pixel trunk of the full-width model on conv_ws_kernel (raw result + in-place LayerNorm pass) with 64- and 128-pixel tiles
+    forced, one 256 x 256 image and a batch of 4, against the program without the kernel (CDC_WS_MIN_WGS huge: split-K convolutions +
+    LayerNorm over the partial sums), which the reference digests pin; and run-to-run determinism (fixed summation order)."""
     kw, man, sd, _, _, _, _ = load_case("full_x")
     S = 256
     for B in (1, 4):
@@ -210,14 +214,16 @@ def test_weight_stationary_trunk_with_layernorm_on_load_matches_the_default_prog
         y = un(x, t, ctx)
         assert not [l for l in _op_labels(un) if " WS" in l]
         monkeypatch.setenv("CDC_WS_MIN_WGS", "1")
+        monkeypatch.setenv("CDC_WS_NPB", npb)
         un2 = cdc.Unet(**kw)
         un2.load_state_dict(sd)
         y2 = un2(x, t, ctx)
         ws = [l for l in _op_labels(un2) if " WS" in l]
-        assert len(ws) >= (8 if B == 1 else 20) and any("LNload" in l for l in ws), ws
+        assert len(ws) >= 8 and all(f"NPB{npb}" in l for l in ws), ws
         assert relerr(y2, y) < 5e-6, (B, relerr(y2, y))
-        for _ in range(5):                                               # run-to-run determinism (fixed summation order)
+        for _ in range(5):
             np.testing.assert_array_equal(un2(x, t, ctx), y2)
+        monkeypatch.delenv("CDC_WS_NPB")
 
 
 @pytest.mark.parametrize("case", PF_S2_CASES)
