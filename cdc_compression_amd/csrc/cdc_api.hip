@@ -16,6 +16,7 @@
 #include "../../include/cdc_hip.h"
 #include "cdc_internal.h"
 #include "conv_ws_kernel.h"
+#include "conv_ws1_kernel.h"
 #include "entropy.h"
 
 using namespace cdc;
@@ -67,7 +68,7 @@ struct AttnW { std::string prefix; int C; ConvW qkv, out; float *ng, *nb;
                unsigned short *kvWh = nullptr; float kv_scale_inv = 1.f; };   // fp16 planes {WH, WL, WH2} of W' 2^s   // fused front half: (W_kv diag(g))^T [C][2C], W_kv b_ln [2C]   // folded output; uq = Wq b_ln
 
 struct Op {
-    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV, CONVPF, PFPACK, CONVWS } kind;
+    enum Kind { CONV, LN, TEMB, KSTATS, CTXP, CTXR, CTXF, COMBINE, DDIM, COPY, UNFOLD, KVCTX, LNCONV, CONVPF, PFPACK, CONVWS, CONVWS1 } kind;
     int prof = PC_SMALL;
     int id = -1;                  // index into cdc_handle::op_ms (per-op timing table, debug aid)
     char label[96] = {0};
@@ -75,6 +76,7 @@ struct Op {
     ConvArgs conv; ConvPlan plan; int nz = 1;
     PfArgs pf; PfPlan pfplan;     // CONVPF: pre-split fp16 operands by LDS-DMA (conv_pf_kernel.h)
     WsArgs ws; WsPlan wsplan;     // CONVWS: weight-stationary 3x3 convolution of the few-pixel levels (conv_ws_kernel.h)
+    Ws1Args ws1; Ws1Plan ws1plan; // CONVWS1: its 1x1 sibling (conv_ws1_kernel.h)
     bool pw = false;              // CONVPF on conv_pw_kernel (pointwise, activations from the fp32 tensor)
     LnArgs ln;
     TembArgs temb;
@@ -654,11 +656,12 @@ struct Builder {
     int pb() const { return planB > 0 ? planB : B; }
     std::vector<Op> *cur = nullptr; // op list being emitted to (h->ops unless set)
 
+    int ws1_h = 0;                  // (label only: rows of the map of the CONVWS1 op being emitted)
     void emit(Op op) {
         op.id = (int)h->op_ms.size();
         h->op_ms.push_back(0); h->op_n.push_back(0); h->op_flops.push_back(op.flops);
         char buf[160];
-        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack", "convws"};
+        const char *kinds[] = {"conv", "ln", "temb", "kstats", "ctxp", "ctxr", "ctxf", "combine", "ddim", "copy", "unfold", "kvctx", "lnconv", "convpf", "pfpack", "convws", "convws1"};
         if (op.kind == Op::PFPACK && op.pk.c4 == 2) kinds[Op::PFPACK] = "pfunpack";
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d tg%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
@@ -674,6 +677,10 @@ struct Builder {
         else if (op.kind == Op::CONVWS)
             snprintf(buf, sizeof buf, "conv 3x3 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS%s", op.ws.Cin, op.ws.Cout, op.ws.H, op.wsplan.W,
                      op.wsplan.NPB, op.wsplan.waves, op.wsplan.tiles, op.wsplan.groups, "");
+        else if (op.kind == Op::CONVWS1)
+            snprintf(buf, sizeof buf, "conv 1x1 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS1%s%s%s", op.ws1.Cin, op.ws1.Cout, ws1_h, op.ws1.HW / std::max(ws1_h, 1),
+                     op.ws1plan.NPB, op.ws1plan.waves, op.ws1plan.tiles, op.ws1plan.groups, op.ws1.pre_mean ? " pre" : "", op.ws1.w_bs ? " perimg" : "",
+                     op.ws1.resid ? " +res" : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -1162,6 +1169,47 @@ struct Builder {
         return true;
     }
 
+    // 1x1 layer of a few-pixel level (maps narrower than 32 pixels) on conv_ws1_kernel (conv_ws1_kernel.h): all of K inside the
+    // workgroup -- no partial-sum tensors, no sum pass.  Epilogue: bias, folded PreNorm (mean on load, rstd after), per-image shift,
+    // residual; shared or per-image weight planes.
+    bool try_ws1(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W, float *out, long long out_bs,
+                 const ConvOpts &o, bool need_all, int prof) {
+        if (rc || h->arith != 1 || !w.wsh || planB > 0 || W >= 32 || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
+        if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0) return false;
+        if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || o.pre_add || o.relu || o.resid1 || o.uf_c) return false;
+        if (o.pre_mean && o.pre_mode != 2) return false;
+        if (o.w_bs && !o.wsp_bs) return false;               // per-image weights without planes
+        if (w.COP != w.Cout || w.Cin_pad != w.Cin || out_bs != (long long)w.Cout * H * W) return false;
+        if (o.resid && (o.resid_cs != (long long)H * W)) return false;
+        Op op;
+        op.kind = Op::CONVWS1; op.prof = prof;
+        if (!ws1_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H * W, pb(), o.wsp_bs != 0, &op.ws1plan)) return false;
+        if (!ensure_f32(s0, bs0) || (s1 && !ensure_f32(s1, bs1)) || (o.resid && !ensure_f32(o.resid, o.resid_bs))) return false;
+        Ws1Args &a = op.ws1;
+        memset(&a, 0, sizeof a);
+        a.x0 = s0; a.x0_bs = bs0; a.x1 = s1; a.x1_bs = bs1;
+        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.HW = H * W; a.B = B;
+        a.pre_mean = o.pre_mean; a.pre_rstd = o.pre_mean ? o.pre_rstd : nullptr;
+        a.w = w.wsh; a.w_bs = o.wsp_bs / 8;                 // units of 8 halfs
+        a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout; a.acc_scale = w.wscale_inv;
+        a.bias = o.no_bias ? nullptr : w.bias;
+        a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
+        a.resid = o.resid; a.resid_bs = o.resid_bs;
+        a.out = out; a.out_bs = out_bs;
+        a.fault = fault_flag();
+        const double px = (double)B * H * W;
+        op.flops = 2.0 * px * w.Cout * w.Cin;
+        op.bytes = 4.0 * px * (w.Cin + w.Cout);
+        if (getenv("CDC_DEBUG_PLAN"))
+            fprintf(stderr, "[plan] conv 1x1 %d->%d out %dx%d on conv_ws1_kernel: %d tiles of %d pixels x %d groups, %d waves%s%s\n", w.Cin, w.Cout, H, W,
+                    op.ws1plan.tiles, op.ws1plan.NPB * 32, op.ws1plan.groups, op.ws1plan.waves, o.pre_mean ? ", folded PreNorm" : "", o.wsp_bs ? ", per-image weights" : "");
+        last_ksplit = 1;
+        last_pf_only = false;
+        ws1_h = H;
+        emit(op);
+        return true;
+    }
+
     // Emits one convolution.  s1 (optional) is the second concat source.  Returns false when
     // `need_all` (fused LN / statistics) cannot be planned; the caller then emits the unfused form.
     bool conv(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1,
@@ -1203,6 +1251,7 @@ struct Builder {
                     return true;
                 }
         }
+        if (!o.uf_c && try_ws1(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof)) return true;
         if (!o.uf_c && try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
@@ -1980,6 +2029,7 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             else HIP_TRY(h, pf_launch(op.pf, op.pfplan, B, op.nz, st));
             break;
         case Op::CONVWS: HIP_TRY(h, ws_launch(op.ws, op.wsplan, st)); break;
+        case Op::CONVWS1: HIP_TRY(h, ws1_launch(op.ws1, op.ws1plan, st)); break;
         case Op::PFPACK:
             if (op.pk.c4 == 2) {       // unpack: planes (pk.dst) -> the tensor's fp32 buffer (pk.src)
                 HIP_TRY(h, pf_unpack_launch(op.pk.dst, op.pk.dst_bs, const_cast<float *>(op.pk.src), op.pk.src_bs, op.pk.C, op.pk.H, op.pk.W, B, st));

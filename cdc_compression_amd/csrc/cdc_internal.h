@@ -72,6 +72,11 @@ struct WsPlan { int W, NPB, waves, tiles, groups; size_t lds_bytes; };
 struct WsArgs;
 bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *plan);
 hipError_t ws_launch(WsArgs a, const WsPlan &plan, hipStream_t st);
+// ... and its pointwise sibling (conv_ws1_kernel.h)
+struct Ws1Plan { int NPB, waves, tiles, groups; size_t lds_bytes; };
+struct Ws1Args;
+bool ws1_make_plan(int Cin, int C0, int Cout, int HW, int B, bool per_image_w, Ws1Plan *plan);
+hipError_t ws1_launch(Ws1Args a, const Ws1Plan &plan, hipStream_t st);
 // pointwise (1x1) convolution with per-wave activation staging from the fp32 tensor (conv_pw_kernel.h, conv_inst_w.hip)
 bool pw_make_plan(const PfShape &s, PfPlan *plan);
 hipError_t pw_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);

@@ -2,6 +2,7 @@
 // convolution of the few-pixel levels.
 #include "cdc_internal.h"
 #include "conv_ws_kernel.h"
+#include "conv_ws1_kernel.h"
 
 namespace cdc {
 
@@ -99,6 +100,50 @@ hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
         fprintf(stderr, "\n");
     }
 #endif
+    return hipGetLastError();
+}
+
+
+// ---- conv_ws1_kernel (conv_ws1_kernel.h): the 1x1 layers of the few-pixel levels --------------------------------------------------
+bool ws1_make_plan(int Cin, int C0, int Cout, int HW, int B, bool per_image_w, Ws1Plan *p) {
+    static const bool off = dev_env("CDC_NO_WS1") != nullptr;
+    if (off || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32 || (HW % 32) || HW < 32) return false;
+    const int groups = Cout / 32, nchunk = Cin / 16;
+    const long long blocks = (long long)B * (HW / 32);
+    const long long min_wgs = dev_env("CDC_WS1_MIN_WGS") ? atoll(dev_env("CDC_WS1_MIN_WGS")) : 12;
+    const int force_npb = dev_env("CDC_WS1_NPB") ? atoi(dev_env("CDC_WS1_NPB")) : 0;
+    for (int npb : {4, 2}) {
+        if (force_npb && npb != force_npb) continue;
+        if (npb == 4 && per_image_w) continue;             // (a weight set per pixel block: four of them do not fit the registers)
+        if (blocks % npb) continue;
+        const long long tiles = blocks / npb, wgs = tiles * groups;
+        if (npb == 4 && !force_npb && wgs < (3 * device_cus()) / 4) continue;     // 128-pixel tiles only where they fill the chip
+        if (wgs < min_wgs || tiles > (1 << 20)) return false;
+        int waves = 0;
+        for (int w = 8; w >= 1; --w)
+            if (nchunk % w == 0) { waves = w; break; }
+        p->NPB = npb; p->waves = waves; p->tiles = (int)tiles; p->groups = groups; p->lds_bytes = (size_t)waves * npb * 4096;
+        return true;
+    }
+    return false;
+}
+
+hipError_t ws1_launch(Ws1Args a, const Ws1Plan &p, hipStream_t st) {
+    const bool pi = a.w_bs != 0;
+    ws1_kernel_fn fn = p.NPB == 4 ? (pi ? conv_ws1_kernel<4, true> : conv_ws1_kernel<4, false>) : (pi ? conv_ws1_kernel<2, true> : conv_ws1_kernel<2, false>);
+    static bool attr_done[16][2][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev][p.NPB == 4][pi]) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) attr_done[dev][p.NPB == 4][pi] = true;
+    }
+    a.tiles = p.tiles;
+    a.cpw = a.nchunk / p.waves;
+    const unsigned grid = (unsigned)(p.tiles * p.groups);
+    a.xcd_remap = (grid % 8 == 0 && grid >= 64) ? 1 : 0;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * p.waves), p.lds_bytes, st, a);
     return hipGetLastError();
 }
 

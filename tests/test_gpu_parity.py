@@ -197,6 +197,33 @@ def test_conv2d_weight_stationary_kernel(O, case, npb, monkeypatch):
     assert relerr(G2.conv2d(x, w, b, s, p), ref) < 1e-5
 
 
+WS1_CASES = [
+    # 1x1 layers of the few-pixel levels on conv_ws1_kernel (all of K inside the workgroup; 32-pixel blocks of the flattened batch)
+    (2, 384, 8, 8, 384), (4, 320, 8, 8, 960), (1, 256, 16, 16, 768), (3, 640, 16, 16, 256), (2, 48, 8, 8, 32), (1, 64, 4, 24, 96),
+]
+
+
+@pytest.mark.parametrize("npb", ["2", "4"])
+@pytest.mark.parametrize("case", WS1_CASES)
+def test_conv2d_pointwise_few_pixel_kernel(O, case, npb, monkeypatch):
+    """bias-only and bias + per-image shift + residual 1x1 convolutions on conv_ws1_kernel against the oracle (64- and 128-pixel tiles;
+    a case whose batch does not divide into the forced tile stays on the round-4 kernels and is still checked)."""
+    monkeypatch.setenv("CDC_WS1_MIN_WGS", "1")
+    monkeypatch.setenv("CDC_WS1_NPB", npb)
+    from cdc_compression_amd.ops import Ops
+    B, Ci, H, W, Co = case
+    x = synth.normal("cx", (B, Ci, H, W), 31)
+    w = synth.normal("cw", (Co, Ci, 1, 1), 31, 1.0 / np.sqrt(Ci))
+    b = synth.normal("cb", (Co,), 31, 0.1)
+    shift = synth.normal("cs", (B, Co), 31, 0.3)
+    ref = O.conv2d(x, w, b, 1, 0)
+    resid = synth.normal("cr", ref.shape, 31)
+    G2 = Ops(0)
+    assert relerr(G2.conv2d(x, w, b, 1, 0), ref) < 1e-5
+    got = G2.conv2d(x, w, b, 1, 0, shift=shift, resid=resid)
+    assert relerr(got, ref + shift[:, :, None, None] + resid) < 1e-5
+
+
 @pytest.mark.parametrize("npb", ["2", "4"])
 def test_weight_stationary_trunk_matches_the_round4_program(npb, monkeypatch):
     """The few-pixel trunk of the full-width model on conv_ws_kernel (raw result + in-place LayerNorm pass) with 64- and 128-pixel tiles
@@ -209,21 +236,29 @@ def test_weight_stationary_trunk_matches_the_round4_program(npb, monkeypatch):
         t = np.full((B, 1), 0.3, np.float32)
         ctx = [synth.normal(f"c{l}", (B, c, S >> l, S >> l), seed=52, std=0.5) for l, c in enumerate([64, 64, 128, 192])]
         monkeypatch.setenv("CDC_WS_MIN_WGS", "1000000")
+        monkeypatch.setenv("CDC_WS1_MIN_WGS", "1000000")
         un = cdc.Unet(**kw)
         un.load_state_dict(sd)
         y = un(x, t, ctx)
         assert not [l for l in _op_labels(un) if " WS" in l]
         monkeypatch.setenv("CDC_WS_MIN_WGS", "1")
+        monkeypatch.setenv("CDC_WS1_MIN_WGS", "1")
         monkeypatch.setenv("CDC_WS_NPB", npb)
+        monkeypatch.setenv("CDC_WS1_NPB", npb)
         un2 = cdc.Unet(**kw)
         un2.load_state_dict(sd)
         y2 = un2(x, t, ctx)
-        ws = [l for l in _op_labels(un2) if " WS" in l]
+        ws = [l for l in _op_labels(un2) if " WS " in l or l.endswith(" WS")]
+        ws1 = [l for l in _op_labels(un2) if " WS1" in l]
         assert len(ws) >= 8 and all(f"NPB{npb}" in l for l in ws), ws
+        # the 1x1 family of the trunk: folded-PreNorm projections, per-image attention products, to_out with the residual, res_convs
+        # (per-image weight sets exist in the 64-pixel form only: one set per pixel block)
+        assert any(" pre" in l for l in ws1) and (npb == "4" or any("perimg" in l for l in ws1)) and any("+res" in l for l in ws1) and len(ws1) >= 4, ws1
         assert relerr(y2, y) < 5e-6, (B, relerr(y2, y))
         for _ in range(5):
             np.testing.assert_array_equal(un2(x, t, ctx), y2)
         monkeypatch.delenv("CDC_WS_NPB")
+        monkeypatch.delenv("CDC_WS1_NPB")
 
 
 @pytest.mark.parametrize("case", PF_S2_CASES)
