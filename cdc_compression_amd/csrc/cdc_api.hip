@@ -1181,6 +1181,12 @@ struct Builder {
         if (o.w_bs && !o.wsp_bs) return false;               // per-image weights without planes
         if (w.COP != w.Cout || w.Cin_pad != w.Cin || out_bs != (long long)w.Cout * H * W) return false;
         if (o.resid && (o.resid_cs != (long long)H * W)) return false;
+        // Measured (batch 32, profiles/per_op_r05*.txt): it wins wherever the alternative is a split-K launch + sum pass (the 8x8 level, the
+        // per-image attention products everywhere); at 16x16 and batch 32 the wide folded-PreNorm projections (24 - 36 channel groups, each
+        // converting the same activations again) and the res_convs are faster on conv_pw_kernel's 64 - 96-channel workgroups.
+        const long long blocks = (long long)pb() * (H * W / 32);
+        static const long long max_blocks = dev_env("CDC_WS1_MAX_BLOCKS") ? atoll(dev_env("CDC_WS1_MAX_BLOCKS")) : 128;
+        if (blocks > max_blocks && !o.wsp_bs) return false;
         Op op;
         op.kind = Op::CONVWS1; op.prof = prof;
         if (!ws1_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H * W, pb(), o.wsp_bs != 0, &op.ws1plan)) return false;
