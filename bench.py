@@ -286,7 +286,19 @@ def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cf
     return out
 
 
-def verify_rows(decode_fn, init, ctx, rec, B, sample_steps):
+def launches_per_iter(L, h):
+    """Kernel launches of one DDIM iteration of the handle's current launch program: its ops without the hoisted (once per decode)
+    context convolutions and without the 7-row combine, which the sampler kernel evaluates -- that kernel is the + 1."""
+    n = 0
+    for i in range(L.cdc_prof_num_ops(h)):
+        lab, ms, cnt, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl))
+        t = lab.value.decode()
+        n += 0 if (" HOIST" in t or t == "combine" or t == "temb") else 1
+    return n + 2          # + the time-embedding row copy + the sampler update
+
+
+def verify_rows(decode_fn, init, ctx, rec, B, sample_steps, count_ops=None):
     """Rows 0 and B-1 of a timed decode decoded again on their own (batch-1 launch plans: different kernels, K splits and
     summation orders) must agree; also the batch-1 latency (what the reference's test scripts run: one image per call)."""
     import torch
@@ -301,6 +313,8 @@ def verify_rows(decode_fn, init, ctx, rec, B, sample_steps):
         errs.append(float((r1[0] - rec[k]).abs().max().item()) / den)
     verify = {"rows": list(rows), "max_rel_err_vs_batch1_decode": max(errs), "tolerance": 1e-4, "ok": bool(max(errs) <= 1e-4)}
     batch1 = {"images_per_s": len(rows) / t1, "ms_per_ddim_iter": t1 / len(rows) / sample_steps * 1e3,
+              # kernel launches of one DDIM iteration of the batch-1 launch program (the U-Net's ops + the sampler update)
+              "launches_per_iter": count_ops() if count_ops else None,
               "note": "one image per call, same model and step count (the reference test scripts' mode)"}
     return verify, batch1
 
@@ -533,7 +547,7 @@ def main():
         if world == 1 and not a.no_verify:
             # Verification + batch-1 latency (what test_xparam.py runs: one image per call): rows 0 and B-1 of the
             # timed decode are decoded again on their own (different launch plans) and must agree.
-            out["verify"], out["batch1"] = verify_rows(decode_fn, init, ctx, rec, B, a.sample_steps)
+            out["verify"], out["batch1"] = verify_rows(decode_fn, init, ctx, rec, B, a.sample_steps, count_ops=lambda: launches_per_iter(L, h))
             out["config"]["finite"] = ok and out["verify"]["ok"]
         if world == 1 and not a.no_alt_arith and arith == 1:
             # The exact-split arithmetic on the record beside the default one: the same decode once more in

@@ -503,21 +503,12 @@ __global__ void __launch_bounds__(64 * NW, CB == 2 ? (VP ? 2 : 3) : 1) kvctx16_k
 hipError_t kvctx_launch(const KvCtxArgs &a, int B, hipStream_t st) {
     if (a.N % (32 * a.nsplit)) return hipErrorInvalidValue;
     dim3 grid((unsigned)a.nsplit, (unsigned)B);
-    static const bool w4 = dev_env("CDC_KVCTX_W4") != nullptr;      // C = 128: 4 waves with the f32-MFMA projection
     // fp16 arithmetic: kvctx16_kernel (shared x split).  Plane-form v tile (VP) only at C = 128: at C = 64 it costs
     // the third workgroup per CU (LDS) and the barrier-synchronised waves gain nothing from moving the split
     // (measured, batch 32: C = 64 / 256^2 0.417 -> 0.280 ms without VP, 0.350 with; C = 128 / 128^2 0.416 -> 0.253 / 0.245).
-    const char *kv16e = dev_env("CDC_KVCTX16");           // (read per launch: the tests switch it inside one process)
-    const int kv16 = kv16e ? atoi(kv16e) : -1;  // 0 kvctx_kernel, 1 no VP, 2 VP, -1 per C
-    const int kv = kv16 >= 0 ? kv16 : (a.C == 128 ? 2 : 1);
-    if (a.C == 64 && a.f16 && kv == 2) hipLaunchKernelGGL((kvctx16_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
-    else if (a.C == 64 && a.f16 && kv == 1) hipLaunchKernelGGL((kvctx16_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
-    else if (a.C == 128 && a.f16 && kv == 2) hipLaunchKernelGGL((kvctx16_kernel<4, 8, true>), grid, dim3(512), 0, st, a);
-    else if (a.C == 128 && a.f16 && kv == 1) hipLaunchKernelGGL((kvctx16_kernel<4, 8, false>), grid, dim3(512), 0, st, a);
-    else if (a.C == 64 && a.f16) hipLaunchKernelGGL((kvctx_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
-    else if (a.C == 128 && a.f16) hipLaunchKernelGGL((kvctx_kernel<4, 8, true>), grid, dim3(512), 0, st, a);
+    if (a.C == 64 && a.f16) hipLaunchKernelGGL((kvctx16_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
+    else if (a.C == 128 && a.f16) hipLaunchKernelGGL((kvctx16_kernel<4, 8, true>), grid, dim3(512), 0, st, a);
     else if (a.C == 64) hipLaunchKernelGGL((kvctx_kernel<2, 4>), grid, dim3(256), 0, st, a);
-    else if (a.C == 128 && w4) hipLaunchKernelGGL((kvctx_kernel<4, 4>), grid, dim3(256), 0, st, a);
     else if (a.C == 128) hipLaunchKernelGGL((kvctx_kernel<4, 8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();

@@ -341,7 +341,7 @@ hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
     if (a.C <= 8 * kLnCache && a.nparts >= 1 && a.nparts <= kLnVecMaxParts2 && (a.HW & 3) == 0 && (a.part_stride & 3) == 0 &&
         ((((uintptr_t)a.in) | ((uintptr_t)a.out) | ((uintptr_t)a.resid) | ((uintptr_t)a.stat_mean) | ((uintptr_t)a.stat_rstd)) & 15) == 0 &&
         !dev_env("CDC_NO_LN_VEC")) {
-        const long long min_wgs = dev_env("CDC_LN_MIN_WGS") ? atoll(dev_env("CDC_LN_MIN_WGS")) : 256;
+        const long long min_wgs = 256;
         int cols = (long long)ceil_div(a.HW, 32) * B >= min_wgs ? 8 : ((long long)ceil_div(a.HW, 16) * B >= min_wgs ? 4 : 2);
         if (const char *e = dev_env("CDC_LN_VEC_COLS")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) cols = v; }
         if (a.nparts > 4) cols = 2;                   // (more than four slices exist for the 8-pixel form only)
@@ -352,9 +352,9 @@ hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
         return hipGetLastError();
     }
     if (a.C <= 8 * kLnCache) {
-        static const int pl8_max = dev_env("CDC_LN_PL8_MAX") ? atoi(dev_env("CDC_LN_PL8_MAX")) : 64;
+        static const int pl8_max = 64;
         // 8-pixel workgroups also wherever 32-pixel ones would leave most of the chip idle (small batches)
-        static const int min_wgs = dev_env("CDC_LN_MIN_WGS") ? atoi(dev_env("CDC_LN_MIN_WGS")) : 256;    // (measured at batch 32: 16x16 maps are faster on 32-pixel workgroups, 128-byte rows)
+        static const int min_wgs = 256;    // (measured at batch 32: 16x16 maps are faster on 32-pixel workgroups, 128-byte rows)
         const bool pl8 = a.HW <= pl8_max || (long long)ceil_div(a.HW, 32) * B < min_wgs;
         const dim3 grid((unsigned)ceil_div(a.HW, pl8 ? 8 : 32), (unsigned)B);
 #define CDC_LN_LAUNCH(PLV, NPV) hipLaunchKernelGGL((ln_kernel_sliced<PLV, NPV>), grid, dim3(256), 0, st, a)
@@ -1178,7 +1178,7 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
     int spf = 1;
     while (2 * spf * C <= 512 && 2 * spf <= nsplit) spf *= 2;
     // whole 32 x 32 blocks (the folded levels of the full-width models: C = 64, 128, 192): R1 / R2 / R3 on the f32 matrix cores
-    const bool mfma = Wq && (C % 32) == 0 && Cin_pad == C && COP == C && !dev_env("CDC_NO_FOLD_MFMA");
+    const bool mfma = Wq && (C % 32) == 0 && Cin_pad == C && COP == C;
     hipLaunchKernelGGL(ctx_r0_kernel, dim3(C, B), dim3(C * spf), sizeof(float) * (2 * nsplit + spf * C), st, S, ksum, C, nsplit,
                        Mt, M, spf, mfma ? 1 : 0);
     if (mfma) {
@@ -1190,11 +1190,10 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
             hipLaunchKernelGGL(fold_r2_mfma_kernel<CTV>, grid, dim3(64), lds, st, T1, Wq, C, scale, ln_g, Mt, Cin_pad, COP, Ws, ws_f16, \
                                u, b_out, biasB);                                                                                    \
         } while (0)
-        const bool ct = !dev_env("CDC_FOLD_RT");      // (the run-time-count form: A/B and the other channel counts)
-        if (ct && C == 64) CDC_FOLD_LAUNCH(64);
-        else if (ct && C == 128) CDC_FOLD_LAUNCH(128);
-        else if (ct && C == 192) CDC_FOLD_LAUNCH(192);
-        else CDC_FOLD_LAUNCH(0);
+        if (C == 64) CDC_FOLD_LAUNCH(64);
+        else if (C == 128) CDC_FOLD_LAUNCH(128);
+        else if (C == 192) CDC_FOLD_LAUNCH(192);
+        else CDC_FOLD_LAUNCH(0);                        // (the run-time-count form: the other channel counts)
 #undef CDC_FOLD_LAUNCH
         return hipGetLastError();
     }
@@ -1364,7 +1363,7 @@ hipError_t step_dec_launch(int *step, hipStream_t st) {
 hipError_t ddim_launch(const DdimArgs &a, hipStream_t st) {
     const long long plane = (long long)a.pH * a.pW;
     if (a.P && plane > 0 && (a.pW & 3) == 0 && plane < (1ll << 30) && a.n % plane == 0 && a.n / plane <= 65535 &&
-        (((uintptr_t)a.P | (uintptr_t)a.x | (uintptr_t)a.x_next | (uintptr_t)a.noise) & 15) == 0 && !dev_env("CDC_NO_DDIM_ROWS4")) {
+        (((uintptr_t)a.P | (uintptr_t)a.x | (uintptr_t)a.x_next | (uintptr_t)a.noise) & 15) == 0) {
         hipLaunchKernelGGL(ddim_rows4_kernel, dim3((unsigned)ceil_div(plane / 4, 256), (unsigned)(a.n / plane)), dim3(256), 0, st, a);
         return hipGetLastError();
     }

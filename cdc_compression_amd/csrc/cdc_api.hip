@@ -484,7 +484,7 @@ int pack_resblock(cdc_handle *h, const std::string &p, int cin, int cout, int k,
     if (hoist_cx > 0) {
         const std::string w1 = p + ".block1.block.0.weight", b1 = p + ".block1.block.0.bias";
         if ((rc = pack_named_conv(h, w1, "", 1, k / 2, false, &rb.c1x, 0, hoist_cx))) return rc;
-        if (k > 3 && hoist_cx * k <= 32 && !dev_env("CDC_NO_UNFOLD")) {
+        if (k > 3 && hoist_cx * k <= 32) {
             // column-unfolded form of the few-channel k x k layer: w'[co][kx*cx + c][ky][0] = w[co][c][ky][kx]
             const Param &pw = h->params[h->pindex.at(w1)];
             const int co_n = (int)pw.shape[0], ci_n = (int)pw.shape[1], cu = hoist_cx * k;
@@ -645,7 +645,7 @@ void free_pool(std::vector<void *> *pool) {
 // ------------------------------------------------------------------------------------------------
 // program construction
 // ------------------------------------------------------------------------------------------------
-static int ks_target() { static const int v = dev_env("CDC_KS_TARGET") ? atoi(dev_env("CDC_KS_TARGET")) : 1024; return v; }
+constexpr int kKsTarget = 1024;     // split-K: workgroups a few-pixel launch is sliced up to
 
 struct Builder {
     cdc_handle *h;
@@ -666,7 +666,7 @@ struct Builder {
         if (op.kind == Op::CONV)
             snprintf(buf, sizeof buf, "conv %dx%d s%d %4d->%-4d out %3dx%-3d MB%d NPW%d WN%d g%d tg%d ipw%d ks%d%s%s%s%s%s", op.conv.KH,
                      op.conv.KW, op.conv.stride, op.conv.Cin, op.conv.Cout, op.conv.Ho, op.conv.Wo, op.plan.MB,
-                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.tg, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? (op.plan.pipe ? " SPLIT2H PIPE" : " SPLIT2H") : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
+                     op.plan.NPW, op.plan.WN, op.plan.groups, op.plan.tg, op.plan.ipw, op.plan.ksplit, op.plan.split == 2 ? (op.plan.arith ? " SPLIT2H" : " SPLIT2") : (op.plan.split ? " SPLIT" : ""),
                      op.conv.ep_g ? " LN" : "",
                      op.conv.ln_mean ? " pre" : "", cur == &h->pre_ops ? " HOIST" : "", op.conv.resid ? " +res" : "");
         else if (op.kind == Op::CONVPF)
@@ -864,7 +864,7 @@ struct Builder {
     }
     // ... the same question by shapes alone (asked in the encoder path, before the decoder half of the join exists)
     bool join_would_read_planes(const ResBlockW &rb, int C0, int H, int W) {
-        if (!pf_on() || !rb.has_res || rb.hoist_cx || dev_env("CDC_NO_PF_ONLY_JOIN")) return false;
+        if (!pf_on() || !rb.has_res || rb.hoist_cx) return false;
         if (rb.cres.Cin != rb.c1.Cin || (C0 % 16) || C0 <= 0 || C0 >= rb.c1.Cin || !pf_site(SITE_JOIN, H, W)) return false;
         for (const ConvW *w : {&rb.c1, &rb.cres}) {
             const bool k3 = w->KH == 3 && w->KW == 3, k1 = w->KH == 1 && w->KW == 1;
@@ -891,7 +891,7 @@ struct Builder {
 
     // Would an Upsample (ConvTranspose2d 4x4 / stride 2 / pad 1) run on conv_pf_kernel<..., TZ = 4> given a PF input of H x W?
     bool pf_tz_would_plan(const ConvW &w, int H, int W) {
-        if (!pf_on() || !w.wsh || !w.transposed || w.tk != 4 || w.KH != 2 || w.KW != 2 || (w.Cin % 16) || dev_env("CDC_PF_TRANSPOSED")) return false;
+        if (!pf_on() || !w.wsh || !w.transposed || w.tk != 4 || w.KH != 2 || w.KW != 2 || (w.Cin % 16)) return false;
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.KH = 2; ps.KW = 2; ps.nz = w.nz; ps.Ho = H; ps.Wo = W; ps.B = pb(); ps.tz = 4;
         PfPlan plan;
@@ -931,9 +931,7 @@ struct Builder {
         if (!t0 || !t0->valid || (s1 && (!t1 || !t1->valid))) return false;
         if (t0->H != H || t0->W != W || (t1 && (t1->H != H || t1->W != W))) return false;
         if (s1 ? (t0->C != C0 || t0->C + t1->C != w.Cin) : t0->C != w.Cin) return false;
-        // transposed 4x4: the four 2x2 phases fused in one workgroup (TZ = 4); CDC_PF_TRANSPOSED=1 selects the older
-        // phase-per-workgroup form (measured slower than the phase-folded split kernel)
-        static const bool pf_t = dev_env("CDC_PF_TRANSPOSED") != nullptr;
+        // transposed 4x4: the four 2x2 phases fused in one workgroup (TZ = 4)
         const bool k3 = w.KH == 3 && w.KW == 3 && !w.transposed, k1 = w.KH == 1 && w.KW == 1, k2 = w.transposed && w.tk == 4 && !s1;
         const bool k17 = w.KH == 1 && w.KW == 7 && !w.transposed && w.stride == 1 && !s1 && !o.ln_g && !o.emit_pf;   // row-folded final convolution
         if (!(k3 || k1 || k2 || k17)) return false;
@@ -941,7 +939,7 @@ struct Builder {
         PfShape ps;
         ps.Cin = w.Cin; ps.Cout = w.Cout; ps.C0 = s1 ? C0 : 0; ps.KH = w.KH; ps.KW = w.KW; ps.nz = w.nz;
         ps.Ho = s.Ho; ps.Wo = s.Wo; ps.B = pb(); ps.need_all_cout = need_all; ps.stride = w.stride;
-        ps.tz = (k2 && !pf_t) ? 4 : 1;
+        ps.tz = k2 ? 4 : 1;
         ps.cop = w.COP;
         PfPlan plan;
         if (!pf_make_plan(ps, &plan)) return false;
@@ -1185,8 +1183,7 @@ struct Builder {
         // per-image attention products everywhere); at 16x16 and batch 32 the wide folded-PreNorm projections (24 - 36 channel groups, each
         // converting the same activations again) and the res_convs are faster on conv_pw_kernel's 64 - 96-channel workgroups.
         const long long blocks = (long long)pb() * (H * W / 32);
-        static const long long max_blocks = dev_env("CDC_WS1_MAX_BLOCKS") ? atoll(dev_env("CDC_WS1_MAX_BLOCKS")) : 128;
-        if (blocks > max_blocks && !o.wsp_bs) return false;
+        if (blocks > 128 && !o.wsp_bs) return false;
         Op op;
         op.kind = Op::CONVWS1; op.prof = prof;
         if (!ws1_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H * W, pb(), o.wsp_bs != 0, &op.ws1plan)) return false;
@@ -1261,8 +1258,7 @@ struct Builder {
         if (!o.uf_c && try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
                                w.nz == 1 && !w.transposed;
-        if (!dev_env("CDC_NO_KSPLIT") && !dev_env("CDC_NO_KSPLIT_PLAN"))
-            s.max_ksplit = o.max_ksplit > 1 ? o.max_ksplit : (linear_ep ? 4 : 1);
+        s.max_ksplit = o.max_ksplit > 1 ? o.max_ksplit : (linear_ep ? 4 : 1);
         if (need_all && (w.Cout % 32)) return false;
         ConvPlan plan;
         if (!conv_make_plan(s, &plan)) {
@@ -1271,16 +1267,16 @@ struct Builder {
                       w.Cin, w.Cout, w.KH, w.KW, s.Ho, s.Wo);
             return true;
         }
-        if (o.uf_c && !(plan.split == 2 && plan.arith == 1 && plan.xu == 1 && plan.lnmode == 0 && !plan.pipe &&
+        if (o.uf_c && !(plan.split == 2 && plan.arith == 1 && plan.xu == 1 && plan.lnmode == 0 &&
                         conv_lookup_split2hu(plan.MB, plan.NPW))) return false;                       // only that kernel unfolds on load
         last_ksplit = 1;
         last_pf_only = false;
-        if (o.max_ksplit > 1 && plan.split == 2 && !need_all && !dev_env("CDC_NO_KSPLIT")) {
+        if (o.max_ksplit > 1 && plan.split == 2 && !need_all) {
             // few workgroups and a long K loop (low-resolution levels): slice K so that the chip holds
             // >= 4 workgroups per CU; the LayerNorm kernel that follows adds the slices
             const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(pb(), plan.ipw) : plan.tiles_x * plan.tiles_y * pb()) *
                                   plan.groups * w.nz;
-            int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(o.max_ksplit, plan.nchunk / 4));
+            int ks = (int)std::min<long long>(ceil_div(kKsTarget, wgs), std::min(o.max_ksplit, plan.nchunk / 4));
             if (ks > 1) { plan.ksplit = ks; last_ksplit = ks; }
         }
         // Plain (linear) epilogues at the few-workgroup levels -- the attention projections and res_convs
@@ -1288,10 +1284,10 @@ struct Builder {
         float *ks_scratch = nullptr;
         const long long dense_bs = (long long)w.Cout * s.Ho * s.Wo;
         if (o.max_ksplit <= 1 && plan.split == 2 && !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean &&
-            !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed && !dev_env("CDC_NO_KSPLIT")) {
+            !o.pre_add && !o.res3_w && w.nz == 1 && !w.transposed) {
             const long long wgs = (long long)(plan.ipw > 1 ? ceil_div(pb(), plan.ipw) : plan.tiles_x * plan.tiles_y * pb()) *
                                   plan.groups;
-            const int ks = (int)std::min<long long>(ceil_div(ks_target(), wgs), std::min(4, plan.nchunk / 4));
+            const int ks = (int)std::min<long long>(ceil_div(kKsTarget, wgs), std::min(4, plan.nchunk / 4));
             if (ks > 1 && (planB > 0 || (size_t)B * dense_bs * 4 * ks <= (64u << 20))) {
                 plan.ksplit = ks;
                 ks_scratch = dalloc((size_t)ks * B * dense_bs);
@@ -1408,8 +1404,7 @@ struct Builder {
         // the split-bf16 kernels hold at most 6 channel blocks per workgroup: wider layers run them over
         // channel groups (2x the matrix rate) and normalise in a separate pass
         // (round 2: eight blocks = 256 channels with NPW = 1, two workgroups per CU)
-        static const bool no_mb8 = dev_env("CDC_NO_MB8") != nullptr;
-        if (w.wsp && w.Cout > (no_mb8 ? 192 : 256) && (W & 3) == 0 && !dev_env("CDC_NO_SPLIT")) return false;
+        if (w.wsp && w.Cout > 256 && (W & 3) == 0 && !dev_env("CDC_NO_SPLIT")) return false;
         ConvShape s;
         s.Cin = w.Cin; s.Cout = w.Cout; s.KH = w.KH; s.KW = w.KW; s.stride = w.stride;
         s.Ho = H; s.Wo = W; s.B = pb(); s.lnmode = 0;
@@ -1421,7 +1416,7 @@ struct Builder {
         if (!conv_make_plan(s, &pu)) return true;
         const double wf = (double)pf.tiles_x * pf.tiles_y * B * pf.WN;
         const double wu = (double)pu.tiles_x * pu.tiles_y * B * pu.groups * pu.WN;
-        static const double thr = dev_env("CDC_FUSE_MIN_WAVES") ? atof(dev_env("CDC_FUSE_MIN_WAVES")) : 512;
+        static const double thr = 512;
         if (wf >= thr) return true;              // >= half of the chip's 1024 SIMDs busy
         return wu < 1.5 * wf;
     }
@@ -1470,7 +1465,7 @@ struct Builder {
             // small batches: up to six slices (the 8 x 8 level: 24 chunks -> 6 slices of 4; measured at batch 1: its 3 x 3 layers
             // 0.53 -> 0.46 ms per iteration, LayerNorm passes unchanged with ln_kernel_vec<2, 6>; whole model -1.4 % at batch 1 - 4,
             // -0.4 % at 8, +0.5 % at 16, +2.2 % at 32: larger batches fill the chip with four)
-            const int kmax = dev_env("CDC_KMAX") ? atoi(dev_env("CDC_KMAX")) : (pb() <= 8 ? 6 : 4);
+            const int kmax = (pb() <= 8 ? 6 : 4);
             float *part = dalloc(plane_f * kmax);
             u.max_ksplit = kmax;
             conv(w, s0, C0, bs0, s1, bs1, H, W, part, out.bs(), u, false, prof);
@@ -1501,8 +1496,7 @@ struct Builder {
         Act h1 = new_act(rb.cout, H, W), out = new_act(rb.cout, H, W, true, out_site);
         if (pf_mode() >= 2 && pf_would_plan(rb.c2, H, W)) add_twin(h1.p, rb.cout, H, W);
         // h1 feeds block2 only: when block2 runs on the pre-split operand kernel the fp32 copy is never read
-        static const bool keep_h1 = dev_env("CDC_PF_KEEP_H1") != nullptr;
-        const bool h1_pf_only = !keep_h1 && twin(h1.p) && pf_would_plan(rb.c2, H, W);
+        const bool h1_pf_only = twin(h1.p) && pf_would_plan(rb.c2, H, W);
         if (a1 && a1_is_context && rb.hoist_cx == a0.C) {
             // identity residual over cat[x, context] (downs.1.0): read from its two sources in block2's epilogue where that runs on a
             // plane-operand kernel (PfArgs::resid1) instead of materialising the concatenation every iteration
@@ -1526,7 +1520,7 @@ struct Builder {
             cur = saved;
             // first 7x7 layer = 7x1 convolution over the kx-unfolded image: the unfolding happens while the patch is loaded
             // (round 4); the explicit unfold pass + its 21-channel tensor remain the fall-back
-            if (rb.has_unfold && (W & 3) == 0 && !dev_env("CDC_NO_UNFOLD_ON_LOAD") &&
+            if (rb.has_unfold && (W & 3) == 0 &&
                 block(rb.c1u, a0.p, a0.C * rb.k, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
                       nullptr, nullptr, prof1, h1_pf_only, a0.C, rb.k / 2)) {
             } else if (rb.has_unfold && (W & 3) == 0) {
@@ -1540,8 +1534,7 @@ struct Builder {
             } else
             block(rb.c1x, a0.p, a0.C, a0.bs(), nullptr, 0, H, W, h1, rb.g1, rb.b1, shift, p1.p, nullptr, 0,
                   nullptr, nullptr, prof1, h1_pf_only);
-            if (rb.has_res && a0.C == 3 && rb.cresx.COP == round_up(rb.cout, 32) && prefer_fused(rb.c2, H, W) &&
-                !dev_env("CDC_NO_RES3")) {
+            if (rb.has_res && a0.C == 3 && rb.cresx.COP == round_up(rb.cout, 32) && prefer_fused(rb.c2, H, W)) {
                 // res_conv over the 3 image channels rides in block2's epilogue; its context half (with
                 // the bias) is the hoisted tensor
                 res = pr.p; res_bs = pr.bs();
@@ -1593,8 +1586,6 @@ struct Builder {
         a.pf = t->p; a.pf_bs = t->bs();
     }
 
-    std::vector<std::pair<const float *, size_t>> dbg_taps;   // debugging aid (CDC_ATTN_TAP)
-
     // Residual(PreNorm(LinearAttention)) (network_components.py:10-16,69-77,117-139)
     // out_planes_only: the output's only reader takes planes (the level-0 Downsample) -- no fp32 copy is written where the folded
     // output runs on the pointwise kernel; Act::pf of the result says whether that happened
@@ -1603,7 +1594,7 @@ struct Builder {
         const int C = at.C, H = x.H, W = x.W, N = H * W;
         const bool fold = at.WoT && N >= 16 * C && !dev_env("CDC_NO_ATTN_FOLD");   // 2 C^3 extra vs 2 C^2 N saved
         // C = 64 levels: k/v projection, row maxima and softmax(k) v^T in ONE pass over x (attn_kernels.hip)
-        const bool fused = fold && (C == 64 || (C == 128 && !dev_env("CDC_NO_KVCTX128"))) &&
+        const bool fused = fold && (C == 64 || C == 128) &&
                            at.kvWt && N % 2048 == 0 && !dev_env("CDC_NO_KVCTX");
         const int kvc = fold ? 2 * C : 3 * C;          // channels of the staged projection
         Act qkv = fused ? Act() : new_act(kvc, H, W, false);
@@ -1617,8 +1608,8 @@ struct Builder {
         int nsplit = std::max(1, ceil_div(1024, tiles * tiles * B));
         nsplit = std::min(nsplit, std::max(1, N / 64));
         if (fused) {        // >= 2.6 rounds of 3 workgroups per CU (C = 64) / 4 rounds of one (C = 128)
-            static const int kv64 = dev_env("CDC_KV64_WGS") ? atoi(dev_env("CDC_KV64_WGS")) : 1024;   // (round 4: 2048 -> 1024: half the partial sums for the fold to add, 13.92 -> 13.89 ms per iteration)
-            static const int kv128 = dev_env("CDC_KV128_WGS") ? atoi(dev_env("CDC_KV128_WGS")) : 1024;
+            static const int kv64 = 1024;   // (round 4: 2048 -> 1024: half the partial sums for the fold to add, 13.92 -> 13.89 ms per iteration)
+            static const int kv128 = 1024;
             nsplit = std::min(128, C == 64 ? ceil_div(kv64, B) : ceil_div(kv128, B));   // (the fold sums the splits serially)
             while (nsplit > 1 && N % (32 * nsplit)) --nsplit;
         }
@@ -1637,7 +1628,7 @@ struct Builder {
         if (fused) {
             Op f; f.kind = Op::KVCTX; f.prof = PC_ATTN_CTX;
             f.kvc = {x.p, x.bs(), sm, sr, at.kvWt, at.kvb, at.kvWs, C, N, nsplit, S, ksum, kmaxs};
-            if (h->arith == 1 && at.kvWh && !dev_env("CDC_KVCTX_BF16")) { f.kvc.Ws = at.kvWh; f.kvc.f16 = 1; f.kvc.wscale_inv = at.kv_scale_inv; }
+            if (h->arith == 1 && at.kvWh) { f.kvc.Ws = at.kvWh; f.kvc.f16 = 1; f.kvc.wscale_inv = at.kv_scale_inv; }
             f.flops = 6.0 * B * (double)C * C * N; f.bytes = 4.0 * B * C * N;
             emit(f);
         }
@@ -1650,8 +1641,7 @@ struct Builder {
             emit(p);
         }
         // folded output as one streaming pass (lnconv_kernel) where the level is wide enough to be bandwidth-bound
-        const bool stream_out = fold && (C == 64 || C == 192 || (C == 128 && dev_env("CDC_LNCONV128"))) && N >= 4096 && N % 1024 == 0 &&
-                                !dev_env("CDC_NO_LNCONV");
+        const bool stream_out = fold && (C == 64 || C == 192) && N >= 4096 && N % 1024 == 0;
         // folded output as a 1x1 split convolution with per-image planes (C % 16 == 0, planes layout = the A-operand
         // layout of conv_split2_kernel with COP == C): replaces the f32-MFMA kernel and, where faster, lnconv_kernel
         const bool no_pic = dev_env("CDC_NO_PERIMAGE_SPLIT") != nullptr;
@@ -1676,9 +1666,6 @@ struct Builder {
         cw.Cin = C; cw.Cout = C; cw.KH = cw.KW = 1; cw.stride = 1; cw.pad = 0;
         cw.Cin_pad = Cin_pad; cw.COP = COP; cw.wp = ctxw; cw.nz = 1; cw.bias = nullptr;
         Act y = new_act(C, H, W, true, out_site);       // a skip tensor is a decoder concat half; an Upsample input has no plane reader
-        if (!fused)
-        dbg_taps = {{sm, (size_t)B * N}, {qkv.p, (size_t)B * kvc * N}, {kmax, (size_t)B * C}, {ksum, (size_t)B * nsplit * C},
-                    {S, (size_t)B * nsplit * C * C}, {ctxw, (size_t)B * Cin_pad * COP}};
         if (split_out || split_ctxq) {
             cw.wsp = Ws;                                   // (bf16 planes unless planes_f16)
             if (planes_f16) { cw.wsh = Ws; cw.wscale_inv = 1.0f / 256.0f; }
@@ -1710,7 +1697,6 @@ struct Builder {
         }
         // out[e,n] = sum_d ctx[d,e] q[d,n]  as a 1x1 convolution with per-image weights (:137)
         Act o = new_act(C, H, W, false);
-        dbg_taps.push_back({o.p, (size_t)B * C * N});
         ConvOpts oo; oo.w_bs = (long long)Cin_pad * COP; oo.no_bias = true;
         if (split_ctxq) oo.wsp_bs = (long long)(C / 16) * 6 * C * 8;
         conv(cw, qkv.p, C, qkv.bs(), nullptr, 0, H, W, o.p, o.bs(), oo, false, PC_CONV1);
@@ -1779,7 +1765,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         h->taps[dn + ".1"] = x;
         // (the level-0 skip is never popped -- unet.py:113 pushes six, :123 pops five: its only reader is the Downsample)
         // Its output goes to the Downsample as planes INSTEAD of fp32 where that convolution runs on the plane-operand kernel.
-        const bool l0_planes = i == 0 && n > 1 && bd.pf_s2_would_plan(h->downs[0], x.H, x.W) && !dev_env("CDC_NO_PF_S2_L0");
+        const bool l0_planes = i == 0 && n > 1 && bd.pf_s2_would_plan(h->downs[0], x.H, x.W);
         // A skip (levels >= 1) has two readers, the Downsample and the decoder join of its level (ResnetBlock 2 n + 2 + 2 (n - 1 - i): block1
         // and res_conv over cat[upsampled, skip]): planes only where all of them take planes.
         bool skip_planes = false;
@@ -1794,7 +1780,10 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         if (i < n - 1) {
             const ConvW &dw = h->downs[i];
             Act y = bd.new_act(dw.Cout, x.H / 2, x.W / 2, true, Builder::SITE_DOWN);
-            Builder::ConvOpts od; od.emit_pf = true;
+            // planes of the Downsample output only where its reader -- block1 of the next level's first ResnetBlock -- takes planes (small
+            // batches: it does not, and a split-K Downsample would need a pack launch to make them)
+            const ResBlockW &nrb = h->rbs[rbi];
+            Builder::ConvOpts od; od.emit_pf = bd.pf_would_plan(nrb.hoist_cx ? nrb.c1x : nrb.c1, y.H, y.W);
             bd.conv(dw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), od, false, PC_DOWN);
             if (x.pf && bd.still_planes_only(x.p) && (h->ops.empty() || h->ops.back().kind != Op::CONVPF || h->ops.back().pw))
                 return fail(h, CDC_ERR_UNSUPPORTED, "planes-only Downsample input without a plane-operand kernel");
@@ -1826,15 +1815,14 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         // (an Upsample reads fp32: planes of its input only with the development switch that runs it on conv_pf_kernel)
         // ... or, where the fused-phase plane-operand kernel takes it, planes INSTEAD of fp32 (the Upsample is the only reader)
-        const bool up_planes = bd.pf_tz_would_plan(h->ups[i], x.H, x.W) && !dev_env("CDC_NO_PF_TZ_PLANES");
-        x = bd.attention(h->attns[ati++], x, sm, sr, up_planes ? Builder::SITE_ALWAYS_PLANES : (dev_env("CDC_PF_TRANSPOSED") ? Builder::SITE_JOIN : Builder::SITE_NONE), up_planes);
+        const bool up_planes = bd.pf_tz_would_plan(h->ups[i], x.H, x.W);
+        x = bd.attention(h->attns[ati++], x, sm, sr, up_planes ? Builder::SITE_ALWAYS_PLANES : Builder::SITE_NONE, up_planes);
         const bool x_planes_only = x.pf != nullptr;
         const size_t ops_before = h->ops.size();
         const ConvW &uw = h->ups[i];
         // the last Upsample feeds the final convolution only: planes INSTEAD of fp32 when that runs on the plane-operand kernel
         // (which needs the final LayerNorm applied here, in this epilogue)
-        const bool fin_planes = i == n - 2 && !dev_env("CDC_NO_FINAL_LN_FUSE") && !dev_env("CDC_NO_PF_17_PLANES") &&
-                                bd.pf_17_would_plan(h->fin_conv, x.H * 2, x.W * 2);
+        const bool fin_planes = i == n - 2 && bd.pf_17_would_plan(h->fin_conv, x.H * 2, x.W * 2);
         Act y = bd.new_act(uw.Cout, x.H * 2, x.W * 2, true, fin_planes ? Builder::SITE_ALWAYS_PLANES : Builder::SITE_JOIN);
         Builder::ConvOpts ou;
         ou.emit_pf = i < n - 2;
@@ -1848,14 +1836,12 @@ int build_program(cdc_handle *h, int B, int H, int W) {
             // from the epilogue when one workgroup owns all channels
             // ... or, better, apply that LayerNorm right there (every phase workgroup owns all channels of
             // its pixels): the final convolution then reads an already normalised tensor
-            if (!dev_env("CDC_NO_FINAL_LN_FUSE")) {
-                Builder::ConvOpts ol;
-                ol.ln_g = h->fin_g; ol.ln_b = h->fin_b;
-                ol.emit_pf = ol.no_f32 = fin_planes;
-                done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ol, true, PC_UP);
-                final_ln_done = done;
-                if (done && bd.last_pf_only) { Builder::PfTwin *ty = bd.twin(y.p); y.pf = ty->p; y.pf_bs = ty->bs(); }
-            }
+            Builder::ConvOpts ol;
+            ol.ln_g = h->fin_g; ol.ln_b = h->fin_b;
+            ol.emit_pf = ol.no_f32 = fin_planes;
+            done = bd.conv(uw, x.p, x.C, x.bs(), nullptr, 0, x.H, x.W, y.p, y.bs(), ol, true, PC_UP);
+            final_ln_done = done;
+            if (done && bd.last_pf_only) { Builder::PfTwin *ty = bd.twin(y.p); y.pf = ty->p; y.pf_bs = ty->bs(); }
             if (!done) {
                 fsm = bd.dalloc((size_t)B * 4 * HWl); fsr = bd.dalloc((size_t)B * 4 * HWl);
                 ou.stat_mean = fsm; ou.stat_rstd = fsr;
@@ -2050,14 +2036,13 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
             HIP_TRY(h, kstats_launch(op.at.k, op.at.bs, op.at.C, op.at.N, op.at.kmax, B, st));
             break;
         case Op::CTXP: {
-            const bool ctxp_f32 = dev_env("CDC_CTXP_F32") != nullptr;
             if (op.at_one) {
                 HIP_TRY(h, ctx_one_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.scale, op.at.ctxw, op.at.Cin_pad, op.at.COP,
-                                          op.at_ws_f16 ? op.at_Ws : nullptr, B, st, h->arith == 1 && !ctxp_f32));
+                                          op.at_ws_f16 ? op.at_Ws : nullptr, B, st, h->arith == 1));
                 break;
             }
             HIP_TRY(h, ctx_partial_launch(op.at.k, op.at.v, op.at.bs, op.at.C, op.at.N, op.at.kmax,
-                                          op.at.S, op.at.ksum, op.at.nsplit, B, st, h->arith == 1 && !ctxp_f32));
+                                          op.at.S, op.at.ksum, op.at.nsplit, B, st, h->arith == 1));
             break;
         }
         case Op::CTXR:
@@ -3602,14 +3587,6 @@ static int op_linear_attention_impl(cdc_handle *h, const float *x, const float *
     bd.ln(ax.p, nullptr, C, H * W, nullptr, nullptr, 0, nullptr, nullptr, sm, sr);   // statistics only
     Act ay = bd.attention(at, ax, sm, sr);
     if (bd.rc) return bd.rc;
-    if (const char *tap = dev_env("CDC_ATTN_TAP")) {          // debugging aid: return an intermediate
-        const size_t idx = (size_t)atoi(tap);
-        if (idx < bd.dbg_taps.size()) {
-            const size_t n = std::min(bd.dbg_taps[idx].second, (size_t)B * C * H * W);
-            memset(y, 0, sizeof(float) * (size_t)B * C * H * W);
-            return sc.run(B, y, bd.dbg_taps[idx].first, n);
-        }
-    }
     return sc.run(B, y, ay.p, (size_t)B * C * H * W);
 }
 

@@ -20,12 +20,9 @@ typedef void (*conv_kernel_fn)(const ConvArgs);
 conv_kernel_fn conv_lookup_a(int MB, int NPW, int lnmode);   // MB 1..3
 conv_kernel_fn conv_lookup_b(int MB, int NPW, int lnmode);   // MB 4..6
 conv_kernel_fn conv_lookup_c(int MB, int NPW, int lnmode);   // MB 7..12
-conv_kernel_fn conv_lookup_abl(int MB, int NPW, int abl);    // tuning aid (CDC_ABLATE)
 conv_kernel_fn conv_lookup_split(int MB, int NPW);           // conv_split_kernel.h
-conv_kernel_fn conv_lookup_split_abl(int MB, int NPW, int abl);
 conv_kernel_fn conv_lookup_split2(int MB, int NPW, int lnmode, int xu = 1);
 conv_kernel_fn conv_lookup_split2h(int MB, int NPW, int lnmode, int xu = 1);   // AR = 1: two fp16 planes
-conv_kernel_fn conv_lookup_split2hp(int MB, int NPW, int lnmode, int xu = 1);  // AR = 1, software-pipelined tap loop (PIPE = 1)
 conv_kernel_fn conv_lookup_split2hu(int MB, int NPW);                          // AR = 1, unfold on load (UF = 1; ConvArgs::uf_c)
 
 struct ConvShape {

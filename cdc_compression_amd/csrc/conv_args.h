@@ -179,7 +179,6 @@ struct ConvPlan {
     int ksplit = 1;         // K slices (split2 only)
     int xu = 1;             // patch units per thread (split2 only)
     int arith = 0;          // split2 only: 0 three bf16 planes (6 MFMA products), 1 two fp16 planes (3 products)
-    int pipe = 0;           // split2, arith 1: the software-pipelined tap loop (conv_split_kernel.h, PIPE = 1)
     int split;              // 1: conv_split_kernel (three-plane bf16 operands on the bf16 MFMA)
 };
 

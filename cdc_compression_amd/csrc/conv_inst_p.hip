@@ -202,14 +202,14 @@ hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     if (!fn) return hipErrorInvalidValue;
     if (a.tz == 4) nz = 1;                                   // the phases are evaluated inside the workgroup
     a.lognbw = 5;
-    { static const char *e = dev_env("CDC_PF_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = 0;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
-    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64) ? 1 : 0;
 #ifdef CDC_TIMELINE
     // Development build only (tools/build_variant.sh timeline -DCDC_TIMELINE): per-workgroup cycle categories of conv_pf_kernel, start /
     // end stamps and the CU each workgroup ran on, summarised on stderr for the first launches of every layer shape.

@@ -27,9 +27,8 @@ int device_cus() {
 
 // Takes a fully described stride-1 3x3 layer (the PfArgs of conv_pf_kernel) and decides whether conv_pf3_kernel runs it.
 bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *p) {
-    static const bool off = dev_env("CDC_NO_PF3") != nullptr;
     p->pf3_epv = 0;
-    if (off || a.KH != 3 || a.KW != 3 || nz != 1) return false;
+    if (a.KH != 3 || a.KW != 3 || nz != 1) return false;
     if (a.pad_y[0] != 1 || a.pad_x[0] != 1) return false;
     const int COPT = a.Cout;
     if ((COPT != 64 && COPT != 128) || a.COP < COPT) return false;
@@ -38,7 +37,7 @@ bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *p) {
     if ((a.Ho % TH) || (a.Wo % 32) || a.Ho != a.H || a.Wo != a.W) return false;
     if ((a.stat_mean != nullptr) != (a.stat_rstd != nullptr)) return false;
     // hoisted partial sums ride on the residual loads (kPf3Pre): not together with a residual
-    if (a.pre_add && (a.resid || a.resid_pf || a.res3_w || a.stat_mean || !a.ep_g || dev_env("CDC_NO_PF3_PRE"))) return false;
+    if (a.pre_add && (a.resid || a.resid_pf || a.res3_w || a.stat_mean || !a.ep_g)) return false;
     if (a.resid_pf && (a.resid || a.res3_w || a.rpf_ps * 16 >= (1ll << 31))) return false;
     if (a.res3_w && (!a.res3_x || a.Ho * (long long)a.Wo * 3 >= (1ll << 30))) return false;
     if (a.out_xs != 1 || a.out_ys != a.Wo || a.out_zoff[0] != 0) return false;

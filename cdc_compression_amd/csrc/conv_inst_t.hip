@@ -21,8 +21,7 @@ ws_kernel_fn ws_lookup(int W, int NPB) {
 
 // Cin / C0 / Cout: channels (C0 = those of the first source, Cin when there is one); H x W: the map; B: batch the plan is made for.
 bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *p) {
-    static const bool off = dev_env("CDC_NO_WS") != nullptr;
-    if (off || (W != 8 && W != 16 && W != 32) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
+    if ((W != 8 && W != 16 && W != 32) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
     const int hw = H * W, groups = Cout / 32, nchunk = Cin / 16;
     if (hw % 32) return false;
     const long long min_wgs = dev_env("CDC_WS_MIN_WGS") ? atoll(dev_env("CDC_WS_MIN_WGS")) : 12;
@@ -68,15 +67,15 @@ hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
     a.tiles = p.tiles; a.groups = p.groups;
     a.dbg = 0;
 #ifdef CDC_WS_LAB
-    a.dbg = dev_env("CDC_WS_DBG") ? atoi(dev_env("CDC_WS_DBG")) : 0;
+    a.dbg = getenv("CDC_WS_DBG") ? atoi(getenv("CDC_WS_DBG")) : 0;      // (lab build only)
 #endif
     a.cpw = a.nchunk / p.waves;
     const unsigned grid = (unsigned)(p.tiles * p.groups);
-    a.xcd_remap = (grid % 8 == 0 && grid >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+    a.xcd_remap = (grid % 8 == 0 && grid >= 64) ? 1 : 0;
 #ifdef CDC_WS_LAB
     static unsigned long long *tl = nullptr;
     static int tl_n = 0;
-    if (dev_env("CDC_WS_TL")) {
+    if (getenv("CDC_WS_TL")) {
         if (!tl) (void)hipMalloc((void **)&tl, (size_t)8192 * 16 * 8);
         (void)hipMemsetAsync(tl, 0, (size_t)8192 * 16 * 8, st);
         a.tl = grid <= 8192 ? tl : nullptr;
@@ -106,8 +105,7 @@ hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
 
 // ---- conv_ws1_kernel (conv_ws1_kernel.h): the 1x1 layers of the few-pixel levels --------------------------------------------------
 bool ws1_make_plan(int Cin, int C0, int Cout, int HW, int B, bool per_image_w, Ws1Plan *p) {
-    static const bool off = dev_env("CDC_NO_WS1") != nullptr;
-    if (off || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32 || (HW % 32) || HW < 32) return false;
+    if ((Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32 || (HW % 32) || HW < 32) return false;
     const int groups = Cout / 32, nchunk = Cin / 16;
     const long long blocks = (long long)B * (HW / 32);
     const long long min_wgs = dev_env("CDC_WS1_MIN_WGS") ? atoll(dev_env("CDC_WS1_MIN_WGS")) : 12;

@@ -84,7 +84,7 @@ hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
     }
     a.lin = p.lin;
     dim3 grid((unsigned)(p.lin ? p.tiles_x : p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
-    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
+    a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64) ? 1 : 0;
 #ifdef CDC_TIMELINE
     // Development build only: cycle categories per workgroup (see pf_launch)
     static unsigned long long *tl_dev = nullptr;

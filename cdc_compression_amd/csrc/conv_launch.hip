@@ -50,8 +50,7 @@ static bool try_plan(const ConvShape &s, int MB, int NPW, int lognbw, ConvPlan *
     const int COPT = MB * 32;
     // 16-byte input pieces: tile origins are multiples of 4 columns, so the patch of phase z starts
     // (-pad_x[z]) mod 4 columns after a 16-byte boundary; widen it to start ON the boundary.
-    const bool xvec = s.Win > 0 && (s.Win & 3) == 0 && s.lnmode != 1 && ((NBW * s.stride) & 3) == 0 &&
-                      !dev_env("CDC_NO_XVEC");
+    const bool xvec = s.Win > 0 && (s.Win & 3) == 0 && s.lnmode != 1 && ((NBW * s.stride) & 3) == 0;
     int xshift[4] = {0, 0, 0, 0};
     if (xvec) {
         int mx = 0;
@@ -109,19 +108,8 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     const int ar = s.arith;                          // 1: two fp16 planes (register-staged variant only)
     const int xpl = ar ? 16 : 24;                    // floats of split patch per position
     auto lookup2 = [&](int mb, int npw, int ln, int xu) { return ar ? conv_lookup_split2h(mb, npw, ln, xu) : conv_lookup_split2(mb, npw, ln, xu); };
-    // software-pipelined tap loop (round 4 experiment, off by default): CDC_SPLIT2_PIPE = 0 off, 1 every fp16 shape with more than
-    // one tap, 2 only the variants that keep three waves per SIMD (<= 168 VGPRs)
-    static const int pipe_mode = dev_env("CDC_SPLIT2_PIPE") ? atoi(dev_env("CDC_SPLIT2_PIPE")) : 0;
-    const int xu_of = s.stride == 2 ? 2 : 1;
-    conv_kernel_fn pipe_fn = (ar && s.KH * s.KW > 1 && pipe_mode != 0) ? conv_lookup_split2hp(MB, NPW, s.lnmode, xu_of) : nullptr;
-    // Measured (round 4, tools/gpu_r04_b.sh, per-workgroup cycle timelines): the pipelined loop shortens a workgroup's life by 12 - 33 %,
-    // but where its second operand set costs the third workgroup per CU (> 168 VGPRs) the layer gets SLOWER (256->64 @128^2 0.517 ->
-    // 0.538 ms, transposed 64 ch 0.377 -> 0.450): these kernels are bound by what a CU's resident workgroups overlap, not by
-    // one wave's latency chain.  Mode 2 (the variants that keep three waves per SIMD) changes nothing measurable either (1x7 final
-    // layer 0.383 -> 0.377 ms, 384 -> 384 @8^2 0.0389 -> 0.0401: the one-block tiles are LDS-bandwidth-bound, 5 ds_read_b128 per 3
-    // MFMAs), so the loop stays off by default.
-    bool pipe = pipe_fn != nullptr;
-    if (pipe && pipe_mode == 2 && kernel_vgprs(pipe_fn) > 168) pipe = false;
+    // (a software-pipelined tap loop was measured in round 4 -- a workgroup's life -12 ... -33 %, the layers no faster: the second operand set
+    //  costs the third workgroup per CU, and the one-block tiles are LDS-bandwidth-bound -- and removed: profiles/split2_pipe_ab_r04.txt)
     const int nblocks = ceil_div(s.Cout, 32);
     if (nblocks % MB) return false;
     const int NBW = 1 << lognbw, NBH = 32 >> lognbw;
@@ -131,7 +119,7 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     // small feature maps (one or two 32-pixel row blocks per wave cover the image): pack several images
     // into the workgroup so the weight stages are still shared by four waves
     int ipw = 1;
-    if (allow_ipw && !s.per_image_w && s.Wo <= NBW && WN <= 2 && s.B >= 2 && !dev_env("CDC_NO_IPW")) { ipw = 4 / WN; WN = 4; }
+    if (allow_ipw && !s.per_image_w && s.Wo <= NBW && WN <= 2 && s.B >= 2) { ipw = 4 / WN; WN = 4; }
     const int wpi = WN / ipw;
     const int nthr = 64 * WN;
     const int TH = wpi * NPW * NBH;
@@ -149,8 +137,8 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     if (lds2 > 80 * 1024) { tg = 1; lds2 = lds_tap; }
     // a third workgroup per CU (+12 % measured on 64->64 @256^2) when single-tap stages bring the LDS
     // footprint under 160/3 KiB and the kernel's registers allow three waves per SIMD
-    if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024 && !dev_env("CDC_NO_TG1"))
-        if (conv_kernel_fn f = pipe ? pipe_fn : lookup2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
+    if (tg > 1 && lds_tap <= 53 * 1024 && lds2 > 53 * 1024)
+        if (conv_kernel_fn f = lookup2(MB, NPW, s.lnmode, s.stride == 2 ? 2 : 1))
             if (kernel_vgprs(f) <= 168) { tg = 1; lds2 = lds_tap; }
     // Few workgroups (low-resolution levels): the chip cannot hide the weight-stage latency by occupancy,
     // so stage ALL taps of a chunk at once -- one barrier and one DMA wait per 16 channels, and the DMA of
@@ -160,14 +148,13 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
         const long long wgs = (long long)(ipw > 1 ? ceil_div(s.B, ipw) : ceil_div(s.Wo, NBW) * ceil_div(s.Ho, TH) * s.B) *
                               (nblocks / MB) * s.nz;
         const size_t lds_all = sizeof(float) * ((size_t)ipw * xpl * plane + (size_t)2 * taps * 24 * COPT);
-        static const char *force = dev_env("CDC_TGALL");
         const bool few = wgs <= 3 * 256 && lds_all <= 72 * 1024;
-        if (taps > tg && ((force && atoi(force) && lds_all <= 150 * 1024) || (!force && few))) { tg = taps; lds2 = lds_all; }
+        if (taps > tg && few) { tg = taps; lds2 = lds_all; }
     }
     // patch units per thread: stride 2 always runs the two-unit / parity-plane variant
     const int xu = s.stride == 2 ? 2 : 1;
     const bool v2 = plane / 2 <= xu * wpi * 64 && s.stride <= 2 && lookup2(MB, NPW, s.lnmode, xu) && lds2 <= 150 * 1024 &&
-                    (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1 && !dev_env("CDC_NO_XU2_SMALL"))) && !dev_env("CDC_NO_XU2"))) && !dev_env("CDC_NO_SPLIT2");
+                    (xu == 1 || ((s.Ho * s.Wo >= 256 || (s.max_ksplit > 1)))) && !dev_env("CDC_NO_SPLIT2");
     if (!v2 && ipw > 1) return try_plan_split(s, MB, NPW, lognbw, p, false);
     if (!v2 && s.per_image_w) return false;          // only the register-staged variant takes per-image planes
     if (!v2 && ar) { ConvShape s0 = s; s0.arith = 0; return try_plan_split(s0, MB, NPW, lognbw, p, allow_ipw); }
@@ -191,7 +178,6 @@ static bool try_plan_split(const ConvShape &s, int MB, int NPW, int lognbw, Conv
     p->ipw = ipw;
     p->xu = v2 ? xu : 1;
     p->arith = v2 ? ar : 0;
-    p->pipe = (v2 && ar && pipe) ? 1 : 0;
     return true;
 }
 
@@ -212,10 +198,6 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     ConvPlan best;
     double best_score = -1;
     // tuning aid: CDC_PLAN="MB,NPW,KC" (0 = free) restricts the candidates
-    int f_mb = 0, f_npw = 0, f_kc = 0;
-    if (const char *e = dev_env("CDC_PLAN")) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
-    // the same for the few-pixel levels only: CDC_PLAN8 (8 x 8 outputs), CDC_PLAN16 (16 x 16)
-    if (const char *e = dev_env(s.Ho * s.Wo <= 64 ? "CDC_PLAN8" : (s.Ho * s.Wo <= 256 ? "CDC_PLAN16" : "CDC_PLAN_NONE"))) sscanf(e, "%d,%d,%d", &f_mb, &f_npw, &f_kc);
     // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
     // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
     const bool split_ok = s.allow_split && (s.lnmode == 0 || s.lnmode == 1 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
@@ -224,12 +206,9 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
                           !dev_env("CDC_NO_SPLIT");
     if (split_ok) {
         for (int MB : mbs) {
-            if (f_mb && !s.need_all_cout && MB != f_mb) continue;
             for (int NPW : {4, 2, 1}) {
                 if (MB * NPW > 8 || MB > 8) continue;
                 if (NPW > 1 && NPW > nb_rows) continue;
-                if (f_npw && NPW != f_npw) continue;
-                if (s.KH == 7 && s.KW == 1 && dev_env("CDC_71_NPW") && NPW != atoi(dev_env("CDC_71_NPW"))) continue;
                 ConvPlan p;
                 p.split = 0;
                 if (!try_plan_split(s, MB, NPW, lognbw, &p)) continue;
@@ -249,14 +228,12 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
         if (best_score >= 0) { *plan = best; return true; }
     }
     for (int MB : mbs) {
-        if (f_mb && !s.need_all_cout && MB != f_mb) continue;
         for (int NPW : {4, 2, 1}) {
             if (MB * NPW > 12) continue;
             if (NPW > 1 && NPW > nb_rows) continue;
-            if (f_npw && NPW != f_npw) continue;
             ConvPlan p;
             p.split = 0;
-            if (!try_plan(s, MB, NPW, lognbw, &p, f_kc)) continue;
+            if (!try_plan(s, MB, NPW, lognbw, &p)) continue;
             // measured (tools/gpu_conv_tune.py): register blocking matters more than the chunk depth
             // (MB2/NPW4/KC4 99 TF vs MB2/NPW2/KC8 91 TF; MB4/NPW2/KC4 103 TF vs KC8 with one WG/CU 91 TF)
             const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups;
@@ -290,17 +267,10 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     const int xv = p.xvec ? 4 : 1;
     a.magic_hw = magic_of((unsigned)(p.PH * p.PW / xv));
     a.magic_w = magic_of((unsigned)(p.PW / xv));
-    conv_kernel_fn fn = p.split == 2 ? (p.arith ? (p.pipe ? conv_lookup_split2hp(p.MB, p.NPW, p.lnmode, p.xu) : conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu))
+    conv_kernel_fn fn = p.split == 2 ? (p.arith ? conv_lookup_split2h(p.MB, p.NPW, p.lnmode, p.xu)
                                                 : conv_lookup_split2(p.MB, p.NPW, p.lnmode, p.xu))
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
-#ifdef CDC_WITH_ABLATIONS      // tuning build only (make ABL=1): compile-time ablated kernels, wrong results
-    static const int ablate = dev_env("CDC_ABLATE") ? atoi(dev_env("CDC_ABLATE")) : 0;
-    if (ablate && p.split == 1)
-        if (conv_kernel_fn f2 = conv_lookup_split_abl(p.MB, p.NPW, ablate)) fn = f2;
-    if (ablate && p.lnmode == 0 && !p.split)
-        if (conv_kernel_fn f2 = conv_lookup_abl(p.MB, p.NPW, ablate)) fn = f2;
-#endif
-    if (a.uf_c) fn = (p.split == 2 && p.arith && !p.pipe && p.xu == 1 && p.lnmode == 0) ? conv_lookup_split2hu(p.MB, p.NPW) : nullptr;
+    if (a.uf_c) fn = (p.split == 2 && p.arith && p.xu == 1 && p.lnmode == 0) ? conv_lookup_split2hu(p.MB, p.NPW) : nullptr;
     if (!fn) return hipErrorInvalidValue;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)fn,
@@ -311,8 +281,8 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
               (unsigned)(nz * a.ksplit));
     a.zfold = 0;
-    a.xcd_remap = (p.split != 1 && p.ipw == 1 && grid.x % 8 == 0 && grid.x >= 64 && !dev_env("CDC_NO_XCD")) ? 1 : 0;
-    if (p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0 && !dev_env("CDC_NO_ZFOLD")) {
+    a.xcd_remap = (p.split != 1 && p.ipw == 1 && grid.x % 8 == 0 && grid.x >= 64) ? 1 : 0;
+    if (p.split == 2 && nz == 4 && a.ksplit == 1 && p.ipw == 1 && grid.x % 8 == 0) {
         a.zfold = 1; grid.x *= 4; grid.z = 1;
     }
     dim3 block(64 * p.WN);

@@ -387,17 +387,15 @@ def test_linear_attention_matches_oracle(O, G, case):
     assert relerr(got, ref) < 5e-6, relerr(got, ref)
 
 
-@pytest.mark.parametrize("case,env", [((2, 64, 64, 64), {"CDC_KVCTX16": "0"}), ((2, 64, 64, 64), {"CDC_KVCTX16": "2"}),
-                                      ((1, 128, 64, 64), {"CDC_KVCTX16": "0"}), ((1, 128, 64, 64), {"CDC_KVCTX16": "1"}),
-                                      ((2, 128, 16, 16), {"CDC_NO_CTXQ_SPLIT": "1"}), ((2, 128, 16, 16), {"CDC_CTXP_F32": "1"}),
-                                      ((1, 192, 32, 32), {}), ((1, 192, 32, 32), {"CDC_CTXP_F32": "1", "CDC_NO_CTXQ_SPLIT": "1"}),
-                                      ((2, 64, 64, 64), {"CDC_ARITH": "0"}),
+@pytest.mark.parametrize("case,env", [((2, 128, 16, 16), {"CDC_NO_CTXQ_SPLIT": "1"}),
+                                      ((1, 192, 32, 32), {}), ((1, 192, 32, 32), {"CDC_NO_CTXQ_SPLIT": "1"}),
+                                      ((2, 64, 64, 64), {"CDC_ARITH": "0"}), ((1, 128, 64, 64), {"CDC_ARITH": "0"}),    # bf16x3: kvctx_kernel, f32 partial context
                                       # few-pixel levels: row maxima + context + reduction in ONE launch (default) / the three-launch chain
                                       ((2, 128, 16, 16), {"CDC_NO_CTX_ONE": "1"}), ((1, 384, 8, 8), {"CDC_NO_CTX_ONE": "1"}), ((3, 320, 16, 16), {}),
-                                      ((3, 320, 16, 16), {"CDC_CTXP_F32": "1"}), ((2, 256, 32, 32), {}), ((2, 320, 8, 8), {})])
+                                      ((3, 320, 16, 16), {"CDC_ARITH": "0"}), ((2, 256, 32, 32), {}), ((2, 320, 8, 8), {})])
 def test_linear_attention_alternate_kernels(O, case, env, monkeypatch):
-    """The non-default attention kernels (older fused front half, plane-form v tile on / off, f32-MFMA partial context,
-    register-staged ctx^T q product, bf16x3 arithmetic) against the same oracle."""
+    """The non-default attention kernels (register-staged ctx^T q product, the three-launch context chain, and the bf16x3 arithmetic
+    with its own fused front half and f32-MFMA partial context) against the same oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     from cdc_compression_amd.ops import Ops
