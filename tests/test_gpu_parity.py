@@ -466,10 +466,10 @@ def test_unet_forward_alternate_kernel_modes(name, env, monkeypatch):
 
 def test_plane_operand_forms_agree_with_the_register_staged_program_on_ragged_frames():
     """Round-4 forms of conv_pf_kernel (stride 2, fused transposed phases, first / final layer, planes-only tensors, residual from
-    planes) against the same network with all of them switched off, on frame sizes whose tiles are ragged in both directions (separate
+    planes) and the round-5 few-pixel kernels against the same network with all of them switched off, on frame sizes whose tiles are ragged in both directions (separate
     processes: some of the switches are read once)."""
     import subprocess, sys
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "..", "tools", "gpu_new_paths_ab.py"), "4x160x224", "3x320x192"],
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "ab_forward.py"), "4x160x224", "3x320x192"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
 
