@@ -530,12 +530,12 @@ struct Builder {
         return true;
     }
 
-    // 1x1 layer of a few-pixel level (maps narrower than 32 pixels) on conv_ws1_kernel (conv_ws1_kernel.h): all of K inside the
+    // 1x1 layer of a few-pixel launch (at most 128 pixel blocks, or per-image weights) on conv_ws1_kernel (conv_ws1_kernel.h): all of K inside the
     // workgroup -- no partial-sum tensors, no sum pass.  Epilogue: bias, folded PreNorm (mean on load, rstd after), per-image shift,
     // residual; shared or per-image weight planes.
     bool try_ws1(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W, float *out, long long out_bs,
                  const ConvOpts &o, bool need_all, int prof) {
-        if (rc || h->arith != 1 || !w.wsh || planB > 0 || W >= 32 || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
+        if (rc || h->arith != 1 || !w.wsh || planB > 0 || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0) return false;
         if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || o.pre_add || o.relu || o.resid1 || o.uf_c) return false;
         if (o.pre_mean && o.pre_mode != 2) return false;
@@ -546,7 +546,7 @@ struct Builder {
         // per-image attention products everywhere); at 16x16 and batch 32 the wide folded-PreNorm projections (24 - 36 channel groups, each
         // converting the same activations again) and the res_convs are faster on conv_pw_kernel's 64 - 96-channel workgroups.
         const long long blocks = (long long)pb() * (H * W / 32);
-        if (blocks > 128 && !o.wsp_bs) return false;
+        if (blocks > 128 && !(o.wsp_bs && W < 32)) return false;     // (per-image products of the few-pixel levels at any batch)
         Op op;
         op.kind = Op::CONVWS1; op.prof = prof;
         if (!ws1_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H * W, pb(), o.wsp_bs != 0, &op.ws1plan)) return false;

@@ -14,6 +14,7 @@ ws_kernel_fn ws_lookup(int W, int NPB) {
         case 8: return NPB == 4 ? conv_ws_kernel<8, 4> : conv_ws_kernel<8, 2>;
         case 16: return NPB == 4 ? conv_ws_kernel<16, 4> : conv_ws_kernel<16, 2>;
         case 32: return NPB == 4 ? conv_ws_kernel<32, 4> : conv_ws_kernel<32, 2>;
+        case 64: return NPB == 4 ? conv_ws_kernel<64, 4> : conv_ws_kernel<64, 2>;
     }
     return nullptr;
 }
@@ -21,13 +22,14 @@ ws_kernel_fn ws_lookup(int W, int NPB) {
 
 // Cin / C0 / Cout: channels (C0 = those of the first source, Cin when there is one); H x W: the map; B: batch the plan is made for.
 bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *p) {
-    if ((W != 8 && W != 16 && W != 32) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
+    if ((W != 8 && W != 16 && W != 32 && W != 64) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
     const int hw = H * W, groups = Cout / 32, nchunk = Cin / 16;
     if (hw % 32) return false;
     const long long min_wgs = dev_env("CDC_WS_MIN_WGS") ? atoll(dev_env("CDC_WS_MIN_WGS")) : 12;
     const int force_npb = dev_env("CDC_WS_NPB") ? atoi(dev_env("CDC_WS_NPB")) : 0;
     for (int npb : {4, 2}) {
         if (force_npb && npb != force_npb) continue;
+        if (npb == 4 && W > 16 && !force_npb) continue;        // (the wider maps' loader holds more values in flight: 128-pixel tiles spill there)
         const int tpx = npb * 32;
         // a tile = whole images (each a multiple of a loader pass of 64 pixels), or an image in equal bands of rows
         if (tpx >= hw ? ((tpx % hw) || (hw % 64)) : ((hw % tpx) || (tpx % W))) continue;
@@ -55,10 +57,10 @@ bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *p) {
 hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
     ws_kernel_fn fn = ws_lookup(p.W, p.NPB);
     if (!fn) return hipErrorInvalidValue;
-    static bool attr_done[16][3][2] = {};                  // [device][width][NPB == 4]
+    static bool attr_done[16][4][2] = {};                  // [device][width][NPB == 4]
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const int wi = p.W == 8 ? 0 : (p.W == 16 ? 1 : 2);
+    const int wi = p.W == 8 ? 0 : (p.W == 16 ? 1 : (p.W == 32 ? 2 : 3));
     if (dev < 0 || dev >= 16 || !attr_done[dev][wi][p.NPB == 4]) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

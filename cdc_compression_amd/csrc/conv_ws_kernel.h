@@ -1,5 +1,5 @@
-// conv_ws_kernel.h -- 3x3 / stride-1 / pad-1 convolutions of the FEW-PIXEL levels (maps 8, 16 or 32 pixels wide: the <= 16^2 trunk of
-// the U-Net, 256 - 768 input channels), weight-stationary in registers (round 5).
+// conv_ws_kernel.h -- 3x3 / stride-1 / pad-1 convolutions of the FEW-PIXEL levels (maps 8 ... 64 pixels wide: the <= 16^2 trunk of
+// the U-Net at batch 32, everything below 128^2 for one image per call; 128 - 768 input channels), weight-stationary in registers (round 5).
 //
 // What bounded these layers on conv_split2_kernel: 2 048 - 8 192 pixels per batch leave a launch < 3 workgroups per CU,
 // so K was sliced over workgroups (4 partial-sum tensors + a LayerNorm pass that adds them), and a 32 x 32 wave tile fetches one
@@ -63,7 +63,7 @@ __host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves)
 
 template <int W_, int NPB>
 __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
-    static_assert(W_ == 8 || W_ == 16 || W_ == 32, "map width");
+    static_assert(W_ == 8 || W_ == 16 || W_ == 32 || W_ == 64, "map width");
     static_assert(NPB % 2 == 0, "pixel blocks are multiplied in pairs");
     WS_STAMP(0);
     // (the fields the kernel uses, as locals: the lambdas below capture THESE -- capturing the argument block itself made hipcc copy it to scratch)

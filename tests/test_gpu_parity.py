@@ -169,6 +169,7 @@ WS_CASES = [
     (1, 64, 32, 32, 96, 3, 1, 1, True),     # 32 wide: 4-row bands; 4 chunks over 4 waves; 3 channel groups
     (2, 48, 8, 8, 32, 3, 1, 1, True),       # 3 chunks over 3 waves, fewer waves than pixel blocks
     (4, 64, 16, 8, 64, 3, 1, 1, True),      # non-square map, 8 wide: 128 pixels per image
+    (1, 128, 8, 64, 192, 3, 1, 1, True),    # 64 wide (one image per call at the 64 x 64 level): a tile = one or two rows
 ]
 
 
@@ -200,6 +201,7 @@ def test_conv2d_weight_stationary_kernel(O, case, npb, monkeypatch):
 WS1_CASES = [
     # 1x1 layers of the few-pixel levels on conv_ws1_kernel (all of K inside the workgroup; 32-pixel blocks of the flattened batch)
     (2, 384, 8, 8, 384), (4, 320, 8, 8, 960), (1, 256, 16, 16, 768), (3, 640, 16, 16, 256), (2, 48, 8, 8, 32), (1, 64, 4, 24, 96),
+    (1, 192, 32, 32, 576), (1, 128, 16, 64, 128),          # wider maps, small launches (one image per call)
 ]
 
 
