@@ -65,9 +65,9 @@ bool pf3_make_plan(const PfArgs &a, int B, int nz, PfPlan *plan);
 hipError_t pf3_launch(PfArgs a, const PfPlan &plan, int B, hipStream_t st);
 int device_cus();                 // CUs of the current device (256 when unknown)
 // weight-stationary 3x3 convolution of the few-pixel levels (conv_ws_kernel.h, conv_inst_t.hip)
-struct WsPlan { int W, NPB, waves, tiles, groups; size_t lds_bytes; };
+struct WsPlan { int W, NPB, stride, waves, tiles, groups; size_t lds_bytes; };
 struct WsArgs;
-bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *plan);
+bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, int stride, WsPlan *plan);     // (H, W: the OUTPUT map)
 hipError_t ws_launch(WsArgs a, const WsPlan &plan, hipStream_t st);
 // ... and its pointwise sibling (conv_ws1_kernel.h)
 struct Ws1Plan { int NPB, waves, tiles, groups; size_t lds_bytes; };

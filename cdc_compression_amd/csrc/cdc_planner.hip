@@ -38,8 +38,8 @@ struct Builder {
                      op.pfplan.groups, op.pfplan.ring, op.pw ? (op.pf.pre_mean ? "PW pre" : "PW") : (op.pfplan.pf3_epv ? (op.pf.ep_g ? "PF3 LN" : "PF3") : (op.pf.ep_g ? "PF LN" : "PF")), op.pf.out ? "" : " nof32", op.pf.out_pf ? " +pf" : "",
                      op.pf.resid ? " +res" : (op.pf.resid_pf ? " +resP" : ""), cur == &h->pre_ops ? " HOIST" : "", op.pf.tz == 4 ? " TZ4" : "");
         else if (op.kind == Op::CONVWS)
-            snprintf(buf, sizeof buf, "conv 3x3 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS%s", op.ws.Cin, op.ws.Cout, op.ws.H, op.wsplan.W,
-                     op.wsplan.NPB, op.wsplan.waves, op.wsplan.tiles, op.wsplan.groups, "");
+            snprintf(buf, sizeof buf, "conv 3x3 s%d %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS%s", op.wsplan.stride, op.ws.Cin, op.ws.Cout, op.ws.H, op.wsplan.W,
+                     op.wsplan.NPB, op.wsplan.waves, op.wsplan.tiles, op.wsplan.groups, op.ws.pre_add ? " pre_add" : "");
         else if (op.kind == Op::CONVWS1)
             snprintf(buf, sizeof buf, "conv 1x1 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS1%s%s%s", op.ws1.Cin, op.ws1.Cout, ws1_h, op.ws1.HW / std::max(ws1_h, 1),
                      op.ws1plan.NPB, op.ws1plan.waves, op.ws1plan.tiles, op.ws1plan.groups, op.ws1.pre_mean ? " pre" : "", op.ws1.w_bs ? " perimg" : "",
@@ -496,33 +496,38 @@ struct Builder {
 
     // 3x3 / stride-1 / pad-1 layer of a few-pixel level on conv_ws_kernel (conv_ws_kernel.h): the RAW result (bias added, no LayerNorm)
     // goes to `raw`; a Block's LayerNorm / ReLU / shift / residual is the in-place pass its caller emits behind it.
+    // (H, W: the INPUT map; the stride-2 form is the Downsample, 3x3 / pad 1 on even extents)
     bool ws_would_plan(const ConvW &w, int C0, bool two_src, int H, int W) {
-        if (h->arith != 1 || !w.wsh || planB > 0 || w.KH != 3 || w.KW != 3 || w.stride != 1 || w.transposed || w.nz != 1) return false;
+        if (h->arith != 1 || !w.wsh || planB > 0 || w.KH != 3 || w.KW != 3 || (w.stride != 1 && w.stride != 2) || w.transposed || w.nz != 1) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 1 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 1) return false;
         if (w.COP != w.Cout || w.Cin_pad != w.Cin) return false;
+        if (w.stride == 2 && ((H & 1) || (W & 1) || two_src)) return false;
         WsPlan plan;
-        return ws_make_plan(w.Cin, two_src ? C0 : w.Cin, w.Cout, H, W, pb(), &plan);
+        return ws_make_plan(w.Cin, two_src ? C0 : w.Cin, w.Cout, H / w.stride, W / w.stride, pb(), w.stride, &plan);
     }
     bool try_ws(const ConvW &w, const float *s0, int C0, long long bs0, const float *s1, long long bs1, int H, int W, float *raw,
-                long long raw_bs, int prof) {
+                long long raw_bs, int prof, const float *pre_add = nullptr) {
         if (rc || !ws_would_plan(w, C0, s1 != nullptr, H, W)) return false;
         if (!ensure_f32(s0, bs0) || (s1 && !ensure_f32(s1, bs1))) return false;
+        const int Ho = H / w.stride, Wo = W / w.stride;
+        if (raw_bs != (long long)w.Cout * Ho * Wo) return false;
         Op op;
         op.kind = Op::CONVWS; op.prof = prof;
-        if (!ws_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H, W, pb(), &op.wsplan)) return false;
+        if (!ws_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, Ho, Wo, pb(), w.stride, &op.wsplan)) return false;
         WsArgs &a = op.ws;
         memset(&a, 0, sizeof a);
         a.x0 = s0; a.x0_bs = bs0; a.x1 = s1; a.x1_bs = bs1;
-        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = H; a.B = B;
+        a.C0 = s1 ? C0 : w.Cin; a.Cin = w.Cin; a.H = Ho; a.B = B;
         a.w = w.wsh; a.nchunk = w.Cin / 16; a.COP = w.COP; a.Cout = w.Cout; a.acc_scale = w.wscale_inv;
-        a.bias = w.bias;
+        a.bias = pre_add ? nullptr : w.bias;            // (a hoisted partial sum already carries the bias)
+        a.pre_add = pre_add;
         a.out = raw; a.out_bs = raw_bs;
         a.fault = fault_flag();
-        const double px = (double)B * H * W;
+        const double px = (double)B * Ho * Wo;
         op.flops = 2.0 * px * w.Cout * w.Cin * 9;
-        op.bytes = 4.0 * px * (w.Cin + w.Cout);
+        op.bytes = 4.0 * ((double)B * H * W * w.Cin + px * w.Cout);
         if (getenv("CDC_DEBUG_PLAN"))
-            fprintf(stderr, "[plan] conv 3x3 %d->%d out %dx%d on conv_ws_kernel: %d tiles of %d pixels x %d groups, %d waves, %zu bytes of LDS\n", w.Cin, w.Cout, H, W,
+            fprintf(stderr, "[plan] conv 3x3 s%d %d->%d out %dx%d on conv_ws_kernel: %d tiles of %d pixels x %d groups, %d waves, %zu bytes of LDS\n", w.stride, w.Cin, w.Cout, Ho, Wo,
                     op.wsplan.tiles, op.wsplan.NPB * 32, op.wsplan.groups, op.wsplan.waves, op.wsplan.lds_bytes);
         last_ksplit = 1;
         last_pf_only = false;
@@ -617,6 +622,10 @@ struct Builder {
                     return true;
                 }
         }
+        // Downsample of a few-pixel level at small batch: all of K inside the workgroup (no split-K, no sum pass)
+        if (w.stride == 2 && !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w && !o.resid && !o.pre_mean &&
+            !o.w_bs && !o.uf_c && !(o.emit_pf && twin(out)) && try_ws(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, prof))
+            return true;
         if (!o.uf_c && try_ws1(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof)) return true;
         if (!o.uf_c && try_pw(w, s0, C0, bs0, s1, bs1, H, W, out, out_bs, o, need_all, prof, s)) return true;
         const bool linear_ep = !need_all && !o.ln_g && !o.relu && !o.shift && !o.stat_mean && !o.pre_add && !o.res3_w &&
@@ -811,8 +820,8 @@ struct Builder {
             if (conv(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), op, true, prof)) return true;
         }
         // few-pixel levels: the weight-stationary kernel (all of K in one workgroup, no partial-sum tensors) + an in-place LayerNorm pass
-        if (!pre_add && !want_res3 && !uf_c && !resid1 && out.bs() == (long long)w.Cout * H * W &&
-            try_ws(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), prof)) {
+        if (!want_res3 && !uf_c && !resid1 && w.stride == 1 && out.bs() == (long long)w.Cout * H * W &&
+            try_ws(w, s0, C0, bs0, s1, bs1, H, W, out.p, out.bs(), prof, pre_add)) {
             ln(out.p, out.p, w.Cout, H * W, g, b, 1, shift, resid, sm, sr);
             return true;
         }
@@ -1438,9 +1447,9 @@ static int op_conv2d_impl(cdc_handle *h, const float *x, const float *w, const f
     const long long obs = (long long)Cout * Ho * Wo;
     const int prof = KH == 7 ? PC_CONV7 : (KH == 1 ? PC_CONV1 : PC_CONV3);
     // few-pixel maps: the weight-stationary kernel (its raw result + the in-place LayerNorm pass; a bias-only call is the raw result)
-    if (dg && relu && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, prof)) {
+    if (dg && relu && stride == 1 && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, prof)) {
         bd.ln(dy, dy, Cout, Ho * Wo, dg, db, relu, ds, dr, nullptr, nullptr);
-    } else if (!dg && !relu && !ds && !dr && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, prof)) {
+    } else if (!dg && !relu && !ds && !dr && stride == 1 && bd.try_ws(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, prof)) {
     } else if (dg) {
         if (!bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, o, true, prof)) {
             bd.conv(cw, dx, Cin, (long long)Cin * H * W, nullptr, 0, H, W, dy, obs, Builder::ConvOpts(),

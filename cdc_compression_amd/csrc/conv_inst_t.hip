@@ -9,7 +9,16 @@ namespace cdc {
 namespace {
 // pixel blocks per workgroup: 4 (128 pixels: a kernel row's weight registers feed 4 x 9 MFMAs) wherever that fills the chip,
 // 2 (64 pixels) for the small batches
-ws_kernel_fn ws_lookup(int W, int NPB) {
+ws_kernel_fn ws_lookup(int W, int NPB, int stride) {
+    if (stride == 2) {                         // Downsample onto an 8 / 16 / 32-wide map, 64-pixel tiles
+        if (NPB != 2) return nullptr;
+        switch (W) {
+            case 8: return conv_ws_kernel<8, 2, 2>;
+            case 16: return conv_ws_kernel<16, 2, 2>;
+            case 32: return conv_ws_kernel<32, 2, 2>;
+        }
+        return nullptr;
+    }
     switch (W) {
         case 8: return NPB == 4 ? conv_ws_kernel<8, 4> : conv_ws_kernel<8, 2>;
         case 16: return NPB == 4 ? conv_ws_kernel<16, 4> : conv_ws_kernel<16, 2>;
@@ -21,15 +30,16 @@ ws_kernel_fn ws_lookup(int W, int NPB) {
 }  // namespace
 
 // Cin / C0 / Cout: channels (C0 = those of the first source, Cin when there is one); H x W: the map; B: batch the plan is made for.
-bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *p) {
+bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, int stride, WsPlan *p) {
     if ((W != 8 && W != 16 && W != 32 && W != 64) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
     const int hw = H * W, groups = Cout / 32, nchunk = Cin / 16;
     if (hw % 32) return false;
-    const long long min_wgs = dev_env("CDC_WS_MIN_WGS") ? atoll(dev_env("CDC_WS_MIN_WGS")) : 12;
+    if (stride != 1 && (stride != 2 || W > 32)) return false;
+    const long long min_wgs = dev_env("CDC_WS_MIN_WGS") ? atoll(dev_env("CDC_WS_MIN_WGS")) : 4;
     const int force_npb = dev_env("CDC_WS_NPB") ? atoi(dev_env("CDC_WS_NPB")) : 0;
     for (int npb : {4, 2}) {
         if (force_npb && npb != force_npb) continue;
-        if (npb == 4 && W > 16 && !force_npb) continue;        // (the wider maps' loader holds more values in flight: 128-pixel tiles spill there)
+        if (npb == 4 && (stride == 2 || (W > 16 && !force_npb))) continue;        // (the wider maps' loader holds more values in flight: 128-pixel tiles spill there)
         const int tpx = npb * 32;
         // a tile = whole images (each a multiple of a loader pass of 64 pixels), or an image in equal bands of rows
         if (tpx >= hw ? ((tpx % hw) || (hw % 64)) : ((hw % tpx) || (tpx % W))) continue;
@@ -40,31 +50,31 @@ bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, WsPlan *p) {
         // 128-pixel tiles only where they leave at most a quarter of the chip idle; 64-pixel tiles below that
         if (npb == 4 && !force_npb && wgs < (3 * device_cus()) / 4) continue;
         if (wgs < min_wgs) return false;
+        if (stride == 2 && wgs > device_cus() && !dev_env("CDC_WS_MIN_WGS")) return false;     // (its one-workgroup-per-CU launches pay as a single round only)
         // K slices over the waves of the workgroup: up to 8 waves (two per SIMD: the kernel holds ~250 registers), equal shares;
         // two workgroups per CU when the launch has more than two per CU (LDS and registers then want <= 4 waves each)
         int waves = 0;
-        for (int w = (wgs > 2 * device_cus() ? 4 : 8); w >= 2; --w)
-            if (nchunk % w == 0) { waves = w; break; }
+        for (int w = ((wgs > 2 * device_cus() || stride == 2) ? 4 : 8); w >= 2; --w)
+            if (nchunk % w == 0 && ws_lds_bytes(W, H, npb, w, stride) <= 160 * 1024) { waves = w; break; }
         if (!waves) continue;
-        const size_t lds = ws_lds_bytes(W, H, npb, waves);
-        if (lds > 160 * 1024) continue;
-        p->W = W; p->NPB = npb; p->waves = waves; p->tiles = tiles; p->groups = groups; p->lds_bytes = lds;
+        const size_t lds = ws_lds_bytes(W, H, npb, waves, stride);
+        p->W = W; p->NPB = npb; p->stride = stride; p->waves = waves; p->tiles = tiles; p->groups = groups; p->lds_bytes = lds;
         return true;
     }
     return false;
 }
 
 hipError_t ws_launch(WsArgs a, const WsPlan &p, hipStream_t st) {
-    ws_kernel_fn fn = ws_lookup(p.W, p.NPB);
+    ws_kernel_fn fn = ws_lookup(p.W, p.NPB, p.stride);
     if (!fn) return hipErrorInvalidValue;
-    static bool attr_done[16][4][2] = {};                  // [device][width][NPB == 4]
+    static bool attr_done[16][4][2][2] = {};               // [device][width][NPB == 4][stride == 2]
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int wi = p.W == 8 ? 0 : (p.W == 16 ? 1 : (p.W == 32 ? 2 : 3));
-    if (dev < 0 || dev >= 16 || !attr_done[dev][wi][p.NPB == 4]) {
+    if (dev < 0 || dev >= 16 || !attr_done[dev][wi][p.NPB == 4][p.stride == 2]) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 16) attr_done[dev][wi][p.NPB == 4] = true;
+        if (dev >= 0 && dev < 16) attr_done[dev][wi][p.NPB == 4][p.stride == 2] = true;
     }
     a.tiles = p.tiles; a.groups = p.groups;
     a.dbg = 0;

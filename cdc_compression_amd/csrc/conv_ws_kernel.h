@@ -28,12 +28,13 @@ struct WsArgs {
     const float *x0, *x1;           // fp32 NCHW sources (channel concatenation; x1 may be null)
     long long x0_bs, x1_bs;         // batch strides in floats
     int C0, Cin;                    // channels taken from x0; total (both multiples of 16)
-    int H, B;                       // rows of the map (its width is the template parameter), batch
+    int H, B;                       // rows of the OUTPUT map (its width is the template parameter; the input is stride times as large), batch
     const void *w;                  // fp16 planes {WH, WL, WH2} of w 2^s: [tap][Cin/16][3][2][COP] 16-byte units
     int nchunk, cpw;                // 16-channel chunks; chunks per wave (nchunk = cpw * waves)
     int COP, Cout;
     float acc_scale;                // 2^-s
     const float *bias;              // [Cout] or null
+    const float *pre_add;           // hoisted partial sums (the step-invariant context half of a concatenated input), layout of `out`, or null
     float *out;                     // raw result, fp32 NCHW
     long long out_bs;
     int tiles, groups;              // pixel tiles; 32-channel groups of Cout (gridDim.x = tiles * groups)
@@ -46,12 +47,13 @@ struct WsArgs {
 };
 
 // LDS bytes of a launch: the waves' patches during the K loop, the partial accumulators after it
-__host__ __device__ inline int ws_ppix(int W, int H, int NPB) {
+// (W, H: the output map; stride 1 or 2)
+__host__ __device__ inline int ws_ppix(int W, int H, int NPB, int stride = 1) {
     const int tpx = NPB * 32, hw = H * W;
-    return (tpx >= hw ? tpx / hw : 1) * ((tpx >= hw ? H : tpx / W) + 2) * (W + 2);
+    return (tpx >= hw ? tpx / hw : 1) * ((tpx >= hw ? H : tpx / W) * stride + 2) * (W * stride + 2);
 }
-__host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves) {
-    const size_t patches = (size_t)waves * 4 * ws_ppix(W, H, NPB) * 16, red = (size_t)waves * NPB * 4096;
+__host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves, int stride = 1) {
+    const size_t patches = (size_t)waves * 4 * ws_ppix(W, H, NPB, stride) * 16, red = (size_t)waves * NPB * 4096;
     return patches > red ? patches : red;
 }
 
@@ -61,10 +63,12 @@ __host__ __device__ inline size_t ws_lds_bytes(int W, int H, int NPB, int waves)
 #define WS_STAMP(i) do { } while (0)
 #endif
 
-template <int W_, int NPB>
-__global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
+// (stride 2: at most four waves per workgroup -- one per SIMD, the whole register file: its loader keeps 9 passes of input values in flight)
+template <int W_, int NPB, int STR = 1>
+__global__ void __launch_bounds__(STR == 2 ? 256 : 512) conv_ws_kernel(const WsArgs PA) {
     static_assert(W_ == 8 || W_ == 16 || W_ == 32 || W_ == 64, "map width");
     static_assert(NPB % 2 == 0, "pixel blocks are multiplied in pairs");
+    static_assert(STR == 1 || STR == 2, "stride");
     WS_STAMP(0);
     // (the fields the kernel uses, as locals: the lambdas below capture THESE -- capturing the argument block itself made hipcc copy it to scratch)
     const auto a_x0 = PA.x0;
@@ -79,35 +83,40 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     const auto a_COP = PA.COP;
     const auto a_acc_scale = PA.acc_scale;
     const auto a_bias = PA.bias;
+    const auto a_pre_add = PA.pre_add;
     const auto a_out = PA.out;
     const auto a_out_bs = PA.out_bs;
     const auto a_tiles = PA.tiles;
     const auto a_xcd_remap = PA.xcd_remap;
     const auto a_fault = PA.fault;
     const int a_dbg = PA.dbg;
-    constexpr int PW = W_ + 2, TPX = NPB * 32;
-    constexpr int MAXLOAD = TPX + 2 * W_;                       // most pixels a tile loads (a band of rows + its two neighbour rows)
+    // W_ / a_H: the OUTPUT map; the input is WI wide (STR = 2: Downsample, 3x3 / stride 2 / pad 1 -- a tile of R output rows reads input rows
+    // 2 y0 - 1 ... 2 (y0 + R) - 1 and columns -1 ... WI - 1)
+    constexpr int WI = W_ * STR, PW = WI + 2, TPX = NPB * 32;
+    constexpr int MAXLOAD = STR == 1 ? TPX + 2 * W_ : TPX * 4 + WI;    // most input pixels a tile loads (a band of rows + its neighbour rows)
     constexpr int NIT = (2 * MAXLOAD + 63) / 64;                // loader passes: an item = 8 channels (one k-half) of one pixel
     extern __shared__ __attribute__((aligned(16))) uint4 ws_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
     const int n = lane & 31, kg = lane >> 5;
-    const int H = a_H, HW = H * W_;
+    const int H = a_H, HW = H * W_;                            // output rows / pixels per image
+    const int HI = H * STR, HWI = HI * WI;                      // input rows / pixels per image
     // ---- this workgroup: channel group g, pixel tile (whole images, or R rows of one image) ------------------------------------
     int slot = blockIdx.x;
     if (a_xcd_remap) slot = (blockIdx.x & 7) * ((int)gridDim.x >> 3) + (blockIdx.x >> 3);     // one contiguous (group-major) band per XCD: its L2 holds ~groups / 8 weight slices
     const int g = slot / a_tiles, tile = slot - g * a_tiles;
     const bool whole = TPX >= HW;
-    const int n_img = whole ? TPX / HW : 1, R = whole ? H : TPX / W_, PR = R + 2, PPIX = n_img * PR * PW;
+    const int n_img = whole ? TPX / HW : 1, R = whole ? H : TPX / W_, PR = R * STR + 2, PPIX = n_img * PR * PW;
     const int parts = whole ? 1 : HW / TPX;
     const int b0 = whole ? tile * n_img : tile / parts, y0 = whole ? 0 : (tile - b0 * parts) * R;
-    // loaded rows of an image part: whole images rows 0 .. H-1 (patch rows 1 .. H); a part also its neighbour rows (patch rows 0 .. R+1)
-    const int row0 = whole ? 1 : 0, nrow = whole ? H : PR, nload = n_img * nrow * W_;
+    // loaded input rows of an image part: whole images rows 0 .. HI-1 (patch rows 1 .. HI); a part also its neighbour rows (patch rows
+    // 0 .. R+1; stride 2: 0 .. 2R, there is no row below)
+    const int row0 = whole ? 1 : 0, nrow = whole ? HI : (STR == 1 ? PR : PR - 1), nload = n_img * nrow * WI;
     uint4 *patch = ws_smem + (size_t)wave * 4 * PPIX;
     // ---- loader items of this lane (the same for every chunk): item e = pass * 64 + lane -> (k-half, loaded pixel) ---------------
     // (no runtime divisions in the set-up: a tile holds at most four images -- compare chains -- and W_ is a power of two)
-    const int per_img = nrow * W_;
+    const int per_img = nrow * WI;
     auto img_of = [](int i, int per) __attribute__((always_inline)) { return (i >= per ? 1 : 0) + (i >= 2 * per ? 1 : 0) + (i >= 3 * per ? 1 : 0); };
     int l_off[NIT];                            // float offset inside a channel plane (+ image stride), -1: nothing to load
     int l_tab[NIT];                            // patch unit incl. the k-half (12 bits) | image << 20
@@ -117,10 +126,10 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
         l_off[it] = -1; l_tab[it] = 0;
         if (e < 2 * nload) {
             const int k2 = e >= nload ? 1 : 0, idx = e - k2 * nload;
-            const int img = img_of(idx, per_img), rem = idx - img * per_img, r = rem / W_, x = rem - r * W_;
-            const int y = y0 - 1 + row0 + r;
-            if (y >= 0 && y < H) {
-                l_off[it] = k2 * 8 * HW + y * W_ + x;            // (+ img * batch stride: added per source below)
+            const int img = img_of(idx, per_img), rem = idx - img * per_img, r = rem / WI, x = rem - r * WI;
+            const int y = y0 * STR - 1 + row0 + r;
+            if (y >= 0 && y < HI) {
+                l_off[it] = k2 * 8 * HWI + y * WI + x;            // (+ img * batch stride: added per source below)
                 l_tab[it] = ((k2 * 2) * PPIX + (img * PR + row0 + r) * PW + x + 1) | (img << 20);
             }
         }
@@ -134,13 +143,13 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
         const bool from0 = chunk < c0_chunks;
         const int cc = from0 ? chunk * 16 : (chunk - c0_chunks) * 16;
         const long long sbs = from0 ? a_x0_bs : a_x1_bs;
-        const char *src = reinterpret_cast<const char *>((from0 ? a_x0 : a_x1) + (size_t)b0 * sbs + (size_t)cc * HW);
+        const char *src = reinterpret_cast<const char *>((from0 ? a_x0 : a_x1) + (size_t)b0 * sbs + (size_t)cc * HWI);
         static_for<NIT>([&](auto itc) __attribute__((always_inline)) {
             constexpr int it = decltype(itc)::value;
             const unsigned vo = l_off[it] >= 0 ? (unsigned)(((l_tab[it] >> 20) & 0xf) * (int)sbs + l_off[it]) * 4u : 0u;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const char *sc = src + (size_t)c * HW * 4;             // (uniform: scalar arithmetic)
+                const char *sc = src + (size_t)c * HWI * 4;             // (uniform: scalar arithmetic)
                 const float v = *reinterpret_cast<const float *>(sc + vo);
                 xv[it][c] = l_off[it] >= 0 ? v : 0.f;
             }
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
     for (int pb = 0; pb < NPB; ++pb) {
         const int p = pb * 32 + n;
         const int img = whole ? img_of(p, HW) : 0, rem = p - img * HW, y = rem / W_, x = rem - y * W_;     // (part of an image: y counts from y0)
-        bbase[pb] = (kg * 2) * PPIX + (img * PR + y) * PW + x;
+        bbase[pb] = (kg * 2) * PPIX + (img * PR + y * STR) * PW + x * STR;
     }
     WS_STAMP(5);
 
@@ -308,6 +317,11 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(const WsArgs PA) {
             mag += fabsf(v[r]);
         }
         if (a_fault && !(mag < 3.0e38f)) *a_fault = 1;          // non-finite accumulators: reported before the LayerNorm pass can hide them
+        if (a_pre_add) {
+            const float *pp = a_pre_add + (size_t)(b0 + img) * a_out_bs + (size_t)cbase * HW + pix;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += pp[(size_t)((r & 3) + 8 * (r >> 2)) * HW];
+        }
         float *o = a_out + (size_t)(b0 + img) * a_out_bs + (size_t)cbase * HW + pix;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];

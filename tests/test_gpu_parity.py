@@ -198,6 +198,22 @@ def test_conv2d_weight_stationary_kernel(O, case, npb, monkeypatch):
     assert relerr(G2.conv2d(x, w, b, s, p), ref) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(2, 320, 16, 16, 320), (1, 256, 32, 32, 256), (1, 64, 64, 64, 64), (3, 192, 32, 64, 192), (1, 128, 64, 32, 96)])
+def test_conv2d_stride2_weight_stationary_kernel(O, case, monkeypatch):
+    """The Downsample (3x3 / stride 2 / pad 1) of a small launch on conv_ws_kernel's stride-2 form (all of K inside the workgroup) against
+    the oracle; the launch really is that kernel."""
+    monkeypatch.setenv("CDC_WS_MIN_WGS", "1")
+    monkeypatch.setenv("CDC_OP_REQUIRE_WS", "1")
+    from cdc_compression_amd.ops import Ops
+    B, Ci, H, W, Co = case
+    x = synth.normal("cx", (B, Ci, H, W), 41)
+    w = synth.normal("cw", (Co, Ci, 3, 3), 41, 1.0 / np.sqrt(Ci * 9))
+    b = synth.normal("cb", (Co,), 41, 0.1)
+    ref = O.conv2d(x, w, b, 2, 1)
+    got = Ops(0).conv2d(x, w, b, 2, 1)
+    assert got.shape == ref.shape and relerr(got, ref) < 1e-5, relerr(got, ref)
+
+
 WS1_CASES = [
     # 1x1 layers of the few-pixel levels on conv_ws1_kernel (all of K inside the workgroup; 32-pixel blocks of the flattened batch)
     (2, 384, 8, 8, 384), (4, 320, 8, 8, 960), (1, 256, 16, 16, 768), (3, 640, 16, 16, 256), (2, 48, 8, 8, 32), (1, 64, 4, 24, 96),
