@@ -157,12 +157,12 @@ def read_prof(L, h):
 
 
 FAMILY = {"PF3": "conv_pf3_kernel", "PF": "conv_pf_kernel", "PW": "conv_pw_kernel", "SPLIT2H": "conv_split2_kernel",
-          "SPLIT2": "conv_split2_kernel", "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel"}
+          "SPLIT2": "conv_split2_kernel", "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel", "WS": "conv_ws_kernel", "WS1": "conv_ws1_kernel"}
 
 
 def kern_of(label):
     t = label.split()
-    return next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
+    return next((k for k in ("PF3", "PF", "PW", "WS1", "WS", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
 
 
 def op_bytes(label, B):

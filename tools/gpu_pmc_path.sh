@@ -11,7 +11,7 @@
 # usage (on the GPU box): bash tools/gpu_pmc_path.sh [sample_steps=4] [round tag=r04]
 set -u
 STEPS="${1:-4}"
-TAG="${2:-r04}"
+TAG="${2:-r05}"
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT

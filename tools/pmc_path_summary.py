@@ -95,19 +95,19 @@ def dispatches(d, counter):
 
 
 def last_iteration(seq):
-    ends = [i for i, (k, _) in enumerate(seq) if k.startswith("ddim_kernel")]
+    ends = [i for i, (k, _) in enumerate(seq) if k.startswith("ddim_")]          # ddim_kernel / ddim_rows4_kernel
     if len(ends) < 2:
         return []
     return seq[ends[-2] + 1: ends[-1] + 1]
 
 
 FAMILY = {"PF3": "conv_pf3_kernel", "PF": "conv_pf_kernel", "PW": "conv_pw_kernel", "SPLIT2H": "conv_split2_kernel", "SPLIT2": "conv_split2_kernel",
-          "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel"}
+          "SPLIT": "conv_split_kernel", "CONV": "conv_mfma_kernel", "WS": "conv_ws_kernel", "WS1": "conv_ws1_kernel"}
 
 
 def kern_of(label):
     t = label.split()
-    return next((k for k in ("PF3", "PF", "PW", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
+    return next((k for k in ("PF3", "PF", "PW", "WS1", "WS", "SPLIT2H", "SPLIT2", "SPLIT") if k in t), "CONV")
 
 
 if ops_file and os.path.exists(ops_file):
