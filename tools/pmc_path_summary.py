@@ -65,8 +65,9 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
     if s["pct"] >= 2.0:
         print(f"{k:<112} {s['calls']:>6} {s['avg_ns'] / 1e3:>9.1f} {s['pct']:>7.2f} {corr / 1e6:>16.1f} | {raw / 1e6:>11.1f} {tbs:>6.2f} {busy:>10.3f} {b.get('SQ_INSTS_MFMA', 0) / nb:>11.0f} {confl:>9.3f}")
 # whole path: every dispatch of the pass / number of DDIM iterations (the 2-iteration build decode and the context pre-pass are in: upper bound)
-tot_fetch = sum(v.get("FETCH_SIZE", 0) for v in A.values()) * 1024
-tot_write = sum(v.get("WRITE_SIZE", 0) for v in Wc.values()) * 1024
+# (not the path: bench.py's own ceiling probes, csrc/probe.hip, which run in the same process since round 5)
+tot_fetch = sum(v.get("FETCH_SIZE", 0) for k, v in A.items() if "probe_" not in k) * 1024
+tot_write = sum(v.get("WRITE_SIZE", 0) for k, v in Wc.items() if "probe_" not in k) * 1024
 iters = steps + 2
 per_iter_corr, per_iter_raw = (2 * tot_fetch + tot_write) / iters, (tot_fetch + tot_write) / iters
 print(f"\nwhole path: FETCH {tot_fetch / 1e9:.2f} GB (raw) + WRITE {tot_write / 1e9:.2f} GB over {iters} DDIM iterations of {B} images")
