@@ -217,8 +217,12 @@ __global__ void __launch_bounds__(256) ln_kernel_vec(const LnArgs a) {
     for (int k = 0; k < NP; ++k)                      // split-K slices of the producing convolution
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c = cs + CS * i;
-            t[k][i] = (pv && c < a.C) ? *reinterpret_cast<const float4 *>(x + (size_t)k * a.part_stride + (size_t)c * a.HW) : zero4;
+            // (always a load from a valid address, the value masked afterwards: "cond ? *p : zero4" became a select between p and the
+            //  address of a zero4 copy in SCRATCH, every load of the pass a flat load and the masked lanes a round trip to private memory)
+            const int c = cs + CS * i, cc = c < a.C ? c : a.C - 1;
+            const float4 ld = *reinterpret_cast<const float4 *>(x + (size_t)k * a.part_stride + (size_t)cc * a.HW);
+            const bool ok = pv && c < a.C;
+            t[k][i] = make_float4(ok ? ld.x : 0.f, ok ? ld.y : 0.f, ok ? ld.z : 0.f, ok ? ld.w : 0.f);
         }
     const float *r = (a.out && a.resid) ? a.resid + base : nullptr;
     const float *sh = (a.out && a.shift) ? a.shift + (size_t)b * a.shift_bs : nullptr;
@@ -226,7 +230,8 @@ __global__ void __launch_bounds__(256) ln_kernel_vec(const LnArgs a) {
     for (int i = 0; i < NV; ++i) {
         const int c = cs + CS * i;
         const bool ok = c < a.C && a.out;
-        rv[i] = (r && pv && ok) ? *reinterpret_cast<const float4 *>(r + (size_t)c * a.HW) : zero4;
+        rv[i] = zero4;
+        if (r && pv && ok) rv[i] = *reinterpret_cast<const float4 *>(r + (size_t)c * a.HW);
         gv[i] = ok ? a.g[c] : 0.f;
         bv[i] = ok ? a.b[c] : 0.f;
         sv[i] = (sh && ok) ? sh[c] : 0.f;

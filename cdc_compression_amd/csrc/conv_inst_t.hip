@@ -120,7 +120,7 @@ bool ws1_make_plan(int Cin, int C0, int Cout, int HW, int B, bool per_image_w, W
     if ((Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32 || (HW % 32) || HW < 32) return false;
     const int groups = Cout / 32, nchunk = Cin / 16;
     const long long blocks = (long long)B * (HW / 32);
-    const long long min_wgs = dev_env("CDC_WS1_MIN_WGS") ? atoll(dev_env("CDC_WS1_MIN_WGS")) : 12;
+    const long long min_wgs = dev_env("CDC_WS1_MIN_WGS") ? atoll(dev_env("CDC_WS1_MIN_WGS")) : 4;
     const int force_npb = dev_env("CDC_WS1_NPB") ? atoi(dev_env("CDC_WS1_NPB")) : 0;
     for (int npb : {4, 2}) {
         if (force_npb && npb != force_npb) continue;

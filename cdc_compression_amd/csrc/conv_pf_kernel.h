@@ -265,6 +265,29 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
 
     const int half = lane >> 5, j = lane & 31;
     const int pr = 0, pc = j;
+    // Hoisted partial sums (pre_add, accumulator order): the epilogue reads 16 - 24 16-byte units per lane of them straight from HBM, with
+    // nothing else of this workgroup in flight (first layer: 20 k of a tile's 42 k cycles were its epilogue).  Their lines are touched
+    // NOW -- one dword per unit, all into one register that nobody reads -- and are in L2 when the epilogue asks.  (The register stays
+    // reserved until the K loop is over: the loop's own vmcnt waits retire these older loads first.)
+    unsigned pre_touch = 0;
+    if constexpr (TZ == 1) {
+        if (P.pre_add && P.pre_c4 && !(CDC_PF_ABLATE && (P.dbg & 512))) {
+            const size_t hw = (size_t)P.Ho * P.Wo;
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+                const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+                if (oy < P.Ho && ox < P.Wo) {
+                    const float4 *p4 = reinterpret_cast<const float4 *>(P.pre_add) +
+                                       ((size_t)b * (P.Cout >> 2) + ((cog * COPT + wm * MB * 32) >> 2) + half) * hw + (size_t)oy * P.Wo + ox;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            asm volatile("global_load_dword %0, %1, off" : "+v"(pre_touch) : "v"(p4 + (size_t)(m * 8 + 2 * g) * hw) : "memory");
+                }
+            }
+        }
+    }
     // A: stage[(pl*2 + half)*COPT + wm*MB*32 + m*32 + j];  B: buf[(half*2 + pl)*PLANE + (row + ky)*PW + pc + kx]
     const uint4 *a_base = smem_u + NPB * PST + half * COPT + wm * MB * 32 + j;
     const uint4 *b_base = smem_u + (half * 2) * PLANE + (wp * NPW * STR) * PW + j;
@@ -464,6 +487,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_touch));   // (pre_touch above: its register is free from here on; nothing is in flight any more)
     __builtin_amdgcn_s_barrier();                         // every wave is done with the operand buffers
     PFTL(3);
     if (CDC_PF_ABLATE && (P.dbg & 256)) { PFTL_END(); return; }
@@ -487,6 +511,120 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     const bool ch_ok = cobase + MB * 32 <= P.Cout || COPT == 32;
     const int nvalid = P.Cout - cobase;
     // block n of the wave: pixel row (n % NPW) of its stack, phase n / NPW (TZ = 4; otherwise the workgroup's z)
+    if constexpr (TZ == 4) {
+        // Fused phases: 128 accumulator registers per lane, and in the general epilogue below the compiler spilled 170 - 230 more to scratch
+        // (all of a lane's per-channel parameters live beside them) -- scratch lines the streaming stores then evicted to HBM: 1.5x the
+        // output bytes written, 1.6x the input bytes read (profiles/pmc_r05_path.json: 801 MB against 537 for the 64-channel Upsample).
+        // What an Upsample needs (bias, the final LayerNorm where one wave holds all channels, stores) one output-row pair at a time:
+        // the two horizontally adjacent phase blocks (px = 0, 1) of a lane are finished and stored before the next pair is touched.
+        if (!P.pre_add && !P.resid && !P.resid_pf && !P.res3_w && !P.relu && !P.shift && !P.stat_mean && (WM == 1 || !P.ep_g)) {
+            static_assert(!ACC2, "fused phases: one accumulator set");
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) {
+                    const int q0 = (py * 2) * NPW + n, q1 = q0 + NPW;
+                    const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
+                    const bool valid = (oy < P.Ho) && (ox < P.Wo) && ch_ok;
+                    // (the parameter pointer is opaque per pair: the compiler otherwise merges the four pairs' identical LDS reads and keeps
+                    //  all 96 parameter values live across them -- the spills again)
+                    int eo = 0;
+                    asm volatile("" : "+v"(eo));          // (an opaque zero offset: the pointer itself would lose its LDS address space -- flat loads)
+                    const float *eq = epl + eo;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float bi = eq[m * 32 + (r & 3) + 8 * (r >> 2)];
+                            acc[m][q0][r] = acc[m][q0][r] * P.acc_scale + bi;
+                            acc[m][q1][r] = acc[m][q1][r] * P.acc_scale + bi;
+                        }
+                    if constexpr (WM == 1) {
+                        if (P.ep_g) {                   // channel LayerNorm: the wave holds every channel of its pixels (lanes l, l + 32)
+                            float mean[2], rinv[2];
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int q = i ? q1 : q0;
+                                float sm = 0.f;
+#pragma unroll
+                                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) sm += acc[m][q][r];
+                                sm += __shfl_xor(sm, 32);
+                                mean[i] = sm * inv_c;
+                                float sq = 0.f;
+#pragma unroll
+                                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) { const float d = acc[m][q][r] - mean[i]; sq += d * d; }
+                                sq += __shfl_xor(sq, 32);
+                                if (P.fault && !(sq < 3.0e38f)) *P.fault = 1;       // range guard, as chan_stats below
+                                rinv[i] = 1.0f / sqrtf(sq * inv_c + P.eps);
+                            }
+#pragma unroll
+                            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
+                                    const float gi = eq[COPT + ci], bi = eq[2 * COPT + ci];
+                                    acc[m][q0][r] = (acc[m][q0][r] - mean[0]) * rinv[0] * gi + bi;
+                                    acc[m][q1][r] = (acc[m][q1][r] - mean[1]) * rinv[1] * gi + bi;
+                                }
+                        }
+                    }
+                    if (!P.ep_g && P.fault) {
+                        float sa = 0.f;
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sa += fabsf(acc[m][q0][r]) + fabsf(acc[m][q1][r]);
+                        if (!(sa < 3.0e38f)) *P.fault = 1;
+                    }
+                    if (valid && !(CDC_PF_ABLATE && (P.dbg & 16))) {
+                        if (P.out) {
+                            float *op = P.out + (size_t)b * P.out_bs + (unsigned)(oy * P.out_ys + ox * P.out_xs + P.out_zoff[py * 2]) + (size_t)(cobase + 4 * half) * P.out_cs;
+#pragma unroll
+                            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    *reinterpret_cast<float2 *>(op + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * P.out_cs) = make_float2(acc[m][q0][r], acc[m][q1][r]);
+                        }
+                        if (P.out_pf) {
+                            const long long u0 = (long long)b * P.pf_bs + (long long)oy * P.pf_ys + (long long)ox * P.pf_xs + P.pf_zoff[py * 2] + half;
+#pragma unroll
+                            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    _Float16 h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        split2h(acc[m][q0][g * 4 + i], h0[i], l0[i]);
+                                        split2h(acc[m][q1][g * 4 + i], h1[i], l1[i]);
+                                    }
+                                    const f16x4 hv0 = {h0[0], h0[1], h0[2], h0[3]}, lv0 = {l0[0], l0[1], l0[2], l0[3]};
+                                    const f16x4 hv1 = {h1[0], h1[1], h1[2], h1[3]}, lv1 = {l1[0], l1[1], l1[2], l1[3]};
+                                    const uint2 a0 = __builtin_bit_cast(uint2, hv0), a1 = __builtin_bit_cast(uint2, hv1);
+                                    const uint2 c0 = __builtin_bit_cast(uint2, lv0), c1 = __builtin_bit_cast(uint2, lv1);
+                                    // lane l (half 0) keeps its pixel-2x half and receives the partner's; lane l + 32 likewise for pixel 2x + 1
+                                    const uint2 sh = half ? a0 : a1, sl = half ? c0 : c1;
+                                    uint2 rh, rl;
+                                    rh.x = __shfl_xor(sh.x, 32); rh.y = __shfl_xor(sh.y, 32);
+                                    rl.x = __shfl_xor(sl.x, 32); rl.y = __shfl_xor(sl.y, 32);
+                                    const uint4 uh = half ? make_uint4(rh.x, rh.y, a1.x, a1.y) : make_uint4(a0.x, a0.y, rh.x, rh.y);
+                                    const uint4 ul = half ? make_uint4(rl.x, rl.y, c1.x, c1.y) : make_uint4(c0.x, c0.y, rl.x, rl.y);
+                                    uint4 *pu = reinterpret_cast<uint4 *>(P.out_pf) + u0 + (long long)((cobase >> 3) + m * 4 + g) * 2 * P.pf_ps;
+                                    pu[0] = uh;
+                                    pu[P.pf_ps] = ul;
+                                }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            PFTL(6);
+            PFTL_END();
+            return;
+        }
+    }
     float mean_v[NB], rinv_v[NB];
     bool valid_v[NB];
     unsigned pix_v[NB];                                   // offset inside one image's channel plane set (< 2^31: host)
@@ -496,12 +634,13 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
         const int zn = TZ == 4 ? n / NPW : z;
         valid_v[n] = (oy < P.Ho) && (ox < P.Wo) && ch_ok;
         pix_v[n] = (unsigned)(oy * P.out_ys + ox * P.out_xs + P.out_zoff[zn]);
+        const float *eq = epl;
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[m][n][r] = (ACC2 ? acc[m][n][r] + acc2[ACC2 ? m : 0][ACC2 ? n : 0][r] * (1.0f / 2048.0f) : acc[m][n][r]) * P.acc_scale +
-                               epl[m * 32 + (r & 3) + 8 * (r >> 2)];
+                               eq[m * 32 + (r & 3) + 8 * (r >> 2)];
         if (P.pre_add && P.pre_c4 && valid_v[n]) {
             // hoisted partial sums in accumulator order: the lane's 4 consecutive channels of a group are one 16-byte load
             const size_t hw = (size_t)P.Ho * P.Wo;
@@ -584,14 +723,16 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     if (P.ep_g) {
         chan_stats(mean_v, rinv_v);
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
+        for (int n = 0; n < NB; ++n) {
+            const float *eq = epl;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ci = m * 32 + (r & 3) + 8 * (r >> 2);
-                    acc[m][n][r] = (acc[m][n][r] - mean_v[n]) * rinv_v[n] * epl[COPT + ci] + epl[2 * COPT + ci];
+                    acc[m][n][r] = (acc[m][n][r] - mean_v[n]) * rinv_v[n] * eq[COPT + ci] + eq[2 * COPT + ci];
                 }
+        }
     } else if (P.fault) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -612,10 +753,11 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaxf(acc[m][n][r], P.relu_slope * acc[m][n][r]);
         }
         if (P.shift) {
+            const float *eq = epl;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] += epl[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += eq[3 * COPT + m * 32 + (r & 3) + 8 * (r >> 2)];
         }
         if (P.resid_pf && valid_v[n]) {       // the residual as a PF tensor: this lane's 8-byte half-units, a = h + l' 2^-11
             const int oy = oy0 + (wp * NPW + n % NPW) * NBH + pr, ox = ox0 + pc;
