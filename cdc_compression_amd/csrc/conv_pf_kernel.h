@@ -265,29 +265,6 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
 
     const int half = lane >> 5, j = lane & 31;
     const int pr = 0, pc = j;
-    // Hoisted partial sums (pre_add, accumulator order): the epilogue reads 16 - 24 16-byte units per lane of them straight from HBM, with
-    // nothing else of this workgroup in flight (first layer: 20 k of a tile's 42 k cycles were its epilogue).  Their lines are touched
-    // NOW -- one dword per unit, all into one register that nobody reads -- and are in L2 when the epilogue asks.  (The register stays
-    // reserved until the K loop is over: the loop's own vmcnt waits retire these older loads first.)
-    unsigned pre_touch = 0;
-    if constexpr (TZ == 1) {
-        if (P.pre_add && P.pre_c4 && !(CDC_PF_ABLATE && (P.dbg & 512))) {
-            const size_t hw = (size_t)P.Ho * P.Wo;
-#pragma unroll
-            for (int n = 0; n < NPW; ++n) {
-                const int oy = oy0 + (wp * NPW + n) * NBH + pr, ox = ox0 + pc;
-                if (oy < P.Ho && ox < P.Wo) {
-                    const float4 *p4 = reinterpret_cast<const float4 *>(P.pre_add) +
-                                       ((size_t)b * (P.Cout >> 2) + ((cog * COPT + wm * MB * 32) >> 2) + half) * hw + (size_t)oy * P.Wo + ox;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            asm volatile("global_load_dword %0, %1, off" : "+v"(pre_touch) : "v"(p4 + (size_t)(m * 8 + 2 * g) * hw) : "memory");
-                }
-            }
-        }
-    }
     // A: stage[(pl*2 + half)*COPT + wm*MB*32 + m*32 + j];  B: buf[(half*2 + pl)*PLANE + (row + ky)*PW + pc + kx]
     const uint4 *a_base = smem_u + NPB * PST + half * COPT + wm * MB * 32 + j;
     const uint4 *b_base = smem_u + (half * 2) * PLANE + (wp * NPW * STR) * PW + j;
@@ -487,7 +464,6 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_touch));   // (pre_touch above: its register is free from here on; nothing is in flight any more)
     __builtin_amdgcn_s_barrier();                         // every wave is done with the operand buffers
     PFTL(3);
     if (CDC_PF_ABLATE && (P.dbg & 256)) { PFTL_END(); return; }
