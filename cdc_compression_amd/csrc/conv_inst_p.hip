@@ -118,7 +118,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
             const int S = (s.Cin / 16) * 9 / tps;                // weight stages of a tile
             if (!ring || S < ring - 1) continue;
             const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B * (s.Cout / COPT);
-            const double min_wgs = dev_env("CDC_PF_S2_MIN_WGS") ? atof(dev_env("CDC_PF_S2_MIN_WGS")) : 256.0;
+            const double min_wgs = dev_env("CDC_PF_S2_MIN_WGS") ? atof(dev_env("CDC_PF_S2_MIN_WGS")) : 128.0;
             if (wgs < min_wgs) continue;                        // one workgroup per CU: fewer than one round leaves CUs idle
             const double score = (double)COPT;
             if (score <= best) continue;
@@ -144,7 +144,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
             const int S = (s.Cin / 16) * 16 / tps;               // weight stages of a tile
             if (!ring || S < ring - 1) continue;
             const double wgs = (double)((s.Wo + 31) / 32) * ((s.Ho + TH - 1) / TH) * s.B;
-            const double min_wgs = dev_env("CDC_PF_TZ_MIN_WGS") ? atof(dev_env("CDC_PF_TZ_MIN_WGS")) : 256.0;
+            const double min_wgs = dev_env("CDC_PF_TZ_MIN_WGS") ? atof(dev_env("CDC_PF_TZ_MIN_WGS")) : 128.0;
             if (wgs < min_wgs) continue;
             best = COPT;
             const size_t patch = (size_t)2 * pf_patch_units(c.NPW, c.WP, 2, 2, 1, 4) * 16, wst = (size_t)tps * pf_rows(c.MB, 4 * c.NPW) * COPT * 16;
