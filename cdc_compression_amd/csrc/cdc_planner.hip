@@ -43,7 +43,7 @@ struct Builder {
         else if (op.kind == Op::CONVWS1)
             snprintf(buf, sizeof buf, "conv 1x1 s1 %4d->%-4d out %3dx%-3d NPB%d waves%d tiles%d g%d WS1%s%s%s", op.ws1.Cin, op.ws1.Cout, ws1_h, op.ws1.HW / std::max(ws1_h, 1),
                      op.ws1plan.NPB, op.ws1plan.waves, op.ws1plan.tiles, op.ws1plan.groups, op.ws1.pre_mean ? " pre" : "", op.ws1.w_bs ? " perimg" : "",
-                     op.ws1.resid ? " +res" : "");
+                     op.ws1.resid ? (op.ws1.resid_is_pre ? " pre_add" : " +res") : "");
         else if (op.kind == Op::LN)
             snprintf(buf, sizeof buf, "ln C=%d HW=%d%s", op.ln.C, op.ln.HW, op.ln.out ? "" : " stats");
         else if (op.kind == Op::KVCTX)
@@ -542,7 +542,7 @@ struct Builder {
                  const ConvOpts &o, bool need_all, int prof) {
         if (rc || h->arith != 1 || !w.wsh || planB > 0 || w.KH != 1 || w.KW != 1 || w.stride != 1 || w.transposed || w.nz != 1) return false;
         if ((w.pad_y >= 0 ? w.pad_y : w.pad) != 0 || (w.pad_x >= 0 ? w.pad_x : w.pad) != 0) return false;
-        if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || o.pre_add || o.relu || o.resid1 || o.uf_c) return false;
+        if (need_all || o.ln_g || o.stat_mean || o.res3_w || o.pf_only || (o.pre_add && o.resid) || o.relu || o.resid1 || o.uf_c) return false;
         if (o.pre_mean && o.pre_mode != 2) return false;
         if (o.w_bs && !o.wsp_bs) return false;               // per-image weights without planes
         if (w.COP != w.Cout || w.Cin_pad != w.Cin || out_bs != (long long)w.Cout * H * W) return false;
@@ -566,6 +566,8 @@ struct Builder {
         a.bias = o.no_bias ? nullptr : w.bias;
         a.shift = o.shift; a.shift_bs = o.shift_bs >= 0 ? o.shift_bs : h->shift_bs;
         a.resid = o.resid; a.resid_bs = o.resid_bs;
+        // (a hoisted partial sum -- the step-invariant context half of a concatenated input, layout of `out` -- is one more addend of this linear epilogue)
+        if (o.pre_add) { a.resid = o.pre_add; a.resid_bs = out_bs; a.resid_is_pre = 1; }
         a.out = out; a.out_bs = out_bs;
         a.fault = fault_flag();
         const double px = (double)B * H * W;

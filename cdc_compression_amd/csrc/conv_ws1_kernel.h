@@ -32,6 +32,7 @@ struct Ws1Args {
     int shift_bs;
     const float *resid;             // + resid[b * resid_bs + co * HW + pix], or null
     long long resid_bs;
+    int resid_is_pre;               // (label only: `resid` is a hoisted partial sum, ConvArgs::pre_add)
     float *out;                     // fp32 NCHW
     long long out_bs;
     int tiles;                      // pixel tiles (gridDim.x = tiles * Cout / 32)

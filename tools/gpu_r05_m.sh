@@ -15,3 +15,6 @@ PY
 for b in 1 2 4 8; do
 timeout 300 python bench.py --batch $b --sample-steps 60 --no-verify --no-cpu-baseline --no-other-configs --no-alt-arith --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch $b: ms/iter', d['roofline']['ms_per_ddim_iter'])"
 done
+for g in 0 1; do
+CDC_GRAPH=$g timeout 300 python bench.py --batch 1 --sample-steps 100 --no-verify --no-cpu-baseline --no-other-configs --no-alt-arith --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('CDC_GRAPH=$g batch 1: ms/iter', d['roofline']['ms_per_ddim_iter'])"
+done
