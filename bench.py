@@ -294,7 +294,10 @@ def launches_per_iter(L, h):
         lab, ms, cnt, fl = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         L.cdc_prof_op(h, i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl))
         t = lab.value.decode()
-        n += 0 if (" HOIST" in t or t == "combine" or t == "temb") else 1
+        if " HOIST" in t or t == "combine" or t == "temb":
+            continue
+        # (the attention fold is two kernels -- ctx_r0, fold_r12_mfma -- at the model's folded widths, ctx_r0 + R1 + R2 otherwise: aux_kernels.hip ctx_fold_launch)
+        n += (2 if any(("C=%d " % c) in t for c in (64, 128, 192)) else 3) if t.startswith("ctxf ") else 1
     return n + 2          # + the time-embedding row copy + the sampler update
 
 

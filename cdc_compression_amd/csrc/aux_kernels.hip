@@ -1174,6 +1174,113 @@ __global__ void __launch_bounds__(64) fold_r2_mfma_kernel(const float *T1, const
     }
 }
 
+// R1 and R2 of the fold in ONE launch (round 5; the compile-time channel counts): a workgroup owns a 32-column block c of M' and has one wave
+// per 32-row block.  R2's tile (ci block, c block) needs T1[:, c block] -- all d, these 32 columns -- which is exactly what the
+// workgroup's waves produce in R1 (wave w: rows d = 32 w ...), so the slab goes through LDS instead of through a launch boundary
+// (a dependent launch costs 6.5 us on this part; the two products are 2 - 8 k cycles).  B operands: the WoT column block by LDS-DMA
+// (R1), the T1 slab (R2); A operands (ctxnT rows / Wq rows of the wave's block) straight from global memory, all of a product's loads
+// in flight at once.  Same products in the same order as fold_r1 / fold_r2_mfma_kernel (k = half, half + 2, ...): the same bits.
+template <int CT>
+__global__ void __launch_bounds__(64 * (CT / 32)) fold_r12_mfma_kernel(const float *ctxnT, const float *WoT, const float *Wq, float scale,
+                                                                       const float *ln_g, float *Mt, int Cin_pad, int COP,
+                                                                       unsigned short *Ws, int ws_f16, const float *u,
+                                                                       const float *b_out, float *biasB) {
+    constexpr int C = CT, NW = CT / 32;
+    extern __shared__ __attribute__((aligned(16))) float fold_lds[];       // Bs [C][32] | Ts [C][32] | us [C]
+    float *Bs = fold_lds, *Ts = fold_lds + C * 32, *us = Ts + C * 32;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 32, b = blockIdx.y, m0 = wave * 32;
+    {
+        const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+        const unsigned b_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)Bs;
+        const float *bp = WoT + n0 + (size_t)r8 * C + c4;
+        for (int k0 = 8 * wave; k0 < C; k0 += 8 * NW) fold_dma16(bp + (size_t)k0 * C, b_lds + (unsigned)k0 * 128u);
+    }
+    for (int k = tid; k < C; k += 64 * NW) us[k] = u[k];
+    float av[C / 2];
+    {   // R1: A[m = d][k = e] = ctxnT[e][d]
+        // (uniform base + 32-bit lane offset: the saddr form -- a 64-bit vector address per load would take 2 x C / 2 registers)
+        const char *a1 = reinterpret_cast<const char *>(ctxnT + (size_t)b * C * C + m0);
+        const unsigned lo = (unsigned)(half * C + j) * 4u;
+#pragma unroll
+        for (int k2 = 0; k2 < C / 2; ++k2) av[k2] = *reinterpret_cast<const float *>(a1 + (size_t)k2 * 2 * C * 4 + lo);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hipcc does not count the DMA loads
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < C / 2; ++k2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2], Bs[(2 * k2 + half) * 32 + j], acc, 0, 0, 0);
+        if ((k2 & 15) == 15) __builtin_amdgcn_sched_barrier(0);          // (the LDS operands 16 at a time, not all C / 2 beside the A operands)
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ts[(m0 + 4 * half + (r & 3) + 8 * (r >> 2)) * 32 + j] = acc[r];     // T1[d][c]
+    {   // R2: A[m = ci][k = d] = Wq[d][ci]
+        const char *a2 = reinterpret_cast<const char *>(Wq + m0);
+        const unsigned lo = (unsigned)(half * C + j) * 4u;
+#pragma unroll
+        for (int k2 = 0; k2 < C / 2; ++k2) av[k2] = *reinterpret_cast<const float *>(a2 + (size_t)k2 * 2 * C * 4 + lo);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < C / 2; ++k2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2], Ts[(2 * k2 + half) * 32 + j], acc, 0, 0, 0);
+        if ((k2 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wave == 0) {                                          // bias row: same summation order as inside the K loop
+        float bsum = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < C / 2; ++k2) { const int k = 2 * k2 + half; bsum += us[k] * Ts[k * 32 + j]; }
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0) biasB[(size_t)b * C + n0 + j] = b_out[n0 + j] + scale * bsum;
+    }
+    const int c = n0 + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ci0 = m0 + 8 * g + 4 * half;               // this lane's 4 consecutive input channels of the 8-channel unit
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = acc[4 * g + i] * scale * ln_g[ci0 + i];   // PreNorm gain folded in (LNMODE 2)
+            Mt[((size_t)b * Cin_pad + ci0 + i) * COP + c] = v[i];
+        }
+        if (Ws) {
+            const int q = (m0 + 8 * g) >> 4, kh = ((m0 + 8 * g) >> 3) & 1;
+            uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(Ws) + (size_t)b * (C / 16) * 6 * C) + half;   // 8-byte half of a unit
+            if (ws_f16) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 wh, wl, wh2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = v[i] * kFoldPlaneScale;
+                    const _Float16 hq = (_Float16)x;
+                    wh[i] = hq; wl[i] = (_Float16)(x - (float)hq); wh2[i] = (_Float16)((float)hq * (1.0f / 2048.0f));
+                }
+                dst[2 * ((size_t)((q * 3 + 0) * 2 + kh) * C + c)] = __builtin_bit_cast(uint2, wh);
+                dst[2 * ((size_t)((q * 3 + 1) * 2 + kh) * C + c)] = __builtin_bit_cast(uint2, wl);
+                dst[2 * ((size_t)((q * 3 + 2) * 2 + kh) * C + c)] = __builtin_bit_cast(uint2, wh2);
+            } else {
+                unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hh[i] = __float_as_uint(v[i]) & 0xFFFF0000u;
+                    const float r1 = v[i] - __uint_as_float(hh[i]);
+                    mm[i] = __float_as_uint(r1) & 0xFFFF0000u;
+                    ll[i] = __float_as_uint(r1 - __uint_as_float(mm[i]));
+                }
+                dst[2 * ((size_t)((q * 3 + 0) * 2 + kh) * C + c)] = make_uint2((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3]);
+                dst[2 * ((size_t)((q * 3 + 1) * 2 + kh) * C + c)] = make_uint2((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3]);
+                dst[2 * ((size_t)((q * 3 + 2) * 2 + kh) * C + c)] = make_uint2((ll[0] >> 16) | (ll[1] & 0xFFFF0000u), (ll[2] >> 16) | (ll[3] & 0xFFFF0000u));
+            }
+        }
+    }
+}
+
 hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit, float scale,
                            const float *WoT, const float *WqT, float *T1, float *Mt, int Cin_pad,
                            int COP, const float *ln_g, const float *u, const float *b_out,
@@ -1184,8 +1291,11 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
     while (2 * spf * C <= 512 && 2 * spf <= nsplit) spf *= 2;
     // whole 32 x 32 blocks (the folded levels of the full-width models: C = 64, 128, 192): R1 / R2 / R3 on the f32 matrix cores
     const bool mfma = Wq && (C % 32) == 0 && Cin_pad == C && COP == C;
+    // (the one-launch fold reads the normalised context of ALL column blocks while other workgroups already write M': it lives in T1 there)
+    const bool two_launches = dev_env("CDC_FOLD_TWO_LAUNCHES") != nullptr;      // (A/B and tests: R1 and R2 as the two launches of round 4)
+    const bool one_launch = mfma && !two_launches && (C == 64 || C == 128 || C == 192);
     hipLaunchKernelGGL(ctx_r0_kernel, dim3(C, B), dim3(C * spf), sizeof(float) * (2 * nsplit + spf * C), st, S, ksum, C, nsplit,
-                       Mt, M, spf, mfma ? 1 : 0);
+                       one_launch ? T1 : Mt, M, spf, mfma ? 1 : 0);
     if (mfma) {
         const size_t lds = sizeof(float) * (2 * C * 32 + C);
         const dim3 grid(C / 32, C / 32, B);
@@ -1195,10 +1305,17 @@ hipError_t ctx_fold_launch(const float *S, const float *ksum, int C, int nsplit,
             hipLaunchKernelGGL(fold_r2_mfma_kernel<CTV>, grid, dim3(64), lds, st, T1, Wq, C, scale, ln_g, Mt, Cin_pad, COP, Ws, ws_f16, \
                                u, b_out, biasB);                                                                                    \
         } while (0)
-        if (C == 64) CDC_FOLD_LAUNCH(64);
+#define CDC_FOLD12_LAUNCH(CTV)                                                                                                      \
+        hipLaunchKernelGGL(fold_r12_mfma_kernel<CTV>, dim3(CTV / 32, B), dim3(64 * (CTV / 32)), sizeof(float) * (2 * CTV * 32 + CTV), st, T1, WoT, Wq,  \
+                           scale, ln_g, Mt, Cin_pad, COP, Ws, ws_f16, u, b_out, biasB)
+        if (C == 64 && !two_launches) CDC_FOLD12_LAUNCH(64);
+        else if (C == 128 && !two_launches) CDC_FOLD12_LAUNCH(128);
+        else if (C == 192 && !two_launches) CDC_FOLD12_LAUNCH(192);
+        else if (C == 64) CDC_FOLD_LAUNCH(64);
         else if (C == 128) CDC_FOLD_LAUNCH(128);
         else if (C == 192) CDC_FOLD_LAUNCH(192);
         else CDC_FOLD_LAUNCH(0);                        // (the run-time-count form: the other channel counts)
+#undef CDC_FOLD12_LAUNCH
 #undef CDC_FOLD_LAUNCH
         return hipGetLastError();
     }

@@ -431,6 +431,28 @@ def test_linear_attention_alternate_kernels(O, case, env, monkeypatch):
     assert relerr(got, ref) < 5e-6, relerr(got, ref)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 64), (1, 128, 64, 64), (1, 192, 64, 64), (3, 64, 32, 64)])
+def test_attention_fold_in_one_launch_equals_the_two_launch_fold(O, case, monkeypatch):
+    """Folded attention levels (N >= 16 C): the two products of the fold (M' = Wq^T (ctx^T Wo^T)) in ONE launch (fold_r12_mfma_kernel: the
+    T1 slab of a column block stays in LDS) against the oracle, and bit-identical to the two launches of round 4 (same products, same order)."""
+    from cdc_compression_amd.ops import Ops
+    B, C, H, W = case
+    x = synth.normal("ax", (B, C, H, W), 24)
+    sd = {"a.fn.norm.g": synth.normal("ag", (1, C, 1, 1), 24, 0.2, 1.0),
+          "a.fn.norm.b": synth.normal("ab", (1, C, 1, 1), 24, 0.2),
+          "a.fn.fn.to_qkv.weight": synth.normal("aq", (3 * C, C, 1, 1), 24, 2.0 / np.sqrt(C)),
+          "a.fn.fn.to_out.weight": synth.normal("ao", (C, C, 1, 1), 24, 1.0 / np.sqrt(C)),
+          "a.fn.fn.to_out.bias": synth.normal("aob", (C,), 24, 0.1)}
+    args = (x, sd["a.fn.norm.g"], sd["a.fn.norm.b"], sd["a.fn.fn.to_qkv.weight"], sd["a.fn.fn.to_out.weight"], sd["a.fn.fn.to_out.bias"])
+    ref = om.attention(O, sd, "a", x)
+    one = Ops(0).linear_attention(*args)
+    monkeypatch.setenv("CDC_DEV", "1")
+    monkeypatch.setenv("CDC_FOLD_TWO_LAUNCHES", "1")
+    two = Ops(0).linear_attention(*args)
+    assert relerr(one, ref) < 5e-6, relerr(one, ref)
+    assert np.array_equal(one, two)
+
+
 def make_unet(name):
     kw, man, sd, x, time, ctx, g = load_case(name)
     un = cdc.Unet(**kw)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round 5: the attention fold's two products in one launch: tests, bench line, small batches, A/B against the two-launch fold
+set -u
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r05_q; mkdir -p $OUT; cd $R
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest.log 2>&1
+tail -4 $OUT/pytest.log
+CDC_BENCH_OPS=400 timeout 900 python bench.py --no-other-configs --no-alt-arith --no-extras > $OUT/bench.json 2> $OUT/bench_stderr.txt
+grep "^\[op\]" $OUT/bench_stderr.txt > $OUT/per_op.txt
+python - <<'PY'
+import json,os
+d=json.loads(open(os.path.join(os.environ["GRAFT_REPO_ROOT"],"gpurun_out/r05_q/bench.json")).read().strip().splitlines()[-1])
+r=d["roofline"]
+print("value", d["value"], "ms/iter", r["ms_per_ddim_iter"], "frac", r["frac"], "verify", d.get("verify"), "batch1", d.get("batch1"))
+PY
+for v in "CDC_X_UNUSED=1" "CDC_FOLD_TWO_LAUNCHES=1"; do
+for b in 1 2 8 32; do
+env CDC_DEV=1 $v timeout 300 python bench.py --batch $b --sample-steps 60 --no-verify --no-cpu-baseline --no-other-configs --no-alt-arith --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$v] batch $b: ms/iter', d['roofline']['ms_per_ddim_iter'])"
+done; done
