@@ -1027,6 +1027,12 @@ struct Builder {
         const bool split_ctxq = !fold && !no_pic && h->arith == 1 && (C % 32) == 0 && (W & 3) == 0 && !dev_env("CDC_NO_CTXQ_SPLIT");
         const bool planes_f16 = (split_out && h->arith == 1) || split_ctxq;
         unsigned short *Ws = (stream_out || split_out || split_ctxq) ? reinterpret_cast<unsigned short *>(dalloc((size_t)B * C * C * 3 / 2 + 8)) : nullptr;
+        // (debugging taps of the level's intermediates: the staged projection, the partial context sums, the per-image matrix)
+        if (!fused) h->taps[at.prefix + ".kv"] = qkv;
+        { Act ts; ts.p = S; ts.C = nsplit; ts.H = C; ts.W = C; h->taps[at.prefix + ".S"] = ts; }
+        { Act ts; ts.p = ksum; ts.C = nsplit; ts.H = 1; ts.W = C; h->taps[at.prefix + ".Z"] = ts; }
+        { Act ts; ts.p = kmax; ts.C = 1; ts.H = 1; ts.W = C; h->taps[at.prefix + ".kmax"] = ts; }
+        { Act ts; ts.p = ctxw; ts.C = 1; ts.H = Cin_pad; ts.W = COP; h->taps[at.prefix + ".M"] = ts; }
         Op r = k; r.kind = fold ? Op::CTXF : Op::CTXR; r.prof = PC_SMALL;
         r.at_M = kmaxs; r.at_Ws = Ws; r.at_ws_f16 = planes_f16 ? 1 : 0; r.at_Wq = at.Wq;
         r.bytes = 4.0 * B * nsplit * C * C;
@@ -1137,6 +1143,7 @@ int build_program(cdc_handle *h, int B, int H, int W) {
         h->taps[dn + ".0"] = x;
         x = bd.resblock(h->rbs[rbi++], x, nullptr, false, sm, sr);
         h->taps[dn + ".1"] = x;
+        { Act ts; ts.p = sm; ts.C = 1; ts.H = x.H; ts.W = x.W; h->taps[dn + ".1.stat_mean"] = ts; ts.p = sr; h->taps[dn + ".1.stat_rstd"] = ts; }   // (the PreNorm statistics the attention reads)
         // (the level-0 skip is never popped -- unet.py:113 pushes six, :123 pops five: its only reader is the Downsample)
         // Its output goes to the Downsample as planes INSTEAD of fp32 where that convolution runs on the plane-operand kernel.
         const bool l0_planes = i == 0 && n > 1 && bd.pf_s2_would_plan(h->downs[0], x.H, x.W);
