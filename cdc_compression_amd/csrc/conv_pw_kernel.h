@@ -237,7 +237,14 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
         constexpr int slot = decltype(slotc)::value;    // (s + 1) % PD, compile-time: PD == 2
         if (s + 1 < S) {
             if (++sn == R) sn = 0;
-            if (s >= PD && s + R - 1 < S && s + 1 + PD < S) vm_wait<NWW + (PD - 1) * (L + NWW)>(); else dma_wait();
+            // Round 5: every step waits for ALL of the wave's LDS-DMA (vmcnt 0), not for a counted prefix.  The counted wait
+            // (vmcnt <= NWW + (PD - 1)(L + NWW): everything newer than the activation pieces of step s + 1) assumed that the pieces of a
+            // wave complete in issue order.  A one-step-at-a-time determinism stress (tools/determinism_stress_steps.py) found the k/v
+            // projection of the 64x64 level (192 -> 384, three channel groups) returning stale values in the LAST-issued activation
+            // pieces of a step (pixel block n = 1) about once in 10 000 launches on some boxes and never on others; waiting for
+            // everything costs nothing measurable (11.9 ms per iteration either way: the step is bound by the matrix pipe and the
+            // barrier, not by the loads two steps ahead).  CDC_PW_COUNTED_WAIT=1 brings the counted wait back for A/B.
+            if (s >= PD && s + R - 1 < S && s + 1 + PD < S && (P.dbg & 1024)) vm_wait<NWW + (PD - 1) * (L + NWW)>(); else dma_wait();
             __builtin_amdgcn_s_barrier();
             fetch_a(a_base + sn * WST, An);
             split_b(slot, Bn);
