@@ -114,7 +114,7 @@ struct Builder {
         if (m != 3) return false;
         // (round 4: up to 128 x 128 -- the Upsample half of a join is written as planes INSTEAD of fp32 when both of its readers take
         //  planes, join_reads_planes, so only the skip half costs a second copy: 256->64 @128^2 0.52 -> 0.37 ms on conv_pf3_kernel)
-        const long long join_max = dev_env("CDC_PF_JOIN_MAXPIX") ? atoll(dev_env("CDC_PF_JOIN_MAXPIX")) : 16384;
+        const long long join_max = 16384;
         return s == SITE_RB_CHAIN || s == SITE_DOWN || s == SITE_ALWAYS_PLANES || (s == SITE_JOIN && (long long)H * W <= join_max);
     }
     bool pf_on() const { return pf_mode() != 0; }

@@ -472,7 +472,7 @@ def test_unet_forward_matches_reference_golden(name):
 @pytest.mark.parametrize("name,env", [("full_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}), ("small_x", {"CDC_PF": "1", "CDC_PF_MAXPIX": "0"}),
                                       ("full_eps", {"CDC_PF": "1", "CDC_PF_MAXPIX": "16384"}),
                                       ("full_x", {"CDC_PF": "2"}), ("full_x", {"CDC_PF": "0"}), ("full_eps", {"CDC_PF": "2"}),
-                                      ("full_x", {"CDC_PF_JOIN_MAXPIX": "65536"}), ("full_x", {"CDC_PF_S2_MIN_WGS": "1"}),
+                                      ("full_x", {"CDC_PF_S2_MIN_WGS": "1"}),
                                       ("full_eps", {"CDC_PF_S2_MIN_WGS": "1"}), ("full_x", {"CDC_NO_PF_S2": "1"}),
                                       ("full_x", {"CDC_PF_TZ_MIN_WGS": "1"}), ("full_eps", {"CDC_PF_TZ_MIN_WGS": "1", "CDC_PF_S2_MIN_WGS": "1"}),
                                       ("full_x", {"CDC_NO_PF_TZ": "1"}),
@@ -974,6 +974,35 @@ def test_eps_param_256_matches_reference_digest_and_batch32_rows():
     rec32 = diff.decompress([np.repeat(c, B, 0) for c in ctx], (B, 3, H, W), sample_steps=steps, init=np.repeat(init, B, 0))
     for k in (0, 19, 31):
         assert relerr(rec32[k], rec1[0]) < 3e-5, (k, relerr(rec32[k], rec1[0]))
+
+
+def test_batch32_ddim_step_is_bit_reproducible():
+    """The same DDIM step of BASELINE configs[1] (batch 32, 256x256) executed 200 times gives the same bits: the model path has no atomics
+    and every summation order is fixed by the launch geometry.  (Round 5 found one launch that broke this about once in 10 000 executions on
+    some boxes -- conv_pw_kernel's counted LDS-DMA wait, profiles/determinism_r05.txt; tools/determinism_stress_steps.py is the long form of
+    this test with the localisation by taps.)"""
+    import ctypes
+    import torch
+    kw, man, sd, _, _, _, _ = load_case("full_x")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    B, S, steps = 32, 256, 500
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(78)
+    x = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8
+    ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5 for l, c in enumerate([64, 64, 128, 192])]
+    diff.set_sample_schedule(steps)
+    L, h = _lib.lib(), un._handle()
+    ptrs = (ctypes.c_void_p * len(ctx))(*[c.data_ptr() for c in ctx])
+    def step(i, out, with_ctx):
+        _lib.check(h, L.cdc_ddim_step(h, x.data_ptr(), i, ptrs if with_ctx else None, len(ctx) if with_ctx else 0, None, 0.0, out.data_ptr(),
+                                      B, S, S, diff._pred_flag(), diff._clip_flag(True), _lib.CDC_MEM_DEVICE, None))
+    ref, out = torch.empty_like(x), torch.empty_like(x)
+    step(250, ref, True)
+    for k in range(200):
+        step(250, out, False)
+        assert torch.equal(out, ref), k
 
 
 def test_configs1_full_length_batch32_rows_match_batch1_decodes():
