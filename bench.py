@@ -283,7 +283,22 @@ def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cf
         "class_tb_per_s": {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0) for k, v in classes.items()},
         "class_ms_per_ddim_iter": {k: v["ms"] / n_prof_iters for k, v in classes.items()},
     })
-    return out
+    # first-class scalars: the executed matrix rate of the dominant kernel against what THIS box's matrix pipe
+    # sustains on random operands, the measured ceilings themselves, the launches sampled
+    rnd = ceilings["mfma"].get("tflops_random_operands") if ceilings else None
+    out["frac_of_measured_sustained"] = (ach * products / rnd) if rnd else None
+    out["mfma_sustained_tflops_measured"] = rnd
+    out["hbm_copy_tb_s_measured"] = (ceilings["hbm"]["gb_per_s"] / 1e3) if ceilings else None
+    out["achieved_tb_s_algorithmic"] = alg_bytes / (dom_ms * 1e-3) / 1e12 if alg_bytes and dom_ms > 0 else None
+    out["sampled_iterations"] = n_prof_iters
+    # The driver's record keeps the scalar fields of this object in order and drops what is nested or comes late: numbers first,
+    # prose and tables last.
+    first = ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_key", "avg_launch_ms", "launches_per_iteration",
+             "ms_per_ddim_iter", "frac_of_measured_sustained", "mfma_sustained_tflops_measured", "hbm_copy_tb_s_measured",
+             "mfma_tflops_executed", "achieved_tb_s_algorithmic", "flops_per_launch", "algorithmic_bytes_per_launch",
+             "whole_path_tflops_canonical", "whole_path_mfma_frac_canonical", "whole_path_tflops_executed", "whole_path_mfma_frac_executed",
+             "whole_path_hbm_frac", "frac_of_f32_mfma_peak", "sampled_iterations", "kernel_source_hash", "traffic_kernel_source_hash"]
+    return {**{k: out[k] for k in first if k in out}, **{k: v for k, v in out.items() if k not in first}}
 
 
 def launches_per_iter(L, h):
@@ -366,13 +381,19 @@ def self_launch(n):
     rank to fail ends the others (by their PIDs); the exit code is that rank's."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # The ranks rendezvous through a FILE store (CDC_BENCH_STORE_FILE -> init_process_group(init_method="file://...")): a free port found
+    # by bind + close can be taken by another process before rank 0 binds it (ADVICE r5).  MASTER_ADDR / MASTER_PORT are still exported for
+    # anything that reads them, but nothing of this script listens there.
+    store_dir = tempfile.mkdtemp(prefix="cdc_bench_store_")
+    store = os.path.join(store_dir, "store")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CDC_BENCH_SELF_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CDC_BENCH_SELF_LAUNCHED="1", CDC_BENCH_STORE_FILE=store)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc, live = 0, list(procs)
     try:
@@ -391,7 +412,18 @@ def self_launch(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        import shutil
+        shutil.rmtree(store_dir, ignore_errors=True)
     return rc
+
+
+def init_pg(dist, backend, **kw):
+    """env:// under an external launcher; the launcher's file store when this script started its own ranks (self_launch)."""
+    store = os.environ.get("CDC_BENCH_STORE_FILE")
+    if store:
+        dist.init_process_group(backend, init_method="file://" + store, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]), **kw)
+    else:
+        dist.init_process_group(backend, **kw)
 
 
 def main():
@@ -412,7 +444,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational compressor / entropy coder legs (profiling runs)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the timed decodes of BASELINE configs[2] and configs[4]")
     ap.add_argument("--dump-ops", default=None, help="write the launch program's op labels (program order) to this file (profiling tools)")
-    ap.add_argument("--prof-every", type=int, default=50)
+    ap.add_argument("--prof-every", type=int, default=125,
+                    help="hipEvent pairs around every launch of the DDIM iterations i %% N == 0 (inside the timed region: roofline.sampling)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group, one all_reduce counts the ranks, rank 0 prints "
                          "{launch_check, ranks_seen, launcher}; no GPU work (CPU test of the self-launch path, gloo)")
@@ -429,7 +462,7 @@ def main():
         import torch.distributed as dist
         if int(os.environ.get("WORLD_SIZE", 1)) != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
-        dist.init_process_group("gloo")
+        init_pg(dist, "gloo")
         one = torch.ones(1)
         dist.all_reduce(one)
         if dist.get_rank() == 0:
@@ -455,9 +488,9 @@ def main():
     if use_dist:
         import torch.distributed as dist
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            init_pg(dist, "nccl", device_id=dev)
         else:
-            dist.init_process_group("gloo")
+            init_pg(dist, "gloo")
 
     un, diff, cfgd = build_model(a.param, local)
     B, S = a.batch, a.size
@@ -571,6 +604,31 @@ def main():
                                 "note": "one timed decode of the same batch, outside `value`"}
             del rec_alt
             _lib.check(h, L.cdc_set_arith(h, 1))
+        if world == 1:
+            # What the hipEvent sampling inside the timed region costs: the same short decode with every iteration
+            # instrumented and with none; the difference per instrumented iteration x the iterations `value` carried.
+            n_s = min(40, a.sample_steps)
+            def short(every):
+                L.cdc_prof_enable(h, every)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                decode_fn(init, ctx, steps=n_s)
+                torch.cuda.synchronize()
+                return time.perf_counter() - ts
+            short(0)
+            t_off = min(short(0), short(0))
+            t_on = min(short(1), short(1))
+            L.cdc_prof_enable(h, 0)
+            L.cdc_prof_reset(h)
+            per_iter = max(0.0, (t_on - t_off) / n_s)
+            n_inst = len([i for i in range(a.sample_steps) if i % max(2, a.prof_every) == 0]) * a.steps
+            out["roofline"]["sampling"] = {"instrumented_iterations": n_inst, "of": a.sample_steps * a.steps,
+                                           "ms_per_instrumented_iteration": per_iter * 1e3,
+                                           "frac_of_timed_region": per_iter * n_inst / dt,
+                                           "note": "hipEvent pairs around every launch of the DDIM iterations i % prof_every == 0, inside the "
+                                                   "timed region; cost = (a 40-iteration decode with every iteration instrumented - the same "
+                                                   "with none) / 40 x the instrumented iterations of the timed region"}
+            out["roofline"]["sampling_cost_frac"] = per_iter * n_inst / dt
         out["range_guard"] = _lib.handle_status(h)
         headline = world == 1 and a.param == "x" and B == 32 and S == 256 and a.sample_steps == 500
         if headline and not a.no_other_configs:
@@ -629,6 +687,26 @@ def main():
                                             "container, host bytes in/out; synthetic parameters, so the sizes say nothing about rate"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.param, S, a.sample_steps)
+        # The driver's record keeps `config` / `roofline` / `cpu_baseline` and drops other top-level keys: what the run measured beside
+        # the headline goes into `config` as flat scalars too (the full objects stay at top level for readers of the raw line).
+        c = out["config"]
+        if "verify" in out:
+            c["verify_ok"] = out["verify"].get("ok")
+            c["verify_max_rel_err_vs_batch1"] = out["verify"].get("max_rel_err_vs_batch1_decode")
+        if "batch1" in out:
+            c["batch1_ms_per_ddim_iter"] = out["batch1"]["ms_per_ddim_iter"]
+            c["batch1_images_per_s"] = out["batch1"]["images_per_s"]
+            c["batch1_launches_per_iter"] = out["batch1"]["launches_per_iter"]
+        if "alt_arith" in out:
+            c["alt_arith_bf16x3_images_per_s"] = out["alt_arith"]["value"]
+            c["alt_arith_bf16x3_ms_per_ddim_iter"] = out["alt_arith"]["ms_per_ddim_iter"]
+            c["alt_arith_bf16x3_max_rel_diff"] = out["alt_arith"]["max_rel_diff_vs_f16x2_decode"]
+        for tag, oc in zip(("configs2_eps_b32_1000", "configs4_x512_b16_500"), out.get("other_configs", [])):
+            c[tag + "_images_per_s"] = oc["value"]
+            c[tag + "_ms_per_ddim_iter"] = oc["ms_per_ddim_iter"]
+            c[tag + "_roofline_frac"] = oc["roofline"]["frac"]
+            c[tag + "_verify_ok"] = oc["verify"]["ok"]
+        c["range_faults"] = out["range_guard"].get("range_faults")
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

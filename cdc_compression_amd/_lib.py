@@ -133,6 +133,8 @@ def lib():
     L.cdc_op_conv_transpose2d.argtypes = [H, _vp, _vp, _vp, _vp] + [_i] * 5
     L.cdc_op_chan_layernorm.argtypes = [H, _vp, _vp, _vp, _vp, _i, _i, _i]
     L.cdc_op_linear_attention.argtypes = [H] + [_vp] * 7 + [_i] * 4
+    L.cdc_op_stress.argtypes = [H, _i]
+    L.cdc_op_stress_result.argtypes = [H, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     L.cdc_probe_mfma_f16.argtypes = [_i, _i, _i, ctypes.POINTER(ctypes.c_double)]
     L.cdc_probe_hbm_copy.argtypes = [_i, ctypes.c_size_t, _i, ctypes.POINTER(ctypes.c_double)]
     _lib = L
@@ -148,7 +150,8 @@ EXPORTS = ["cdc_create", "cdc_destroy", "cdc_last_error", "cdc_version", "cdc_nu
            "cdc_hyperdec_decode", "cdc_dequantize", "cdc_bpp", "cdc_encoder_create",
            "cdc_encoder_encode", "cdc_set_arith", "cdc_get_arith", "cdc_unet_tap", "cdc_prof_num_ops", "cdc_prof_op",
            "cdc_entropy_encode", "cdc_entropy_peek", "cdc_entropy_set_limit", "cdc_entropy_decode", "cdc_get_range_faults",
-           "cdc_get_nonfinite_results", "cdc_set_schedule_v", "cdc_probe_mfma_f16", "cdc_probe_hbm_copy"]
+           "cdc_get_nonfinite_results", "cdc_set_schedule_v", "cdc_probe_mfma_f16", "cdc_probe_hbm_copy",
+           "cdc_op_stress", "cdc_op_stress_result"]
 
 
 def handle_status(handle):

@@ -1620,6 +1620,21 @@ hipError_t nonfinite_launch(const float *x, long long bs, long long n, int B, in
     return hipGetLastError();
 }
 
+// cdc_op_stress (include/cdc_hip.h): does this execution's result equal the first one's, bit for bit?
+__global__ void __launch_bounds__(256) bits_differ_kernel(const unsigned *a, const unsigned *b, long long n, long long *c) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) bad |= a[i] != b[i];
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr((unsigned long long *)(c + 2), 1ull);
+}
+__global__ void bits_differ_tally_kernel(long long *c) { c[0] += 1; if (c[2]) { c[1] += 1; c[2] = 0; } }
+
+hipError_t bits_differ_launch(const float *a, const float *b, long long n, long long *counters, hipStream_t st) {
+    const int gx = (int)std::min<long long>((n + 255) / 256, 512);
+    hipLaunchKernelGGL(bits_differ_kernel, dim3(gx), dim3(256), 0, st, reinterpret_cast<const unsigned *>(a), reinterpret_cast<const unsigned *>(b), n, counters);
+    hipLaunchKernelGGL(bits_differ_tally_kernel, dim3(1), dim3(1), 0, st, counters);
+    return hipGetLastError();
+}
+
 // round_w_offset (utils.py:72-75): out = round(x - loc) + loc, torch.round = round-half-to-even = rintf
 __global__ void __launch_bounds__(256) dequantize_kernel(const float *x, const float *loc, float *out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

@@ -49,6 +49,10 @@ int run_op(cdc_handle *h, const Op &op, int B, hipStream_t st) {
         ea = get_event(h); eb = get_event(h);
         HIP_TRY(h, hipEventRecord(ea, st));
     }
+    // CDC_DEV_REPEAT=n (development, tools/trace_cold_hot.py): every launch n times in a row, so that a kernel trace shows each
+    // kernel cold (first launch: code, operands and argument block as the program leaves them) beside itself hot.
+    static const int nrep = [] { const char *e = dev_env("CDC_DEV_REPEAT"); return e ? std::max(1, atoi(e)) : 1; }();
+    for (int rep = 0; rep < nrep; ++rep)
     switch (op.kind) {
         case Op::CONV: HIP_TRY(h, conv_launch(op.conv, op.plan, B, op.nz, st)); break;
         case Op::CONVPF:

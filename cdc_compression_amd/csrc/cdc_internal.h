@@ -97,7 +97,7 @@ inline const char *dev_env(const char *name) {
         const char *e = ::getenv("CDC_DEV");
         if (e && atoi(e) != 0) return true;
         static const char *const user_level[] = {"CDC_DEV=", "CDC_ARITH=", "CDC_NO_RANGE_GUARD=", "CDC_GRAPH=", "CDC_DEBUG_PLAN=", "CDC_PROF_OPS=",
-                                                 "CDC_BENCH_", "CDC_TEST_", "CDC_SYNC_EACH_OP=", "CDC_HIP_LIB=", "CDC_NO_COMBINE_FUSE="};
+                                                 "CDC_BENCH_", "CDC_TEST_OBS=", "CDC_SYNC_EACH_OP=", "CDC_HIP_LIB=", "CDC_NO_COMBINE_FUSE="};
         for (char **v = environ; v && *v; ++v) {
             if (strncmp(*v, "CDC_", 4)) continue;
             bool user = false;
@@ -227,6 +227,8 @@ hipError_t bpp_launch(const float *qh, long long nh, int hw_h, const float *prio
                       const float *scale, long long nl, float inv_hw, float *bpp, int B, hipStream_t st);
 hipError_t clamp_min_launch(float *x, long long bs, long long n, float lo, int B, hipStream_t st);
 hipError_t nonfinite_launch(const float *x, long long bs, long long n, int B, int *flag, hipStream_t st);
+// cdc_op_stress: counters[0] += 1, counters[1] += (a[0..n) differs bitwise from b[0..n)); counters[2] is scratch
+hipError_t bits_differ_launch(const float *a, const float *b, long long n, long long *counters, hipStream_t st);
 hipError_t dequantize_launch(const float *x, const float *loc, float *out, long long n, hipStream_t st);
 hipError_t unfold_x_launch(const float *src, long long src_bs, float *dst, long long dst_bs, int C, int KW,
                            int pad, int H, int W, int B, hipStream_t st);

@@ -1413,6 +1413,22 @@ struct OpScope {                 // temporary device pool + op list for the cdc_
                 if (rc) return rc;
             }
         }
+        if (h->op_stress_n > 0) {      // cdc_op_stress: the program again and again, every result against the first, on the device
+            void *first = nullptr, *cnt = nullptr;
+            HIP_TRY(h, hipMalloc(&first, n * sizeof(float))); pool.push_back(first);
+            HIP_TRY(h, hipMalloc(&cnt, 3 * sizeof(long long))); pool.push_back(cnt);
+            HIP_TRY(h, hipMemsetAsync(cnt, 0, 3 * sizeof(long long), st));
+            HIP_TRY(h, hipMemcpyAsync(first, dev_out, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+            for (int k = 0; k < h->op_stress_n; ++k) {
+                for (const Op &op : h->ops) { rc = run_op(h, op, B, st); if (rc) return rc; }
+                HIP_TRY(h, bits_differ_launch(dev_out, (const float *)first, (long long)n, (long long *)cnt, st));
+            }
+            long long c[3] = {0, 0, 0};
+            HIP_TRY(h, hipStreamSynchronize(st));
+            HIP_TRY(h, hipMemcpy(c, cnt, sizeof c, hipMemcpyDeviceToHost));
+            h->op_stress_launches = c[0]; h->op_stress_differing = c[1];
+            dev_out = (const float *)first;           // the caller gets the FIRST execution's result
+        }
         HIP_TRY(h, hipStreamSynchronize(st));
         HIP_TRY(h, hipMemcpy(host_out, dev_out, n * sizeof(float), hipMemcpyDeviceToHost));
         return CDC_OK;
@@ -1596,6 +1612,21 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g, 
                             const float *w_qkv, const float *w_out, const float *b_out, float *y, int B,
                             int C, int H, int W) {
     return op_with_guard(h, [&] { return op_linear_attention_impl(h, x, norm_g, norm_b, w_qkv, w_out, b_out, y, B, C, H, W); });
+}
+
+int cdc_op_stress(cdc_handle *h, int repeats) {
+    if (!h) return CDC_ERR_INVALID;
+    if (repeats < 0) return fail(h, CDC_ERR_INVALID, "cdc_op_stress: repeats < 0");
+    h->op_stress_n = repeats;
+    h->op_stress_launches = h->op_stress_differing = 0;
+    return CDC_OK;
+}
+
+int cdc_op_stress_result(cdc_handle *h, int64_t *launches, int64_t *differing) {
+    if (!h) return CDC_ERR_INVALID;
+    if (launches) *launches = h->op_stress_launches;
+    if (differing) *differing = h->op_stress_differing;
+    return CDC_OK;
 }
 
 }  // extern "C"

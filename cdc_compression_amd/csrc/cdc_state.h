@@ -184,6 +184,8 @@ struct cdc_handle {
     hipEvent_t gev_in = nullptr, gev_out = nullptr;   // order the caller's stream around the graph stream
     int graph_key[4] = {0, 0, 0, 0};      // steps, pred_mode, clip, stream-independent program generation
     int time_steps_B = 0;
+    int op_stress_n = 0;                 // cdc_op_stress: extra executions of every cdc_op_* program, results compared on the device
+    long long op_stress_launches = 0, op_stress_differing = 0;
     // profiling
     bool prof = false;
     double prof_ms[PC_COUNT] = {0}, prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0};

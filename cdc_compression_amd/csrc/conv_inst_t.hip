@@ -30,6 +30,7 @@ ws_kernel_fn ws_lookup(int W, int NPB, int stride) {
 }  // namespace
 
 // Cin / C0 / Cout: channels (C0 = those of the first source, Cin when there is one); H x W: the map; B: batch the plan is made for.
+constexpr long long kWsMaxWgsDefault = 0;      // 0 = no bound
 bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, int stride, WsPlan *p) {
     if ((W != 8 && W != 16 && W != 32 && W != 64) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
     const int hw = H * W, groups = Cout / 32, nchunk = Cin / 16;
@@ -50,6 +51,13 @@ bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, int stride, Ws
         // 128-pixel tiles only where they leave at most a quarter of the chip idle; 64-pixel tiles below that
         if (npb == 4 && !force_npb && wgs < (3 * device_cus()) / 4) continue;
         if (wgs < min_wgs) return false;
+        // upper bound of a stride-1 launch (block() tries this kernel before the fused register-staged one for every map up to
+        // 64 wide that the plane-operand path did not take -- encoder / context-decoder programs, mid-size batches at 64 x 64).
+        // CDC_WS_MAX_WGS: A/B knob; the default is set from profiles/ws_cap_ab_r06.txt.
+        if (stride == 1 && !dev_env("CDC_WS_MIN_WGS")) {
+            const long long max_wgs = dev_env("CDC_WS_MAX_WGS") ? atoll(dev_env("CDC_WS_MAX_WGS")) : kWsMaxWgsDefault;
+            if (max_wgs > 0 && wgs > max_wgs) return false;
+        }
         if (stride == 2 && wgs > device_cus() && !dev_env("CDC_WS_MIN_WGS")) return false;     // (its one-workgroup-per-CU launches pay as a single round only)
         // K slices over the waves of the workgroup: up to 8 waves (two per SIMD: the kernel holds ~250 registers), equal shares;
         // two workgroups per CU when the launch has more than two per CU (LDS and registers then want <= 4 waves each)

@@ -83,6 +83,7 @@ hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     a.lin = p.lin;
+    if (const char *e = dev_env("CDC_PW_DBG")) a.dbg = atoi(e); else
     a.dbg = dev_env("CDC_PW_COUNTED_WAIT") ? 1024 : 0;  // (A/B: the counted s_waitcnt of round 4 instead of vmcnt(0) per step, conv_pw_kernel.h)
     dim3 grid((unsigned)(p.lin ? p.tiles_x : p.tiles_x * p.tiles_y * B), (unsigned)p.groups, 1);
     a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64) ? 1 : 0;

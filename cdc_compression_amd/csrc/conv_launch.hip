@@ -197,7 +197,6 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
     const int nb_rows = ceil_div(s.Ho, NBH);
     ConvPlan best;
     double best_score = -1;
-    // tuning aid: CDC_PLAN="MB,NPW,KC" (0 = free) restricts the candidates
     // fp32-exact products on the bf16 matrix cores where the layer is matrix-bound (k x k taps, >= 16
     // input channels, chunks aligned to the concat seam, 16-byte alignable rows)
     const bool split_ok = s.allow_split && (s.lnmode == 0 || s.lnmode == 1 || (s.lnmode == 2 && s.KH * s.KW == 1)) &&
@@ -234,7 +233,7 @@ bool conv_make_plan(const ConvShape &s, ConvPlan *plan) {
             ConvPlan p;
             p.split = 0;
             if (!try_plan(s, MB, NPW, lognbw, &p)) continue;
-            // measured (tools/gpu_conv_tune.py): register blocking matters more than the chunk depth
+            // measured (round 1, batch 32): register blocking matters more than the chunk depth
             // (MB2/NPW4/KC4 99 TF vs MB2/NPW2/KC8 91 TF; MB4/NPW2/KC4 103 TF vs KC8 with one WG/CU 91 TF)
             const double wgs = (double)p.tiles_x * p.tiles_y * s.B * p.groups;
             const double fill = std::min(1.0, wgs * p.WN / (256.0 * 4.0));

@@ -150,7 +150,7 @@ __device__ __forceinline__ void pf3_st2u(char *sbase, unsigned voff, unsigned a,
 // s_waitcnt vmcnt(N) that the residual rows depend on (so no use is scheduled above it)
 template <int N, int NB> __device__ __forceinline__ void pf3_wait_rows(f32x4 (&v)[NB][4]) {
     static_assert(NB >= 1 && NB <= 4, "blocks per wave tile");
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]) : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]) : "n"(N & kVmWaitMask) : "memory");
     if constexpr (NB > 1) asm volatile("" : "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]));
     if constexpr (NB > 2) asm volatile("" : "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]));
     if constexpr (NB > 3) asm volatile("" : "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3]));
@@ -159,7 +159,7 @@ template <int N, int NB> __device__ __forceinline__ void pf3_wait_rows(f32x4 (&v
 // the same for the half-units of a PF residual (kPf3ResPf)
 template <int N, int NB> __device__ __forceinline__ void pf3_wait_units(unsigned long long (&h)[NB][4], unsigned long long (&l)[NB][4]) {
     static_assert(NB >= 1 && NB <= 4, "blocks per wave tile");
-    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[0][2]), "+v"(h[0][3]), "+v"(l[0][0]), "+v"(l[0][1]), "+v"(l[0][2]), "+v"(l[0][3]) : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[0][2]), "+v"(h[0][3]), "+v"(l[0][0]), "+v"(l[0][1]), "+v"(l[0][2]), "+v"(l[0][3]) : "n"(N & kVmWaitMask) : "memory");
     if constexpr (NB > 1) asm volatile("" : "+v"(h[1][0]), "+v"(h[1][1]), "+v"(h[1][2]), "+v"(h[1][3]), "+v"(l[1][0]), "+v"(l[1][1]), "+v"(l[1][2]), "+v"(l[1][3]));
     if constexpr (NB > 2) asm volatile("" : "+v"(h[2][0]), "+v"(h[2][1]), "+v"(h[2][2]), "+v"(h[2][3]), "+v"(l[2][0]), "+v"(l[2][1]), "+v"(l[2][2]), "+v"(l[2][3]));
     if constexpr (NB > 3) asm volatile("" : "+v"(h[3][0]), "+v"(h[3][1]), "+v"(h[3][2]), "+v"(h[3][3]), "+v"(l[3][0]), "+v"(l[3][1]), "+v"(l[3][2]), "+v"(l[3][3]));

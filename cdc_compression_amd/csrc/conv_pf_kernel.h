@@ -32,7 +32,17 @@
 namespace cdc {
 
 
-template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Counted wait: the N newest vector-memory operations of the wave may stay in flight, everything older has completed.  This is
+// exact because a wave's vector-memory operations leave the counter in issue order on gfx9-class parts -- loads, stores and LDS-DMA
+// alike (it is the model hipcc's own s_waitcnt insertion uses on this target; tools/ubench/dma_order.hip: 6.5e9 counted waits with
+// cold / hot / mixed LDS-DMA pieces, both piece sizes and stores in flight, no piece found missing).
+// -DCDC_DMA_WAIT_ALL (A/B build, profiles/determinism_r06.txt): every counted wait of the plane-operand kernels becomes vmcnt(0).
+#ifdef CDC_DMA_WAIT_ALL
+constexpr int kVmWaitMask = 0;
+#else
+constexpr int kVmWaitMask = ~0;
+#endif
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N & kVmWaitMask) : "memory"); }
 
 // LDS-DMA with the destination in M0 (declared clobbered: no save / restore around every piece) and a 64-bit
 // scalar base + 32-bit per-lane byte offset.  The s_nop is the wait state between the M0 write and the DMA.

@@ -244,7 +244,14 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
             // pieces of a step (pixel block n = 1) about once in 10 000 launches on some boxes and never on others; waiting for
             // everything costs nothing measurable (11.9 ms per iteration either way: the step is bound by the matrix pipe and the
             // barrier, not by the loads two steps ahead).  CDC_PW_COUNTED_WAIT=1 brings the counted wait back for A/B.
-            if (s >= PD && s + R - 1 < S && s + 1 + PD < S && (P.dbg & 1024)) vm_wait<NWW + (PD - 1) * (L + NWW)>(); else dma_wait();
+            // Round 6 (profiles/determinism_r06.txt): the layer of the event reproduces it in isolation (tools/op_stress.py: 5 of 200 000
+            // executions differ with the counted wait, 0 with vmcnt(0)); CDC_PW_DBG bits beside 1024 are the arms of the localisation:
+            // 2048 = the counted wait with a margin of the NWW weight pieces that follow the needed activation pieces in the queue,
+            // 4096 = the counted wait followed by ~256 idle cycles before the barrier.
+            if (s >= PD && s + R - 1 < S && s + 1 + PD < S && (P.dbg & 1024)) {
+                if (P.dbg & 2048) vm_wait<(PD - 1) * (L + NWW)>(); else vm_wait<NWW + (PD - 1) * (L + NWW)>();
+                if (P.dbg & 4096) __builtin_amdgcn_s_sleep(4);
+            } else dma_wait();
             __builtin_amdgcn_s_barrier();
             fetch_a(a_base + sn * WST, An);
             split_b(slot, Bn);

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, 1) conv_split_kernel(const ConvArgs P) {
 
 // ------------------------------------------------------------------------------------------------
 // Variant for small channel groups (MB*NPW <= 4): two workgroups per CU.  The ablation of the kernel
-// above (tools/gpu_conv_tune.py, CDC_ABLATE) shows MFMA time 0.56 ms and everything else 0.61 ms with NO
+// above (round 2, profiles/HISTORY_r01_r04.md) shows MFMA time 0.56 ms and everything else 0.61 ms with NO
 // overlap at one wave per SIMD, so this variant shrinks the LDS footprint below 80 KiB: the fp32 patch
 // never touches LDS -- it is fetched global -> registers one chunk ahead (16-byte loads of the aligned
 // patch rows), split in registers and written straight into the three bf16 planes.  While one

@@ -53,13 +53,22 @@ struct Ev {
     ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
+// the probes run on `device` and leave the caller's current device as they found it
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int device) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 extern "C" {
 
 int cdc_probe_mfma_f16(int device, int random_operands, int iters, double *tflops) {
     if (!tflops || iters < 1) return CDC_ERR_INVALID;
-    if (hipSetDevice(device) != hipSuccess) return CDC_ERR_HIP;
+    DeviceScope ds(device);
+    if (!ds.ok) return CDC_ERR_HIP;
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, device) != hipSuccess) return CDC_ERR_HIP;
     float *d = nullptr;
@@ -92,7 +101,8 @@ int cdc_probe_mfma_f16(int device, int random_operands, int iters, double *tflop
 
 int cdc_probe_hbm_copy(int device, size_t bytes, int reps, double *gbytes_per_s) {
     if (!gbytes_per_s || bytes < (1u << 20) || reps < 1) return CDC_ERR_INVALID;
-    if (hipSetDevice(device) != hipSuccess) return CDC_ERR_HIP;
+    DeviceScope ds(device);
+    if (!ds.ok) return CDC_ERR_HIP;
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, device) != hipSuccess) return CDC_ERR_HIP;
     const long long n = (long long)(bytes / 16);

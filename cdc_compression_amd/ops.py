@@ -39,6 +39,17 @@ class Ops:
         """{"arith", "range_faults", "nonfinite_results"} of this handle (range guard of the fp16 arithmetic)."""
         return _lib.handle_status(self._h)
 
+    def stress(self, repeats):
+        """Every following operator call launches its program `repeats` more times and counts the executions whose result is not
+        bit-identical to the first one (on the device; include/cdc_hip.h: cdc_op_stress).  0 turns it off."""
+        _lib.check(self._h, _lib.lib().cdc_op_stress(self._h, int(repeats)))
+
+    def stress_result(self):
+        """(executions compared, executions that differed) of the last operator call."""
+        n, d = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._h, _lib.lib().cdc_op_stress_result(self._h, ctypes.byref(n), ctypes.byref(d)))
+        return n.value, d.value
+
     def prof(self, on=True):
         L = _lib.lib()
         L.cdc_prof_reset(self._h)

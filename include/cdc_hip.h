@@ -334,6 +334,14 @@ int cdc_op_linear_attention(cdc_handle *h, const float *x, const float *norm_g,
                             const float *norm_b, const float *w_qkv, const float *w_out,
                             const float *b_out, float *y, int B, int C, int H, int W);
 
+/* Determinism stress of the single-operator entry points (test infrastructure of the model path: it has no atomics and every
+ * summation order is fixed by the launch geometry, so a launch program must reproduce its own bits).  After
+ * cdc_op_stress(h, n), every cdc_op_* call launches its program n more times behind the first execution and counts the
+ * executions whose result differs bitwise from the first one -- all on the device, no host round trip per launch.
+ * cdc_op_stress_result returns the counts of the LAST cdc_op_* call.  n = 0 (default) turns it off. */
+int cdc_op_stress(cdc_handle *h, int repeats);
+int cdc_op_stress_result(cdc_handle *h, int64_t *launches, int64_t *differing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,3 +163,27 @@ def test_encoder_manifest_matches_reference_state_dict(name):
     m = getattr(cdc, meta["class"])(**meta["kwargs"])
     want = [(n, list(s)) for n, s in meta["manifest"] if n.startswith("enc.") or n.startswith("hyper_enc.")]
     assert [(n, list(s)) for n, s in m.encoder_manifest()] == want
+
+
+# ---- sanitizer build of the C-ABI ------------------------------------------------
+
+def test_c_abi_host_paths_under_address_sanitizer():
+    """`make asan` (csrc/Makefile: the host side of the C-ABI under AddressSanitizer, device code untouched) and one pass over the
+    life cycle and the error paths of every handle kind through it -- create / manifest / strict load / finalize / destroy, raw
+    C-ABI misuse, the entropy container parser on hostile bytes (tests/asan_driver.py).  Runs without a GPU: every compute call
+    must fail loudly there, not crash."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not shutil.which("make"):
+        pytest.skip("needs hipcc + make")
+    csrc = os.path.join(ROOT, "cdc_compression_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-j8", "asan"], stdout=subprocess.DEVNULL)
+    rt = subprocess.check_output([hipcc, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               CDC_HIP_LIB=os.path.join(ROOT, "cdc_compression_amd", "libcdc_hip_asan.so"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
