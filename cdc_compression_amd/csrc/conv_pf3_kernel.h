@@ -46,6 +46,14 @@ namespace cdc {
 #ifndef CDC_PF3_ABL
 #define CDC_PF3_ABL 0        // lab only (tools/ubench/pf_lab.hip): 1 no result stores, 2 no residual loads, 4 no LayerNorm math, 8 no LDS transposes, 16 no PF split
 #endif
+// Cache policy of the epilogue's result stores.  -DCDC_PF3_ST_WT: write-through to the memory side (sc1), so that the kernel leaves no dirty
+// lines for the end-of-kernel write-back -- A/B of round 6 (profiles/launch_floor_r06.txt: a boundary behind >= 16 MB of dirty lines costs
+// 3.4 - 3.7 us instead of 1.5).
+#ifdef CDC_PF3_ST_WT
+#define CDC_PF3_ST_POLICY " sc1"
+#else
+#define CDC_PF3_ST_POLICY ""
+#endif
 #ifndef CDC_PF3_D
 #define CDC_PF3_D 5          // weight stages are issued D steps ahead; ring = D + 2 slots (a slot is rewritten two steps after its last reader)
 #endif
@@ -134,7 +142,7 @@ __device__ __forceinline__ f32x4 pf3_ld4(const char *sbase, unsigned voff) {
 // hipcc inserts them for its own stores but does not look inside an asm statement -- without the s_nop the first dword
 // of a row piece was sporadically the NEXT value computed in that register)
 __device__ __forceinline__ void pf3_st4(char *sbase, unsigned voff, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2" CDC_PF3_ST_POLICY "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // (a 64-bit scalar, not a 2-vector: one virtual register that hipcc has no reason to take apart -- or copy -- before the data has landed)
@@ -145,7 +153,7 @@ __device__ __forceinline__ unsigned long long pf3_ld2(const char *sbase, unsigne
 }
 __device__ __forceinline__ void pf3_st2u(char *sbase, unsigned voff, unsigned a, unsigned b) {
     const u32x2 v = {a, b};
-    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, %2" CDC_PF3_ST_POLICY ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // s_waitcnt vmcnt(N) that the residual rows depend on (so no use is scheduled above it)
 template <int N, int NB> __device__ __forceinline__ void pf3_wait_rows(f32x4 (&v)[NB][4]) {

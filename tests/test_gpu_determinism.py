@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 REPEATS = 20000
 
-PF_ENV = {"CDC_PF": "1", "CDC_PF_MAXPIX": "0", "CDC_WS_MIN_WGS": "1000000000"}     # (the last: never the weight-stationary kernel)
+PF_ENV = {"CDC_PF": "1", "CDC_PF_MAXPIX": "0", "CDC_WS_MIN_WGS": "1000000000", "CDC_PF_MIN_WAVES": "1"}     # (never the weight-stationary kernel; small launches stay on the plane kernels)
 # (label, env, kind, case)   conv: (B, Cin, H, W, Cout, k, stride, pad, fused)   convT: (B, Cin, H, W, Cout)
 FAMILIES = [
     ("conv_pf3_kernel<2,2,1,4> 3x3 64ch persistent ping-pong", PF_ENV, "conv", (4, 64, 128, 256, 64, 3, 1, 1, True)),

@@ -33,7 +33,8 @@ template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_wai
 struct Rec { u32 step, piece, lane, got, want, kind, wave, wg; };
 __device__ __forceinline__ u32 rng(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
-// MODE bit 0: counted wait (else vmcnt(0));  bit 1: stores in flight;  bit 2: 4-byte activation pieces
+// MODE bit 0: counted wait (else vmcnt(0));  bit 1: stores in flight;  bit 2: 4-byte activation pieces;
+// bit 3: LDS read pressure (every wave reads 48 x 1 KiB of the workgroup's LDS per step with ds_read_b128, as the A / B operand fetches of the real kernels do)
 // addr: 0 = every piece cold (random 1-KiB place of the big buffer), 1 = hot (a 4-MiB window), 2 = one cold piece in eight
 template <int L, int NW, int MODE> __global__ void __launch_bounds__(256) k(const u32 *big, size_t big_words, const u32 *hot, u32 *sink, int steps, int addr,
                                                                             unsigned long long *bad, Rec *recs, u32 seed, int rowstride = 0) {
@@ -71,6 +72,15 @@ template <int L, int NW, int MODE> __global__ void __launch_bounds__(256) k(cons
 #pragma unroll
                 for (int q = 0; q < S; ++q) { u32x4 v = {sv, sv + 1, sv + 2, sv + 3}; asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(sink + ((size_t)wid * S + q) * 256 + lane * 4), "v"(v) : "memory"); }
             }
+        }
+        if constexpr (MODE & 8) {
+            u32x4 acc4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 48; ++q) acc4 += *reinterpret_cast<const u32x4 *>(lds + ((q * 977 + wave * 131 + step) & 4095) * 4 + 0 * lane);    // (same address in every lane: a broadcast read per instruction; 48 instructions)
+            sv += acc4[0] ^ acc4[3];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc4 += *reinterpret_cast<const u32x4 *>(lds + (((q * 613 + step) & 255) * 64 + lane) * 4);               // (16 full-width 1-KiB reads)
+            sv += acc4[1];
         }
         if (step == 0) continue;
         // activation pieces of step - 1: older than the (NW + S) + (L + NW + S) operations issued since
@@ -144,6 +154,9 @@ int main(int argc, char **argv) {
             snprintf(nm, sizeof nm, "L=4 NW=2, pieces of 8 rows 16 KiB apart, %s, vmcnt(0) control", an);   run<4, 2, 0>(nm, big, words, hot, sink, steps, addr, launches, 4096);
             snprintf(nm, sizeof nm, "L=4 NW=2, pieces of 8 rows 16 KiB apart, %s, COUNTED wait", an);       run<4, 2, 1>(nm, big, words, hot, sink, steps, addr, launches, 4096);
             snprintf(nm, sizeof nm, "L=4 NW=2, pieces of 8 rows 1 MiB apart, %s, COUNTED wait", an);        run<4, 2, 1>(nm, big, words, hot, sink, steps, addr, launches, 262144);
+            snprintf(nm, sizeof nm, "L=4 NW=2, 8 rows 16 KiB apart, %s, COUNTED wait + LDS read pressure", an);   run<4, 2, 9>(nm, big, words, hot, sink, steps, addr, launches, 4096);
+            snprintf(nm, sizeof nm, "L=4 NW=2, 8 rows 16 KiB apart, %s, vmcnt(0) + LDS read pressure", an);       run<4, 2, 8>(nm, big, words, hot, sink, steps, addr, launches, 4096);
+            snprintf(nm, sizeof nm, "L=4 NW=2, contiguous 1-KiB pieces, %s, COUNTED wait + LDS read pressure", an); run<4, 2, 9>(nm, big, words, hot, sink, steps, addr, launches, 0);
         }
         return 0;
     }
