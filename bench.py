@@ -604,7 +604,7 @@ def main():
                                 "note": "one timed decode of the same batch, outside `value`"}
             del rec_alt
             _lib.check(h, L.cdc_set_arith(h, 1))
-        if world == 1:
+        if world == 1 and not a.no_extras:
             # What the hipEvent sampling inside the timed region costs: the same short decode with every iteration
             # instrumented and with none; the difference per instrumented iteration x the iterations `value` carried.
             n_s = min(40, a.sample_steps)

@@ -4,6 +4,9 @@
 #include <string.h>
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdint.h>
 
 #include <string>
@@ -110,6 +113,22 @@ inline const char *dev_env(const char *name) {
         return false;
     }();
     return on ? ::getenv(name) : nullptr;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel, size) instead of once per launch: the plane-operand and
+// register-staged launchers asked for it in front of EVERY launch of a kernel with more than 64 KB of LDS (a host call per launch).
+inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &have = done[{dev, fn}];
+    if (have >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
 }
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -54,6 +54,8 @@ struct Builder {
             snprintf(buf, sizeof buf, "%s C=%d N=%d nsplit=%d", op.at_one ? "ctx1" : kinds[op.kind], op.at.C, op.at.N, op.at_one ? 1 : op.at.nsplit);
         else
             snprintf(buf, sizeof buf, "%s", kinds[op.kind]);
+        // every op of the context-only part of the program says so (the convolutions' formats above already do)
+        if (cur == &h->pre_ops && !strstr(buf, " HOIST") && strlen(buf) + 7 < sizeof buf) strcat(buf, " HOIST");
         h->op_label.push_back(buf);
         (cur ? cur : &h->ops)->push_back(op);
     }

@@ -204,10 +204,7 @@ hipError_t pf_launch(PfArgs a, const PfPlan &p, int B, int nz, hipStream_t st) {
     a.lognbw = 5;
     a.dbg = 0;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
-    if (p.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void *)fn, p.lds_bytes); e != hipSuccess) return e;
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)p.groups, (unsigned)nz);
     a.xcd_remap = (grid.x % 8 == 0 && grid.x >= 64) ? 1 : 0;
 #ifdef CDC_TIMELINE

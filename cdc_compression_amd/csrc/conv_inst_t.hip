@@ -30,7 +30,8 @@ ws_kernel_fn ws_lookup(int W, int NPB, int stride) {
 }  // namespace
 
 // Cin / C0 / Cout: channels (C0 = those of the first source, Cin when there is one); H x W: the map; B: batch the plan is made for.
-constexpr long long kWsMaxWgsDefault = 0;      // 0 = no bound
+constexpr long long kWsMaxWgsDefault = 2048;   // eight rounds of the chip; a bound of 1280 changes nothing measurable at batch 4 / 8 / 16 (3.366 / 4.785 / 7.107 against
+                                                // 3.363 / 4.793 / 7.094 ms per iteration, profiles/planner_ab_r06.txt): no measured crossover below the bound
 bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, int stride, WsPlan *p) {
     if ((W != 8 && W != 16 && W != 32 && W != 64) || H < 2 || (Cin % 16) || (C0 % 16) || (Cout % 32) || Cin < 32) return false;
     const int hw = H * W, groups = Cout / 32, nchunk = Cin / 16;
@@ -48,12 +49,13 @@ bool ws_make_plan(int Cin, int C0, int Cout, int H, int W, int B, int stride, Ws
         if (tot_px % tpx) continue;
         const int tiles = (int)(tot_px / tpx);
         const long long wgs = (long long)tiles * groups;
-        // 128-pixel tiles only where they leave at most a quarter of the chip idle; 64-pixel tiles below that
-        if (npb == 4 && !force_npb && wgs < (3 * device_cus()) / 4) continue;
+        // 128-pixel tiles from 5/8 of the chip's CUs on (round 6: the 320-channel layers of the 8 x 8 level at batch 32, 160 workgroups of 128
+        // pixels against 320 of 64: 12.02 / 12.02 against 12.06 / 12.05 ms per iteration, profiles/planner_ab_r06.txt); 64-pixel tiles below
+        if (npb == 4 && !force_npb && wgs < (5 * device_cus()) / 8) continue;
         if (wgs < min_wgs) return false;
         // upper bound of a stride-1 launch (block() tries this kernel before the fused register-staged one for every map up to
         // 64 wide that the plane-operand path did not take -- encoder / context-decoder programs, mid-size batches at 64 x 64).
-        // CDC_WS_MAX_WGS: A/B knob; the default is set from profiles/ws_cap_ab_r06.txt.
+        // CDC_WS_MAX_WGS: A/B knob (0 = no bound).
         if (stride == 1 && !dev_env("CDC_WS_MIN_WGS")) {
             const long long max_wgs = dev_env("CDC_WS_MAX_WGS") ? atoll(dev_env("CDC_WS_MAX_WGS")) : kWsMaxWgsDefault;
             if (max_wgs > 0 && wgs > max_wgs) return false;

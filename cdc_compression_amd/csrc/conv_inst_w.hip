@@ -78,10 +78,7 @@ hipError_t pw_launch(PfArgs a, const PfPlan &p, int B, hipStream_t st) {
     if (!fn) return hipErrorInvalidValue;
     a.lognbw = 5;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.B = B; a.ring = p.ring;
-    if (p.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void *)fn, p.lds_bytes); e != hipSuccess) return e;
     a.lin = p.lin;
     if (const char *e = dev_env("CDC_PW_DBG")) a.dbg = atoi(e); else
     a.dbg = dev_env("CDC_PW_COUNTED_WAIT") ? 1024 : 0;  // (A/B: the counted s_waitcnt of round 4 instead of vmcnt(0) per step, conv_pw_kernel.h)

@@ -271,12 +271,7 @@ hipError_t conv_launch(ConvArgs a, const ConvPlan &p, int B, int nz, hipStream_t
                         : (p.split ? conv_lookup_split(p.MB, p.NPW) : lookup(p.MB, p.NPW, p.lnmode));
     if (a.uf_c) fn = (p.split == 2 && p.arith && p.xu == 1 && p.lnmode == 0) ? conv_lookup_split2hu(p.MB, p.NPW) : nullptr;
     if (!fn) return hipErrorInvalidValue;
-    if (p.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)fn,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)p.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void *)fn, p.lds_bytes); e != hipSuccess) return e;
     dim3 grid((unsigned)(p.ipw > 1 ? ceil_div(B, p.ipw) : p.tiles_x * p.tiles_y * B), (unsigned)p.groups,
               (unsigned)(nz * a.ksplit));
     a.zfold = 0;

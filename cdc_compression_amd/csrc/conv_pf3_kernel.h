@@ -95,7 +95,7 @@ __host__ __device__ constexpr Pf3Ops pf3_ops_epi_sync(int nblk, int epv) {
 // Operations of this wave issued after the TARGET and before the wait point of step t (steps < 0: previous slot):
 // target = the weight DMA of step t + 1 - D (wweight) or the last patch piece of this slot, step KXW - 1 (!wweight).
 __host__ __device__ constexpr int pf3_younger(bool wwave, bool wweight, int KXW, int D, const Pf3Ops &prev, const Pf3Ops &cur, int t) {
-    const int ts = wweight ? t + 1 - D : KXW - 1;
+    const int ts = wweight ? t + 1 + CDC_DMA_WAIT_MARGIN - D : KXW - 1;     // (margin: the stage of the step after next as well -- one step earlier than its first reader needs it)
     int n = 0;
     for (int u = ts; u <= t; ++u) {
         const Pf3Ops &o = u < 0 ? prev : cur;

@@ -37,6 +37,13 @@ namespace cdc {
 // alike (it is the model hipcc's own s_waitcnt insertion uses on this target; tools/ubench/dma_order.hip: 6.5e9 counted waits with
 // cold / hot / mixed LDS-DMA pieces, both piece sizes and stores in flight, no piece found missing).
 // -DCDC_DMA_WAIT_ALL (A/B build, profiles/determinism_r06.txt): every counted wait of the plane-operand kernels becomes vmcnt(0).
+// CDC_DMA_WAIT_MARGIN (default 1 since round 6): the weight-stage waits of conv_pf_kernel / conv_pf3_kernel ask for one stage MORE than the
+// next reader needs.  Why: conv_pw_kernel's zero-margin counted wait on 16-byte LDS-DMA pieces let a wave read a piece that had not fully landed
+// once in ~10 000 launches (profiles/determinism_r06.txt); a margin of one stage cut that rate 20 - 40 fold there, and costs nothing here
+// (11.976 / 11.959 against 11.980 / 11.962 ms per iteration, batch 32, -DCDC_DMA_WAIT_MARGIN=0 is the round-5 form).
+#ifndef CDC_DMA_WAIT_MARGIN
+#define CDC_DMA_WAIT_MARGIN 1
+#endif
 #ifdef CDC_DMA_WAIT_ALL
 constexpr int kVmWaitMask = 0;
 #else
@@ -417,7 +424,7 @@ __global__ void __launch_bounds__(64 * WM * WP, (KH == 1 && KW == 7) ? 3 : STR =
                 }
             } else if (!TAIL || rem >= R - 2) {
                 // newer than W(s+1) in this wave's queue: W(s+2) .. W(s+R-2) = (R-3) stages
-                vm_wait<(R - 3) * NWW * TPS>();
+                vm_wait<(R - 3 - (R >= 5 ? CDC_DMA_WAIT_MARGIN : 0)) * NWW * TPS>();
             } else {
                 dma_wait();                               // tail of the tile: everything in flight is needed next
             }

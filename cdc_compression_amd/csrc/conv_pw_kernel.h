@@ -255,6 +255,26 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
             __builtin_amdgcn_s_barrier();
             fetch_a(a_base + sn * WST, An);
             split_b(slot, Bn);
+#ifdef CDC_PW_LATE_PROBE
+            // Lab build (tools/build_variant.sh pwprobe -DCDC_PW_LATE_PROBE, CDC_PW_DBG=9216): the same stage read AGAIN ~1000 cycles later, before
+            // its slot is requested anew.  A difference = a piece that landed AFTER the counted wait had released the wave.
+            if (P.dbg & 8192) {
+                __builtin_amdgcn_s_sleep(16);
+                OpsB Bt;
+                split_b(slot, Bt);
+                unsigned late = 0;
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) {
+                    bool d = false;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d |= (float)Bn[0][n][i] != (float)Bt[0][n][i] || (float)Bn[1][n][i] != (float)Bt[1][n][i];
+                    if (__any(d)) late |= 1u << n;
+                }
+                if (late && lane == 0)
+                    printf("[pw late piece] workgroup (%d,%d) wave %d step %d of %d: pixel-block mask %x differs between the read behind vmcnt(%d) and a read 1000 cycles later\n",
+                           (int)blockIdx.x, (int)blockIdx.y, wave, s + 1, S, late, NWW + (PD - 1) * (L + NWW));
+            }
+#endif
             if (s + 1 + PD < S) issue_x(s + 1 + PD, slot);
             if (s + R - 1 < S) issue_w();
         }

@@ -77,6 +77,7 @@ def main():
     ends = [i for i, r in enumerate(rows) if r[2].startswith("ddim_")]
     per_op = collections.defaultdict(list)
     n_ok = n_bad = 0
+    bad_at = None
     for a0, a1 in zip(ends[:-1], ends[1:]):
         seq = rows[a0 + 1:a1 + 1]
         if rows[a1][0] - rows[a0][1] > 5e8 or len(seq) < len(labels):     # a gap of the host (first iterations, graph capture): skip
@@ -85,9 +86,8 @@ def main():
         for lab in labels:
             pref, cnt = expect(lab)
             if i >= len(seq) or not seq[i][2].startswith(pref):
-                if lab.startswith("pfpack"):          # a pack of the context-only part of the program (once per decode): not in the iteration
-                    continue
                 ok = False
+                bad_at = (lab, seq[i][2] if i < len(seq) else "<end of iteration>")
                 break
             j = i + 1
             if cnt == 0:
@@ -105,6 +105,11 @@ def main():
             per_op[(k, lab, nk)].append(us)
     print(f"# {a.csv}: {len(rows)} dispatches, {len(ends)} sampler kernels, {n_ok} iterations matched to {len(labels)} op labels ({n_bad} not matched)")
     if not n_ok:
+        print(f"# first mismatch: op label '{bad_at[0]}' against dispatch '{bad_at[1][:100]}'" if bad_at else "# no complete iteration in the trace")
+        if len(ends) > 3:          # the kernel names of one iteration beside the labels, for the eye
+            seq = rows[ends[-3] + 1:ends[-2] + 1]
+            for k in range(max(len(seq), len(labels))):
+                print(f"{(seq[k][2][:60] if k < len(seq) else ''):62s} | {labels[k] if k < len(labels) else ''}")
         return 1
     tot = 0.0
     by_cls, by_lvl, by_lvl_n = collections.Counter(), collections.Counter(), collections.Counter()
