@@ -204,9 +204,9 @@ template <int COLS, int NP>
 __global__ void __launch_bounds__(256) ln_kernel_vec(const LnArgs a) {
     constexpr int CS = 256 / COLS, NV = 8 * kLnCache / CS;
     __shared__ float4 red[2][4][COLS];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = a.img_major ? blockIdx.x : blockIdx.y, bx = a.img_major ? blockIdx.y : blockIdx.x, tid = threadIdx.x;
     const int col = tid % COLS, cs = tid / COLS, wave = tid >> 6;
-    const int p = (blockIdx.x * COLS + col) * 4;
+    const int p = (bx * COLS + col) * 4;
     const bool pv = p < a.HW;
     const size_t base = (size_t)b * a.C * a.HW + (pv ? p : 0);
     const float *x = a.in + base;
@@ -350,10 +350,17 @@ hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st) {
         int cols = (long long)ceil_div(a.HW, 32) * B >= min_wgs ? 8 : ((long long)ceil_div(a.HW, 16) * B >= min_wgs ? 4 : 2);
         if (const char *e = dev_env("CDC_LN_VEC_COLS")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) cols = v; }
         if (a.nparts > 4) cols = 2;                   // (more than four slices exist for the 8-pixel form only)
-        const dim3 grid((unsigned)ceil_div(a.HW, 4 * cols), (unsigned)B);
-        if (cols == 8) ln_vec_launch<8>(a, grid, st);
-        else if (cols == 4) ln_vec_launch<4>(a, grid, st);
-        else ln_vec_launch<2>(a, grid, st);
+        // Narrow workgroups (8 / 16 pixels = 32 / 64 bytes of every 128-byte channel row) share each cache line with their neighbours of the
+        // same image.  Workgroups go to the XCDs round robin by linear id, and the eight L2s share nothing: with the image as the FAST grid
+        // dimension (and B a multiple of 8) all column blocks of an image run on ONE XCD, so a line is fetched from the memory side once
+        // instead of once per neighbour (round 6; CDC_LN_NO_IMG_MAJOR=1 brings the old order back for A/B).
+        LnArgs la = a;
+        la.img_major = (cols < 8 && B % 8 == 0 && a.HW > 4 * cols && !dev_env("CDC_LN_NO_IMG_MAJOR")) ? 1 : 0;
+        const unsigned nbx = (unsigned)ceil_div(a.HW, 4 * cols);
+        const dim3 grid = la.img_major ? dim3((unsigned)B, nbx) : dim3(nbx, (unsigned)B);
+        if (cols == 8) ln_vec_launch<8>(la, grid, st);
+        else if (cols == 4) ln_vec_launch<4>(la, grid, st);
+        else ln_vec_launch<2>(la, grid, st);
         return hipGetLastError();
     }
     if (a.C <= 8 * kLnCache) {

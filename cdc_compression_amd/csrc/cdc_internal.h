@@ -149,6 +149,7 @@ struct LnArgs {
     int nparts;               // > 1: `in` holds split-K partial sums, slice k at in + k*part_stride
     long long part_stride;
     int *fault;               // range guard (ConvArgs::fault): set to 1 when a pixel's statistics are not finite (may be null)
+    int img_major;            // set by ln_launch: blockIdx.x = image, blockIdx.y = pixel-column block (see there)
 };
 hipError_t ln_launch(const LnArgs &a, int B, hipStream_t st);
 

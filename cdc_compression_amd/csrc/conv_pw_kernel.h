@@ -256,10 +256,10 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
             fetch_a(a_base + sn * WST, An);
             split_b(slot, Bn);
 #ifdef CDC_PW_LATE_PROBE
-            // Lab build (tools/build_variant.sh pwprobe -DCDC_PW_LATE_PROBE, CDC_PW_DBG=9216): the same stage read AGAIN ~1000 cycles later, before
+            // Lab build (tools/build_variant.sh pwprobe -DCDC_PW_LATE_PROBE, CDC_PW_DBG=9216): the same stage read AGAIN right behind the first read's arithmetic, before
             // its slot is requested anew.  A difference = a piece that landed AFTER the counted wait had released the wave.
             if (P.dbg & 8192) {
-                __builtin_amdgcn_s_sleep(16);
+                if (P.dbg & 16384) __builtin_amdgcn_s_sleep(16);       // (with the pause the steady state shifts and the event itself goes away)
                 OpsB Bt;
                 split_b(slot, Bt);
                 unsigned late = 0;
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
                     if (__any(d)) late |= 1u << n;
                 }
                 if (late && lane == 0)
-                    printf("[pw late piece] workgroup (%d,%d) wave %d step %d of %d: pixel-block mask %x differs between the read behind vmcnt(%d) and a read 1000 cycles later\n",
+                    printf("[pw late piece] workgroup (%d,%d) wave %d step %d of %d: pixel-block mask %x differs between the read behind vmcnt(%d) and a second read\n",
                            (int)blockIdx.x, (int)blockIdx.y, wave, s + 1, S, late, NWW + (PD - 1) * (L + NWW));
             }
 #endif
