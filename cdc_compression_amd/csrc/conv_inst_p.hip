@@ -176,7 +176,7 @@ bool pf_make_plan(const PfShape &s, PfPlan *p) {
         // Few workgroups (small batches at the 64^2 / 32^2 levels): the register-staged kernel with split-K fills the
         // chip better (batch 1: 192->192 @64^2 0.032 ms against 0.09 here; 128->128 @128^2 with 128 workgroups: 0.07
         // against 0.038 -- the threshold sits between the two)
-        static const double min_waves = dev_env("CDC_PF_MIN_WAVES") ? atof(dev_env("CDC_PF_MIN_WAVES")) : 256.0;
+        const double min_waves = dev_env("CDC_PF_MIN_WAVES") ? atof(dev_env("CDC_PF_MIN_WAVES")) : 256.0;     // (read per plan: the tests switch it)
         if (wgs * NW < min_waves) continue;
         // (the 4-row 192-channel shape exists to fill the chip at batch 32; at batch 1 its 32 workgroups lose to the register-staged
         //  kernel with split-K: 192 -> 192 @64^2 0.054 against 0.032 ms)

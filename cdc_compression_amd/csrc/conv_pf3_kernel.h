@@ -25,7 +25,8 @@
 //     at weight chunk (slot mod nchunk) and walks the chunks cyclically (the sum over chunks is taken in a rotated
 //     order; fp32 accumulation, fixed per launch geometry -> deterministic);
 //   * the vector-memory issue pattern of a wave is completely static (patches are fetched in every slot, needed or
-//     not; the epilogue's loads / stores are template flags), so every s_waitcnt vmcnt(N) is a compile-time count;
+//     not; the epilogue's loads / stores are template flags), so every s_waitcnt vmcnt(N) is a compile-time count (a weight stage is
+//     awaited one step before its first reader needs it: CDC_DMA_WAIT_MARGIN, conv_pf_kernel.h);
 //   * the epilogue moves fp32 NCHW rows 16 bytes per lane (a 32-channel x 32-pixel block changes between the
 //     accumulator layout and the row layout through a private 4-KiB LDS
 //     region): 4 + 4 vector-memory instructions per block instead of 16 + 16; PF units as 8-byte halves (8 per block).

@@ -34,8 +34,9 @@ namespace cdc {
 
 // Counted wait: the N newest vector-memory operations of the wave may stay in flight, everything older has completed.  This is
 // exact because a wave's vector-memory operations leave the counter in issue order on gfx9-class parts -- loads, stores and LDS-DMA
-// alike (it is the model hipcc's own s_waitcnt insertion uses on this target; tools/ubench/dma_order.hip: 6.5e9 counted waits with
-// cold / hot / mixed LDS-DMA pieces, both piece sizes and stores in flight, no piece found missing).
+// alike (it is the model hipcc's own s_waitcnt insertion uses on this target; tools/ubench/dma_order.hip: 1e11 counted waits with
+// cold / hot / mixed LDS-DMA pieces, both piece sizes and stores in flight, no piece found missing).  What a counted wait
+// does NOT guarantee for a 16-byte piece is that the piece it just covered is readable in full at once: see CDC_DMA_WAIT_MARGIN below.
 // -DCDC_DMA_WAIT_ALL (A/B build, profiles/determinism_r06.txt): every counted wait of the plane-operand kernels becomes vmcnt(0).
 // CDC_DMA_WAIT_MARGIN (default 1 since round 6): the weight-stage waits of conv_pf_kernel / conv_pf3_kernel ask for one stage MORE than the
 // next reader needs.  Why: conv_pw_kernel's zero-margin counted wait on 16-byte LDS-DMA pieces let a wave read a piece that had not fully landed

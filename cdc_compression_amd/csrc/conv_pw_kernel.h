@@ -5,8 +5,9 @@
 // the two k-halves, 128-byte row segments of the fp32 NCHW tensor), into a private LDS area PD steps ahead; the lane
 // reads its 8 values back, subtracts the PreNorm mean if there is one and splits into the two fp16 planes in registers.
 // No patch, no conversion pass, no ds_write, and no barrier for the activations (a wave only ever reads what it
-// requested itself: its own s_waitcnt suffices).  All vector-memory operations of the main loop are LDS-DMA, so the
-// counted s_waitcnt vmcnt is exact: per step a wave issues L = 8*NPW activation pieces, then its NWW weight pieces.
+// requested itself: its own s_waitcnt suffices).  Per step a wave issues L activation pieces, then its NWW weight pieces, and waits for
+// ALL of them a step later (vmcnt 0; a counted wait that lets exactly the newer operations fly is in-order exact, but a 16-byte piece it
+// has just covered is not always readable in full at once: see the step lambda and DESIGN section 5).
 // The weights go through the LDS-DMA ring of conv_pf_kernel.h (every wave issues its share of a stage, one s_barrier
 // per 16-channel step), shared by the WM x WP waves; shapes with MB*NPW <= 4 use the planes {WH, WL} and a second
 // accumulator set.  Epilogue: scale (2^-s, x rstd of the pixel with PreNorm), bias, hoisted partial sums, ReLU,
@@ -237,17 +238,17 @@ __global__ void __launch_bounds__(64 * WM * WP, WM * WP == 8 ? 1 : 2) conv_pw_ke
         constexpr int slot = decltype(slotc)::value;    // (s + 1) % PD, compile-time: PD == 2
         if (s + 1 < S) {
             if (++sn == R) sn = 0;
-            // Round 5: every step waits for ALL of the wave's LDS-DMA (vmcnt 0), not for a counted prefix.  The counted wait
-            // (vmcnt <= NWW + (PD - 1)(L + NWW): everything newer than the activation pieces of step s + 1) assumed that the pieces of a
-            // wave complete in issue order.  A one-step-at-a-time determinism stress (tools/determinism_stress_steps.py) found the k/v
-            // projection of the 64x64 level (192 -> 384, three channel groups) returning stale values in the LAST-issued activation
-            // pieces of a step (pixel block n = 1) about once in 10 000 launches on some boxes and never on others; waiting for
-            // everything costs nothing measurable (11.9 ms per iteration either way: the step is bound by the matrix pipe and the
-            // barrier, not by the loads two steps ahead).  CDC_PW_COUNTED_WAIT=1 brings the counted wait back for A/B.
-            // Round 6 (profiles/determinism_r06.txt): the layer of the event reproduces it in isolation (tools/op_stress.py: 5 of 200 000
-            // executions differ with the counted wait, 0 with vmcnt(0)); CDC_PW_DBG bits beside 1024 are the arms of the localisation:
-            // 2048 = the counted wait with a margin of the NWW weight pieces that follow the needed activation pieces in the queue,
-            // 4096 = the counted wait followed by ~256 idle cycles before the barrier.
+            // Every step waits for ALL of the wave's LDS-DMA (vmcnt 0), not for a counted prefix (round 5).  The counted wait -- vmcnt <=
+            // NWW + (PD - 1)(L + NWW): exactly the operations newer than the activation pieces of step s + 1 -- returned stale values in the
+            // LAST-issued 16-byte activation pieces of a step about once in 10 000 launches on some boxes (the k/v projection of the 64x64
+            // level, 192 -> 384, three channel groups).  Waiting for everything costs nothing measurable here (the step is bound by the matrix
+            // pipe and the barrier, not by the loads two steps ahead).
+            // Round 6 (profiles/determinism_r06.txt): the layer alone reproduces it (tools/op_stress.py: 61 - 116 of 400 000
+            // executions differ with the counted wait, 0 with vmcnt(0)); a wave's operations DO leave vmcnt in issue order (tools/ubench/
+            // dma_order.hip), but with global_load_lds_dwordx4 the counter can reach N a short time before the last-issued needed piece is
+            // readable in full.  CDC_PW_DBG (development) selects the arms of that localisation: 1024 = the counted wait, + 2048 = with a margin
+            // of the NWW weight pieces that follow the needed pieces in the queue (3 events), + 4096 = followed by ~256 idle cycles (4 events);
+            // with 4-byte pieces (CDC_NO_PW_X16) the counted wait shows none.
             if (s >= PD && s + R - 1 < S && s + 1 + PD < S && (P.dbg & 1024)) {
                 if (P.dbg & 2048) vm_wait<(PD - 1) * (L + NWW)>(); else vm_wait<NWW + (PD - 1) * (L + NWW)>();
                 if (P.dbg & 4096) __builtin_amdgcn_s_sleep(4);
