@@ -211,7 +211,7 @@ def roofline_block(classes, ops, B, S, arith, value, sample_steps, steps, dt, cf
     exec_gflop_iter = sum(c["flops"] for c in classes.values()) / n_prof_iters / 1e9     # per batch iteration
     exec_tf = exec_gflop_iter * 1e-3 / B * sample_steps * value
     # Counter-based HBM traffic of the dominant pair, if PMC passes of THIS round's build were committed for it
-    # (tools/gpu_profiles_r05.sh -> profiles/pmc_r05_traffic.json: {op label: {...}}, per-dispatch FETCH_SIZE / WRITE_SIZE of the
+    # (tools/gpu_profiles_r06.sh -> profiles/pmc_r06_traffic.json: {op label: {...}}, per-dispatch FETCH_SIZE / WRITE_SIZE of the
     # whole-path passes matched to the launch program's op labels).  `traffic` is the mean over the SAME launches that
     # `algorithmic_bytes_per_launch` averages (every epilogue variant of the pair), so the two figures compare like with like.
     traffic, traffic_src, traffic_variants, traffic_hash = None, None, None, None

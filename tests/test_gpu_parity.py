@@ -22,7 +22,7 @@ TOL = 1e-4         # north_star's statement.  The test bounds below are ~3x what
 TOL_FWD = 1e-5     #   one U-Net / compressor forward (or a stage of it) against the reference golden: measured <= 3.0e-6
 TOL_DEC = 5e-5     #   a few-step / full-length decode chain against the reference golden: measured <= 2.1e-5
 # (CDC_TEST_OBS=<file>: every relerr() of a run is appended there with its test id -- how the bounds were measured;
-#  tools/gpu_profiles_r05.sh, summary under profiles/parity_obs_r05.txt)
+#  tools/gpu_profiles_r06.sh, summary under profiles/parity_obs_r06.txt)
 
 
 def relerr(a, ref):

@@ -3,6 +3,7 @@
 # without event pairs, A/B of the build variants (write-through stores of conv_pf3_kernel, wait margins), the long-form determinism test,
 # the long stress of the plane-operand kernels.
 set -u
+# (build the variants first: tools/build_variant.sh pf3wt -DCDC_PF3_ST_WT; margin -DCDC_DMA_WAIT_MARGIN=1 [=0 is the round-5 form now]; margin6 "... -DCDC_PF3_D=6")
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r06b; mkdir -p $OUT
 cd $R
 CDC_DEV=1 CDC_PW_DBG=1024 timeout 300 python tools/op_stress.py 32 192 64 64 384 1 1 0 150000 2>&1 | grep -v amdgpu.ids | tee $OUT/box_indicator.txt
