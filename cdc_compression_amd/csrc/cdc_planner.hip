@@ -553,7 +553,12 @@ struct Builder {
         // per-image attention products everywhere); at 16x16 and batch 32 the wide folded-PreNorm projections (24 - 36 channel groups, each
         // converting the same activations again) and the res_convs are faster on conv_pw_kernel's 64 - 96-channel workgroups.
         const long long blocks = (long long)pb() * (H * W / 32);
-        if (blocks > 128 && !(o.wsp_bs && W < 32)) return false;     // (per-image products of the few-pixel levels at any batch)
+        // (CDC_WS1_MAX_BLOCKS / CDC_WS1_MAX_GROUPS: A/B knobs of round 6 -- layers with few channel groups at up to 256 pixel blocks,
+        //  profiles/planner_ab_r06.txt)
+        const long long max_blocks = dev_env("CDC_WS1_MAX_BLOCKS") ? atoll(dev_env("CDC_WS1_MAX_BLOCKS")) : 128;
+        const int max_groups_wide = dev_env("CDC_WS1_MAX_GROUPS") ? atoi(dev_env("CDC_WS1_MAX_GROUPS")) : 0;
+        const bool wide_ok = blocks <= max_blocks || (max_groups_wide > 0 && blocks <= 256 && w.Cout / 32 <= max_groups_wide);
+        if (!wide_ok && !(o.wsp_bs && W < 32)) return false;     // (per-image products of the few-pixel levels at any batch)
         Op op;
         op.kind = Op::CONVWS1; op.prof = prof;
         if (!ws1_make_plan(w.Cin, s1 ? C0 : w.Cin, w.Cout, H * W, pb(), o.wsp_bs != 0, &op.ws1plan)) return false;
