@@ -187,3 +187,22 @@ def test_c_abi_host_paths_under_address_sanitizer():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py")], env=env, capture_output=True, text=True, timeout=600)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_bench_roofline_object_leads_with_its_scalars():
+    """The driver's record keeps the scalar fields of `roofline` in order and drops what is nested or late: numbers first,
+    `frac_of_measured_sustained` and the measured ceilings among them; tables and prose behind."""
+    import bench
+    ops = [dict(label="conv 3x3 s1   64->64   out 256x256 MB2 NPW2 WM1 WP4 g1 R5 PF3 LN nof32 +pf", ms=0.41, n=4, flops=154.6e9),
+           dict(label="conv 3x3 s1   64->64   out 256x256 MB2 NPW2 WM1 WP4 g1 R5 PF3 LN +resP", ms=0.48, n=4, flops=154.6e9),
+           dict(label="conv 1x1 s1   64->64   out 256x256 MB2 NPW2 WM1 WP4 g1 R6 PW pre nof32 +pf +res", ms=0.29, n=4, flops=17.2e9)]
+    classes = {k: dict(ms=1.0, launches=4, flops=1e11, bytes=1e9) for k in ("conv3x3", "conv1x1", "layernorm")}
+    ceil = {"mfma": {"tflops_random_operands": 1500.0, "tflops_constant_operands": 2400.0}, "hbm": {"gb_per_s": 4900.0}}
+    r = bench.roofline_block(classes, ops, 32, 256, 1, 5.3, 500, 1, 6.0, bench.FULL["x"], 125, ceilings=ceil)
+    keys = list(r)
+    assert keys[:5] == ["bound", "achieved", "peak", "unit", "frac"]
+    lead = keys[:keys.index("launches")]
+    assert {"traffic", "frac_of_measured_sustained", "mfma_sustained_tflops_measured", "hbm_copy_tb_s_measured", "whole_path_tflops_canonical"} <= set(lead)
+    assert all(not isinstance(r[k], (dict, list)) for k in lead)
+    assert abs(r["frac_of_measured_sustained"] - r["mfma_tflops_executed"] / 1500.0) < 1e-9
+    assert r["kernel"] == "conv_pf3_kernel" and r["launches_per_iteration"] == 2
