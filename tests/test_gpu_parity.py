@@ -1030,6 +1030,43 @@ def test_configs1_full_length_batch32_rows_match_batch1_decodes():
     assert un.status() == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}
 
 
+def _full_length_rows_against_batch1(diff, un, ctx_channels, B, S, steps, rows, seed):
+    import torch
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    init = torch.randn((B, 3, S, S), generator=gen, device=dev) * 0.8
+    ctx = [torch.randn((B, c, S >> l, S >> l), generator=gen, device=dev) * 0.5 for l, c in enumerate(ctx_channels)]
+    rec = diff.decompress(ctx, (B, 3, S, S), sample_steps=steps, init=init)
+    assert bool(torch.isfinite(rec).all().item())
+    assert float((rec[rows[0]] - rec[rows[1]]).abs().max().item()) > 0.05          # the rows really are different images
+    for k in rows:
+        r1 = diff.decompress([c[k:k + 1] for c in ctx], (1, 3, S, S), sample_steps=steps, init=init[k:k + 1])
+        e = relerr(r1[0].cpu().numpy(), rec[k].cpu().numpy())
+        assert e < TOL_DEC, (k, e)
+    assert un.status() == {"arith": 1, "range_faults": 0, "nonfinite_results": 0}
+
+
+def test_configs2_full_length_eps_batch32_rows_match_batch1_decodes():
+    """BASELINE configs[2] at full length and full batch inside pytest (bench.py's other_configs does the same outside
+    it): eps-param, batch 32 of distinct images, 256x256, all 1000 DDIM iterations without clipping on the batch-32 launch program, then
+    rows 0 / 13 / 31 on their own with the batch-1 program.  Measured by bench.py's verify: 5.8e-6."""
+    kw, man, sd, _, _, _, _ = load_case("full_eps")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    diff = cdc.GaussianDiffusionEps(un, None, num_timesteps=20000, clip_noise="none", pred_mode="noise", var_schedule="linear")
+    _full_length_rows_against_batch1(diff, un, [3, 64, 128, 192], 32, 256, 1000, (0, 13, 31), 79)
+
+
+def test_configs4_full_length_512_batch16_rows_match_batch1_decodes():
+    """BASELINE configs[4] at full length and full batch inside pytest: x-param, batch 16 of distinct images, 512x512, all 500 DDIM
+    iterations, rows 0 / 9 / 15 against batch-1 decodes.  Measured by bench.py's verify: 8.6e-6."""
+    kw, man, sd, _, _, _, _ = load_case("full_x")
+    un = cdc.Unet(**kw)
+    un.load_state_dict(sd)
+    diff = cdc.GaussianDiffusionX(un, None, None, num_timesteps=8193, pred_mode="x", var_schedule="cosine")
+    _full_length_rows_against_batch1(diff, un, [64, 64, 128, 192], 16, 512, 500, (0, 9, 15), 80)
+
+
 TAPS = ["downs.0.0", "downs.0.2", "downs.1.3", "mid_block1", "ups.0"]
 
 
