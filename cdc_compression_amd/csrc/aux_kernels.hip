@@ -503,13 +503,16 @@ __global__ void __launch_bounds__(256) ctx_partial_kernel(const float *k, const 
                                                           long long kv_bs, int C, int N,
                                                           const float *kmax, float *S, float *Zp,
                                                           int nsplit, int tiles, float scale = 0.f, float *ctxw = nullptr,
-                                                          int Cin_pad = 0, int COP = 0, unsigned short *Ws = nullptr) {
+                                                          int Cin_pad = 0, int COP = 0, unsigned short *Ws = nullptr, int img_major = 0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // 2 stages x (k 64x64 + v 64x64)
     __shared__ float rows_s[4 * 64];                               // ONE: row maxima, then the waves' row sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dt = blockIdx.x / tiles, et = blockIdx.x % tiles;
-    const int split = blockIdx.y, b = blockIdx.z;
+    // img_major (ctx_one_launch): the image is the fast grid dimension, so that the tiles^2 workgroups of an image -- every k row block is read by
+    // `tiles` of them, every v row block too -- run on ONE XCD and meet in its L2 (workgroups go to the XCDs round robin by linear id)
+    const int tile = img_major ? blockIdx.z : blockIdx.x;
+    const int dt = tile / tiles, et = tile % tiles;
+    const int split = blockIdx.y, b = img_major ? blockIdx.x : blockIdx.z;
     const int d0 = dt * 64, e0 = et * 64;
     const int nps = round_up(ceil_div(N, nsplit), kCtxPch);
     const int n_begin = split * nps;
@@ -761,12 +764,14 @@ hipError_t ctx_one_launch(const float *k, const float *v, long long kv_bs, int C
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    const int img_major = (tiles > 1 && B % 8 == 0 && !dev_env("CDC_CTX_NO_IMG_MAJOR")) ? 1 : 0;      // (round 6; the switch: A/B)
+    const dim3 grid = img_major ? dim3((unsigned)B, 1, (unsigned)(tiles * tiles)) : dim3((unsigned)(tiles * tiles), 1, (unsigned)B);
     if (f16)
-        hipLaunchKernelGGL((ctx_partial_kernel<true, true>), dim3(tiles * tiles, 1, B), dim3(256), lds, st, k, v, kv_bs, C, N, nullptr, nullptr, nullptr, 1, tiles, scale,
-                           ctxw, Cin_pad, COP, Ws);
+        hipLaunchKernelGGL((ctx_partial_kernel<true, true>), grid, dim3(256), lds, st, k, v, kv_bs, C, N, nullptr, nullptr, nullptr, 1, tiles, scale,
+                           ctxw, Cin_pad, COP, Ws, img_major);
     else
-        hipLaunchKernelGGL((ctx_partial_kernel<false, true>), dim3(tiles * tiles, 1, B), dim3(256), lds, st, k, v, kv_bs, C, N, nullptr, nullptr, nullptr, 1, tiles, scale,
-                           ctxw, Cin_pad, COP, Ws);
+        hipLaunchKernelGGL((ctx_partial_kernel<false, true>), grid, dim3(256), lds, st, k, v, kv_bs, C, N, nullptr, nullptr, nullptr, 1, tiles, scale,
+                           ctxw, Cin_pad, COP, Ws, img_major);
     return hipGetLastError();
 }
 
@@ -789,12 +794,15 @@ hipError_t ctx_partial_launch(const float *k, const float *v, long long kv_bs, i
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    // (image-major as in ctx_one_launch: the tiles of an image and split share its k / v row blocks)
+    const int img_major = (tiles > 1 && B % 8 == 0 && !dev_env("CDC_CTX_NO_IMG_MAJOR")) ? 1 : 0;
+    const dim3 grid = img_major ? dim3((unsigned)B, (unsigned)nsplit, (unsigned)(tiles * tiles)) : dim3((unsigned)(tiles * tiles), (unsigned)nsplit, (unsigned)B);
     if (f16)
-        hipLaunchKernelGGL(ctx_partial_kernel<true>, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
-                           kv_bs, C, N, kmax, S, Zp, nsplit, tiles);
+        hipLaunchKernelGGL(ctx_partial_kernel<true>, grid, dim3(256), lds, st, k, v,
+                           kv_bs, C, N, kmax, S, Zp, nsplit, tiles, 0.f, nullptr, 0, 0, nullptr, img_major);
     else
-        hipLaunchKernelGGL(ctx_partial_kernel<false>, dim3(tiles * tiles, nsplit, B), dim3(256), lds, st, k, v,
-                           kv_bs, C, N, kmax, S, Zp, nsplit, tiles);
+        hipLaunchKernelGGL(ctx_partial_kernel<false>, grid, dim3(256), lds, st, k, v,
+                           kv_bs, C, N, kmax, S, Zp, nsplit, tiles, 0.f, nullptr, 0, 0, nullptr, img_major);
     return hipGetLastError();
 }
 
